@@ -1208,6 +1208,7 @@ class SAC_Base(AuxHeadsMixin):
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('policy'))
         self.optimizer_policy.step()
         with torch.no_grad():
+            self._stats['loss_policy'].copy_(loss.detach())
             if self.d_action_sizes:
                 self._stats['d_entropy'].copy_(torch.mean(d_policy.entropy().sum(-1) / self.d_action_branch_size))
             if self.c_action_size:
@@ -1570,15 +1571,18 @@ class SAC_Base(AuxHeadsMixin):
         return self.increase_global_step()
 
     @torch.no_grad()
-    def _refresh_policy_stats(self) -> None:
+    def _refresh_policy_stats(self, log_c_alpha: torch.Tensor | None = None) -> None:
         """The stock policy step forms its gradients on chip and leaves the logged statistics (policy
-        objective, Gaussian entropy) to be computed here, on demand, from the step's buffers."""
+        objective, Gaussian entropy) to be computed here, on demand, from the step's buffers.  The objective
+        is weighted by the temperature: by default the current one (already moved by the step's temperature
+        update, which is what a log line sees); `log_c_alpha` = the value the policy step itself used."""
         if self._pi_stats_src is None:
             return
         logp, scale = self._pi_stats_src
         E, Es = self.ensemble_q_num, self.ensemble_q_sample
         native.policy_loss_fwd_bwd(logp, self._pi_q.view(E, -1), self._subsets['pi_c'] if Es != E else None, Es,
-                                   self.log_c_alpha, scale, self._stats['loss_policy'],
+                                   self.log_c_alpha if log_c_alpha is None else log_c_alpha, scale,
+                                   self._stats['loss_policy'],
                                    torch.empty_like(self._grad_logp), torch.empty_like(self._grad_q),
                                    self._stats['c_entropy'])
 

@@ -239,6 +239,17 @@ class SacRef:
             d['model_inverse_dynamic'] = self.model_inverse_dynamic
         return d
 
+    def named_optimizers(self) -> dict:
+        """named like the reference's ckpt_dict (sac_base.py:493-566)"""
+        d = {'optimizer_rep': self.optimizer_rep, 'optimizer_policy': self.optimizer_policy}
+        for i in range(self.E):
+            d[f'optimizer_q_{i}'] = self.optimizer_q_list[i]
+        if self.use_auto_alpha:
+            d['optimizer_alpha'] = self.optimizer_alpha
+        if self.curiosity is not None:
+            d['optimizer_curiosity'] = self.optimizer_curiosity
+        return {k: v for k, v in d.items() if v is not None}
+
     # -- sac_base.py:745-764 ---------------------------------------------------------------------
     @torch.no_grad()
     def update_target(self, tau):
@@ -402,6 +413,7 @@ class SacRef:
         self.optimizer_policy.step()
         d_ent = torch.mean(d_policy.entropy().sum(-1) / self.d_branches).detach() if self.d_action_sizes else None
         c_ent = torch.mean(masked_sum_entropy(c_policy.entropy())).detach() if self.c_action_size else None
+        self.last_loss_policy = loss.detach()
         return d_ent, c_ent
 
     # -- sac_base.py:1913-1949 -------------------------------------------------------------------
@@ -522,7 +534,7 @@ class SacRef:
 
         # write-backs, sac_base.py:2558-2605
         out = dict(ids=ids, is_weights=is_w, loss_q=loss_q, d_entropy=d_ent, c_entropy=c_ent,
-                   loss_curiosity=loss_cur, padding_mask=batch['padding_mask'].numpy().copy(),
+                   loss_policy=self.last_loss_policy, loss_curiosity=loss_cur, padding_mask=batch['padding_mask'].numpy().copy(),
                    index=batch['index'].numpy().copy())
         bn_states = bnx_states[:, :-1]
         pi_probs = None

@@ -306,9 +306,14 @@ def gen_episode(rng, obs_shapes, d_action_sizes, c_action_size, hidden_shape, T)
         parts.append(np.eye(s, dtype=np.float32)[rng.integers(0, s, T)])
     if c_action_size:
         parts.append(rng.random((T, c_action_size)).astype(np.float32))
+    def obs(s):   # images are k/255 (8-bit pixels widened to f32), so fixtures can keep them as uint8
+        if len(s) == 3:
+            return rng.integers(0, 256, (1, T, *s)).astype(np.uint8).astype(np.float32) / np.float32(255.)
+        return rng.standard_normal((1, T, *s)).astype(np.float32)
+
     return dict(
         ep_indexes=np.arange(T, dtype=np.int32)[None],
-        ep_obses_list=[rng.standard_normal((1, T, *s)).astype(np.float32) for s in obs_shapes],
+        ep_obses_list=[obs(s) for s in obs_shapes],
         ep_actions=np.concatenate(parts, -1)[None],
         ep_rewards=rng.standard_normal((1, T)).astype(np.float32),
         ep_dones=(rng.random((1, T)) < 0.5),
@@ -342,7 +347,12 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
         for k, v in ep.items():
             if k == 'ep_obses_list':
                 for j, o in enumerate(v):
-                    out[f'ep{i}/obs_{j}'] = o
+                    if o.ndim == 5:      # image k/255: stored as the 8-bit k (tests/parity_utils.golden_episodes)
+                        u8 = np.rint(o * 255.).astype(np.uint8)
+                        assert np.array_equal(u8.astype(np.float32) / np.float32(255.), o)
+                        out[f'ep{i}/obs_{j}_u8'] = u8
+                    else:
+                        out[f'ep{i}/obs_{j}'] = o
             else:
                 out[f'ep{i}/{k}'] = v
     out['n_episodes'] = np.int64(len(ep_lens))
@@ -357,12 +367,33 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
         return r
 
     def pol(*a, **k):
-        r = orig_pol(*a, **k)
+        # the policy objective is a local of the reference's `_train_policy` (sac_base.py:1903): observe the
+        # tensor its `.backward(inputs=...)` is called on
+        orig_backward = torch.Tensor.backward
+
+        def spy(t, *ba, **bk):
+            seen.setdefault('loss_policy', t.detach().numpy().copy())
+            return orig_backward(t, *ba, **bk)
+
+        torch.Tensor.backward = spy
+        try:
+            r = orig_pol(*a, **k)
+        finally:
+            torch.Tensor.backward = orig_backward
         seen['d_ent'] = None if r[0] is None else r[0].detach().numpy().copy()
         seen['c_ent'] = None if r[1] is None else r[1].detach().numpy().copy()
         return r
 
     sac._train_rep_q, sac._train_policy = rq, pol
+    if sac.curiosity is not None:
+        orig_cur = sac._train_curiosity
+
+        def cur(*a, **k):
+            r = orig_cur(*a, **k)
+            seen['loss_curiosity'] = r.detach().numpy().copy()
+            return r
+
+        sac._train_curiosity = cur
     orig_update = sac.replay_buffer.update
 
     def upd(ids, td):
@@ -393,6 +424,17 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
         out[f'step{s}/sample_ids'] = seen['sample_ids']
         out[f'step{s}/is_weights'] = seen['w']
         out[f'step{s}/loss_q'] = seen['loss_q']
+        if 'loss_policy' in seen:
+            out[f'step{s}/loss_policy'] = seen['loss_policy']
+        if s == 0:
+            # Adam's first moment after the first step is (1 - beta1) * gradient: the step's gradients, per
+            # optimizer and parameter (in `parameters()` order), without touching the step
+            for oname, opt in sac.ckpt_dict.items():
+                if oname.startswith('optimizer') and opt is not None:
+                    for j, p in enumerate(opt.param_groups[0]['params']):
+                        st = opt.state.get(p)
+                        if st:
+                            out[f'g0/{oname}/{j}'] = st['exp_avg'].detach().numpy().copy()
         if seen.get('c_ent') is not None:
             out[f'step{s}/c_entropy'] = seen['c_ent']
         if seen.get('d_ent') is not None:
@@ -404,6 +446,8 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
         out[f'step{s}/hidden'] = sac.replay_buffer._trans_storage._buffer['pre_seq_hidden_state'].copy()
         out[f'step{s}/log_c_alpha'] = sac.log_c_alpha.detach().numpy().copy()
         out[f'step{s}/log_d_alpha'] = sac.log_d_alpha.detach().numpy().copy()
+        if 'loss_curiosity' in seen:
+            out[f'step{s}/loss_curiosity'] = seen['loss_curiosity']
     for name, m in mods.items():
         for k, v in m.state_dict().items():
             out[f'w1/{name}/{k}'] = v.numpy().copy()
@@ -497,6 +541,140 @@ def aux_cases():
                                           burn_in_step=2, **tiny), eps, 2)
 
 
+IMG_OBS = dict(obs_names=('vector', 'image'), obs_shapes=((10,), (3, 30, 30)), c_action_size=4)
+
+
+def conv_cases():
+    """BASELINE configs[3] / configs[4] compositions, scaled down: the reference's own conv plugins
+    (`tests/nn_conv_vanilla.py`, `tests/nn_conv_attn.py`), burn_in_step 5 / n_step 3 as in its
+    `tests/test_sac_params.py:75-76`.  Two of four critics sampled: the two randperm subsets of `_get_y`
+    (sac_base.py:1434-1442) are live; FORWARD curiosity: the bonus lands twice in the aliased reward window
+    (1333-1343 through 2223)."""
+    from algorithm.utils.enums import CURIOSITY
+    tiny = dict(batch_size=16, replay_config={'capacity': 256}, burn_in_step=5, n_step=3)
+    f6_step('conv', 'tests/nn_conv_vanilla.py', dict(ensemble_q_num=4, ensemble_q_sample=2, **tiny),
+            [40, 30, 50], 2, **IMG_OBS)
+    f6_step('conv_attn_cur', 'tests/nn_conv_attn.py',
+            dict(seq_encoder=SEQ_ENCODER.ATTN, curiosity=CURIOSITY.FORWARD, **tiny), [40, 30, 50, 9], 2, **IMG_OBS)
+
+
+# ------------------------------------------------------------------------------------------------
+def f8_interop():
+    """Files the reference writes (`<step>.pth`, `<step>-rb_tree.npy`, `<step>-rb_storage.npz`;
+    sac_base.py:654-668, replay_buffer.py:96-111, 220-227, 436-440) after two train steps, and what the
+    reference does when it restores them and trains one more step — the product has to load the same files
+    and continue the same way."""
+    import shutil
+    import tempfile
+    nn_mod = load_ref_nn('envs/test/nn_rnn.py')
+    kw = dict(obs_names=['vector'], obs_shapes=[(6,)], d_action_sizes=[], c_action_size=2, nn=nn_mod, device='cpu',
+              batch_size=16, n_step=3, burn_in_step=2, seq_encoder=SEQ_ENCODER.RNN, replay_config={'capacity': 128})
+    seed_all(8)
+    rng = np.random.default_rng(8)
+    tmp = Path(tempfile.mkdtemp())
+    sac = SAC_Base(model_abs_dir=tmp, **kw)
+    for T in (40, 30, 50, 45):       # 165 rows on a 128-slot ring: the id map has wrapped
+        sac.put_episode(**gen_episode(rng, [(6,)], [], 2, tuple(sac.seq_hidden_state_shape), T))
+    for _ in range(2):
+        sac.train()
+    sac.save_model(save_replay_buffer=True)
+    sac.close()
+    dst = HERE / 'interop'
+    dst.mkdir(exist_ok=True)
+    for name in ('2.pth', '2-rb_tree.npy', '2-rb_storage.npz'):
+        shutil.copy(tmp / 'model' / name, dst / name)
+
+    seed_all(9)
+    sac = SAC_Base(model_abs_dir=tmp, **kw)          # restores step 2 and the replay files
+    assert sac.get_global_step() == 2
+    out, seen = {}, {}
+    orig_update = sac.replay_buffer.update
+    sac.replay_buffer.update = lambda ids, td: (seen.update(ids=np.array(ids).copy(), td=np.array(td).copy()),
+                                                orig_update(ids, td))[1]
+    orig_sample = sac.replay_buffer.sample
+
+    def smp():
+        r = orig_sample()
+        seen['sample_ids'], seen['w'] = np.array(r[0]).copy(), r[2].numpy().copy()
+        return r
+
+    sac.replay_buffer.sample = smp
+    orig_rq = sac._train_rep_q
+    sac._train_rep_q = lambda *a, **k: (lambda r: (seen.update(loss_q=r[0].detach().numpy().copy()), r)[1])(orig_rq(*a, **k))
+    with ref_shims.DrawRecorder() as rec:
+        assert sac.train() == 3
+    out['u'] = rec.u[0]
+    for j, e in enumerate(rec.eps):
+        out[f'eps{j}'] = e.numpy()
+    out['n_eps'] = np.int64(len(rec.eps))
+    out['perm'] = torch.stack(rec.perm).numpy()
+    out['sample_ids'], out['is_weights'], out['td_error'], out['loss_q'] = seen['sample_ids'], seen['w'], seen['td'], seen['loss_q']
+    out['tree'] = sac.replay_buffer._sum_tree._tree.copy()
+    out['mu_prob'] = sac.replay_buffer._trans_storage._buffer['mu_prob'].copy()
+    out['hidden'] = sac.replay_buffer._trans_storage._buffer['pre_seq_hidden_state'].copy()
+    out['log_c_alpha'] = sac.log_c_alpha.detach().numpy().copy()
+    for name, m in sac.ckpt_dict.items():
+        if isinstance(m, torch.nn.Module):
+            for k, v in m.state_dict().items():
+                out[f'w1/{name}/{k}'] = v.numpy().copy()
+    sac.close()
+    shutil.rmtree(tmp)
+    np.savez_compressed(HERE / 'f8_interop.npz', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def f9_acting():
+    """`choose_action` / `choose_attn_action` (sac_base.py:968-1086): inputs, weights, the Gaussian draw of
+    `c_policy.sample()` -> action, probability, next hidden state.  Vector, RNN and attention agents;
+    sampled and deterministic."""
+    out = {}
+    rng = np.random.default_rng(9)
+    n_env = 5
+    cases = {'vec': ('envs/test/nn.py', dict()),
+             'rnn': ('envs/test/nn_rnn.py', dict(seq_encoder=SEQ_ENCODER.RNN, burn_in_step=3)),
+             'attn': ('envs/test/nn_attn.py', dict(seq_encoder=SEQ_ENCODER.ATTN, burn_in_step=4))}
+    for tag, (nn_rel, kw) in cases.items():
+        seed_all(90)
+        sac = _tiny_sac(load_ref_nn(nn_rel), n_step=3, **kw)
+        for name, m in sac.ckpt_dict.items():
+            if isinstance(m, torch.nn.Module):
+                for k, v in m.state_dict().items():
+                    out[f'{tag}/w0/{name}/{k}'] = v.numpy().copy()
+        out[f'{tag}/w0/log_c_alpha'] = sac.log_c_alpha.detach().numpy().copy()
+        out[f'{tag}/w0/log_d_alpha'] = sac.log_d_alpha.detach().numpy().copy()
+        hs = tuple(sac.seq_hidden_state_shape)
+        if tag == 'attn':
+            T = 7                      # episode so far; the window keeps the last burn_in_step positions
+            args = dict(ep_indexes=np.tile(np.arange(T, dtype=np.int32), (n_env, 1)),
+                        ep_padding_masks=np.zeros((n_env, T), dtype=bool),
+                        ep_obses_list=[rng.standard_normal((n_env, T, 6)).astype(np.float32)],
+                        ep_pre_actions=rng.random((n_env, T, 2)).astype(np.float32),
+                        ep_pre_attn_states=rng.standard_normal((n_env, T, *hs)).astype(np.float32))
+            args['ep_padding_masks'][0, :5] = True
+            args['ep_indexes'][0, :5] = -1
+            fn = sac.choose_attn_action
+        else:
+            args = dict(obs_list=[rng.standard_normal((n_env, 6)).astype(np.float32)],
+                        pre_action=rng.random((n_env, 2)).astype(np.float32),
+                        pre_seq_hidden_state=rng.standard_normal((n_env, *hs)).astype(np.float32))
+            fn = sac.choose_action
+        for k, v in args.items():
+            if isinstance(v, list):
+                out[f'{tag}/in/{k}'] = v[0]
+            else:
+                out[f'{tag}/in/{k}'] = v
+        for mode, extra in (('sample', {}), ('deter', dict(disable_sample=True))):
+            with ref_shims.DrawRecorder() as rec:
+                action, prob, hidden = fn(**{k: (list(v) if isinstance(v, list) else v.copy()) for k, v in args.items()},
+                                          **extra)
+            out[f'{tag}/{mode}/n_eps'] = np.int64(len(rec.eps))
+            for j, e in enumerate(rec.eps):
+                out[f'{tag}/{mode}/eps{j}'] = e.numpy()
+            out[f'{tag}/{mode}/action'], out[f'{tag}/{mode}/prob'], out[f'{tag}/{mode}/hidden'] = action, prob, hidden
+        sac.close()
+    np.savez_compressed(HERE / 'f9_acting.npz', **out)
+
+
 def main():
     torch.set_num_threads(1)
     f1_sumtree()
@@ -520,6 +698,9 @@ def main():
     f6_step('hybrid', 'envs/test/nn.py', dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2, **small),
             [60, 45, 70], 3, d_action_sizes=(3, 2), c_action_size=2)
     aux_cases()
+    conv_cases()
+    f8_interop()
+    f9_acting()
     print('golden fixtures written to', HERE)
 
 

@@ -40,10 +40,17 @@ def load_golden_weights(agent, g, prefix='w0'):
     return mods
 
 
+def golden_obs(g, i, j):
+    """observation j of episode i; image observations are stored as their 8-bit pixel values"""
+    if f'ep{i}/obs_{j}_u8' in g.files:
+        return g[f'ep{i}/obs_{j}_u8'].astype(np.float32) / np.float32(255.)
+    return g[f'ep{i}/obs_{j}']
+
+
 def golden_episodes(g, n_obs=1):
     for i in range(int(g['n_episodes'])):
         yield dict(ep_indexes=g[f'ep{i}/ep_indexes'],
-                   ep_obses_list=[g[f'ep{i}/obs_{j}'] for j in range(n_obs)],
+                   ep_obses_list=[golden_obs(g, i, j) for j in range(n_obs)],
                    ep_actions=g[f'ep{i}/ep_actions'], ep_rewards=g[f'ep{i}/ep_rewards'],
                    ep_dones=g[f'ep{i}/ep_dones'], ep_probs=g[f'ep{i}/ep_probs'],
                    ep_pre_seq_hidden_states=g[f'ep{i}/ep_pre_seq_hidden_states'])
@@ -76,3 +83,96 @@ def host_draws(rng, B, n, A, E, has_d=False):
 
 def snapshot_tree(agent):
     return agent.replay_buffer._tree.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-step golden cases (tests/golden/f6_step_<case>.npz), shared by the oracle (CPU) and product (GPU) tests
+# ------------------------------------------------------------------------------------------------
+VEC = dict(obs_names=['vector'], obs_shapes=[(6,)], c_action_size=2, batch_size=32, capacity=512)
+IMG = dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 30, 30)], c_action_size=4, batch_size=16, capacity=256)
+# case -> (plugin module name under tests.plugins, learner keywords, discrete action sizes, observation / size set)
+STEP_CASES = {
+    'cfg1': ('nn_vec', dict(n_step=1, use_priority=False), (), VEC),
+    'cfg2': ('nn_vec', dict(n_step=4), (), VEC),
+    'cfg3': ('nn_rnn', dict(n_step=3, burn_in_step=3, seq_encoder='RNN'), (), VEC),
+    'attn': ('nn_attn', dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), VEC),
+    'hybrid': ('nn_vec', dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2), (3, 2), VEC),
+    # BASELINE configs[3] / configs[4] compositions (reference tests/nn_conv_vanilla.py, tests/nn_conv_attn.py)
+    'conv': ('nn_conv', dict(n_step=3, burn_in_step=5, ensemble_q_num=4, ensemble_q_sample=2), (), IMG),
+    'conv_attn_cur': ('nn_conv_attn', dict(n_step=3, burn_in_step=5, seq_encoder='ATTN', curiosity='FORWARD'), (), IMG),
+}
+
+
+def plugin(name):
+    import importlib
+    return importlib.import_module(f'tests.plugins.{name}')
+
+
+# module of the reference's ckpt_dict -> the optimizer that owns its parameters
+OPTIMIZER_OF = {'model_rep': 'optimizer_rep', 'model_policy': 'optimizer_policy',
+                'model_forward_dynamic': 'optimizer_curiosity', 'model_inverse_dynamic': 'optimizer_curiosity',
+                'model_rnd': 'optimizer_rnd'}
+
+
+def product_first_moments(agent) -> dict:
+    """{optimizer name (reference ckpt_dict naming): [Adam first-moment view per parameter, `parameters()` order]}"""
+    out = {}
+    for name, opt in agent.ckpt_dict.items():
+        if not name.startswith('optimizer') or opt is None:
+            continue
+        views = []
+        for seg in opt.names:
+            off = opt.group.segments[seg][0]
+            for p in opt.group.params[seg]:
+                views.append(opt.exp_avg[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+        out[name] = views
+    return out
+
+
+def assert_first_step_gradients(agent, g, rtol, atol_frac):
+    """After the FIRST train step Adam's first moment is (1 - beta1) * gradient: compares every gradient of the
+    step with the reference's (`g0/<optimizer>/<j>`), entry by entry, within rtol + atol_frac * max|tensor|."""
+    moments = product_first_moments(agent)
+    checked = 0
+    for key in g.files:
+        if not key.startswith('g0/'):
+            continue
+        _, oname, j = key.split('/')
+        want = g[key]
+        got = moments[oname][int(j)].cpu().numpy()
+        scale = float(np.abs(want).max())
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol_frac * scale + 1e-12, err_msg=key)
+        checked += 1
+    assert checked > 0
+    return checked
+
+
+def assert_weights_close(mods, g, n_steps, lr, rtol, atol, small_frac=1e-3, prefix='w1'):
+    """Post-training weights against the reference's.  Adam's first updates are sign-like (-lr * g / (|g| + eps)),
+    so an entry whose reference gradient is analytically zero or at rounding level (|g0| < small_frac * max|g0| of
+    its tensor) may move by +-lr per step with a device-dependent sign: those entries — and only those — get
+    2 * lr * n_steps of slack.  Returns {tensor: fraction of slack entries} for the tensors that have any."""
+    slack = {}
+    for name, mod in mods.items():
+        params = [k for k, _ in mod.named_parameters()]
+        oname = OPTIMIZER_OF.get(name) or ('optimizer_q_' + name.rsplit('_', 1)[1] if name.startswith('model_q_') else None)
+        for k, v in mod.state_dict().items():
+            key = f'{prefix}/{name}/{k}'
+            if key not in g.files:
+                continue
+            got, want = v.detach().cpu().numpy(), g[key]
+            loose = np.zeros(want.shape, dtype=bool)
+            gkey = f'g0/{oname}/{params.index(k)}' if oname is not None and k in params else None
+            if gkey is not None and gkey in g.files:
+                g0 = np.abs(g[gkey])
+                loose = g0 < small_frac * max(float(g0.max()), 1e-30)
+                if g0.max() == 0:
+                    loose[...] = True
+            err = np.abs(got - want)
+            bound = np.where(loose, 2.2 * lr * n_steps, atol) + rtol * np.abs(want)
+            assert (err <= bound).all(), (f'{name}/{k}: {int((err > bound).sum())} of {err.size} entries off, worst '
+                                          f'{float(err.max()):.3g} (strict entries: {float(err[~loose].max()) if (~loose).any() else 0:.3g})')
+            if loose.any():
+                slack[f'{name}/{k}'] = float(loose.mean())
+    return slack

@@ -1,0 +1,111 @@
+"""GPU: every BASELINE.json configuration at its REAL size (bench.CONFIGS: batch 256 / 256 / 512 / 1024, capacity
+2^19 for the vector configurations, window 81 for the RNN one, 4 608 / 9 216 frames per representation pass for the
+image ones) against the CPU oracle, through the eager step AND the captured hipGraph.
+
+Protocol: product learner and `oracle.sac_ref.SacRef` start from identical weights, episodes and tree bytes.  The
+product draws its own numbers on the device (Philox, the graph-capturable source the bench runs with); after each
+step the draws are read back from the step's static buffers and replayed on the oracle, so both sides consume the
+same uniforms, Gaussians and ensemble subsets.  Step 0 runs eager, step 1 is the capture + first replay, step 2 a
+replay.  Required: PER ids bit-exact, IS weights to 2e-6, losses / td-errors / priorities within the fp32
+tolerances of tests/test_sac_step_gpu.py.  This covers what the small goldens cannot: the multi-workgroup return
+kernel, the fused sampler at 256..1024 strata over 19 tree levels, convolution group tails at 4 608 and 9 216
+frames, the GRU at 256 x 81."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import bench  # noqa: E402
+from oracle import sac_ref  # noqa: E402
+from tests import parity_utils as pu  # noqa: E402
+
+FILL = {'cfg2': 2 ** 15, 'cfg3': 2 ** 14, 'cfg4': 4096, 'cfg5': 4096}
+SUBSET_ROWS = ('y_cn', 'y_cnext', 'pi_c', 'td_cn', 'td_cnext')      # the oracle's consumption order (continuous head)
+
+
+def _full_perm(subset, E):
+    """a permutation of range(E) whose first entries are `subset` (the reference keeps `randperm(E)[:E_sample]`)"""
+    subset = [int(x) for x in subset]
+    return np.array(subset + [e for e in range(E) if e not in subset], dtype=np.int64)
+
+
+def _episode(rng, cfg, T):
+    A = cfg['c_action_size']
+    return dict(ep_indexes=np.arange(T, dtype=np.int32)[None],
+                ep_obses_list=[rng.standard_normal((1, T, *s)).astype(np.float32) for s in cfg['obs_shapes']],
+                ep_actions=rng.random((1, T, A)).astype(np.float32),
+                ep_rewards=rng.standard_normal((1, T)).astype(np.float32),
+                ep_dones=(rng.random((1, T)) < 0.5),
+                ep_probs=rng.random((1, T, A)).astype(np.float32),
+                ep_pre_seq_hidden_states=rng.standard_normal((1, T, *cfg['hidden'])).astype(np.float32))
+
+
+@pytest.mark.parametrize('name', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
+def test_baseline_config_full_size_vs_oracle(name):
+    import asac_amd  # noqa: F401
+    from algorithm.sac_base import SAC_Base
+    from algorithm.utils.enums import CURIOSITY, SEQ_ENCODER
+    cfg = bench.CONFIGS[name]
+    plugin = pu.plugin(cfg['plugin'])
+    B, n, A, E = cfg['batch_size'], cfg['n_step'], cfg['c_action_size'], cfg['ensemble_q_num']
+    common = dict(n_step=n, burn_in_step=cfg['burn_in_step'], batch_size=B, ensemble_q_num=E,
+                  ensemble_q_sample=cfg['ensemble_q_sample'], replay_config={'capacity': cfg['capacity']})
+    torch.manual_seed(0)
+    agent = SAC_Base(cfg['obs_names'], cfg['obs_shapes'], [], A, None, plugin, device='cuda:0',
+                     seq_encoder=SEQ_ENCODER[cfg['seq_encoder']] if cfg['seq_encoder'] else None,
+                     curiosity=CURIOSITY[cfg['curiosity']] if cfg.get('curiosity') else None,
+                     hip_config={'use_graph': True, 'graph_warmup': 1}, **common)
+    oracle = sac_ref.SacRef(cfg['obs_names'], cfg['obs_shapes'], [], A, plugin, seq_encoder=cfg['seq_encoder'],
+                            curiosity=cfg.get('curiosity'), **common)
+    pu.copy_weights_to_oracle(agent, oracle)
+    if cfg.get('curiosity'):
+        oracle.model_forward_dynamic.load_state_dict(
+            {k: v.detach().cpu().clone() for k, v in agent.model_forward_dynamic.state_dict().items()})
+
+    rng = np.random.default_rng(7)
+    T = cfg['episode_len']
+    for _ in range(FILL[name] // T):
+        ep = _episode(rng, cfg, T)
+        agent.put_episode(**ep)
+        oracle.put_episode(**ep)
+    rb, orb = agent.replay_buffer, oracle.replay_buffer
+    # non-uniform priorities: one |N(0,1)| update pass on the device; the oracle starts from the same tree bytes
+    ids = torch.arange(rb.size, device=rb.device, dtype=torch.int64)
+    td = torch.from_numpy(np.abs(rng.standard_normal(rb.size)).astype(np.float32)).to(rb.device)
+    for s in range(0, rb.size, 4096):
+        rb.update(ids[s:s + 4096], td[s:s + 4096])
+    last = ids[T - 1::T]
+    rb._update_ids(last, torch.zeros(last.numel(), device=rb.device), stale_check=False, mode=1)
+    orb.tree.tree[:] = rb._tree.cpu().numpy()
+    assert np.array_equal(orb.storage.columns['_id'], rb._slot_ids.cpu().numpy())
+
+    trained_rep = agent.optimizer_rep is not None
+    rt = 1e-3 if trained_rep else 2e-4
+    for step in range(3):
+        agent.train()
+        torch.cuda.synchronize()
+        assert (agent._graph is not None) == (step >= 1), 'step 0 eager, step 1 captures and replays'
+        # the step's draws, read back from its static buffers
+        u = [rb._u.cpu().numpy()]
+        eps = [b.cpu().numpy().copy() for b in (agent._eps_y, agent._eps_pi, agent._eps_alpha, agent._eps_td)]
+        perm = [_full_perm(agent._subsets[k].cpu().numpy(), E) for k in SUBSET_ROWS]
+        oracle.noise = sac_ref.RecordedNoise(u, eps, perm)
+        out = oracle.train()
+        assert not oracle.noise.eps and not oracle.noise.perm and not oracle.noise.u
+        assert np.array_equal(rb._ids.cpu().numpy(), out['ids']), f'{name} step {step}: PER index selection'
+        np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], out['is_weights'], rtol=2e-6)
+        np.testing.assert_allclose(agent._stats['loss_q'].item(), float(out['loss_q']), rtol=rt)
+        if cfg.get('curiosity'):
+            np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), float(out['loss_curiosity']), rtol=rt)
+        np.testing.assert_allclose(agent._td_error.cpu().numpy(), out['td_error'].reshape(-1), rtol=rt, atol=5e-5)
+        np.testing.assert_allclose(rb._tree.cpu().numpy(), orb.tree.tree, rtol=rt, atol=1e-5)
+        np.testing.assert_allclose(rb._columns['mu_prob'].cpu().numpy(), orb.storage.columns['mu_prob'],
+                                   rtol=5e-3, atol=1e-6)
+        if rb._columns['pre_seq_hidden_state'].shape[-1]:
+            np.testing.assert_allclose(rb._columns['pre_seq_hidden_state'].cpu().numpy(),
+                                       orb.storage.columns['pre_seq_hidden_state'], rtol=rt, atol=5e-5)
+        np.testing.assert_allclose(agent.log_c_alpha.item(), oracle.log_c_alpha.item(), rtol=2e-4)
+    rb.check_health()
+    assert rb.check_tree_invariant() == 0
+    agent.close()

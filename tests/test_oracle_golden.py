@@ -7,7 +7,7 @@ import torch
 
 from oracle import sac_ref
 from oracle.per_ref import PrioritizedReplayRef, SumTreeRef
-from tests.plugins import nn_attn, nn_rnn, nn_vec
+from tests import parity_utils as pu
 
 
 # ------------------------------------------------------------------------------------------------
@@ -90,40 +90,27 @@ def _load_weights(agent, g, prefix):
         mod.load_state_dict(sd)
 
 
-def _episodes(g, n_obs=1):
-    for i in range(int(g['n_episodes'])):
-        yield dict(ep_indexes=g[f'ep{i}/ep_indexes'],
-                   ep_obses_list=[g[f'ep{i}/obs_{j}'] for j in range(n_obs)],
-                   ep_actions=g[f'ep{i}/ep_actions'], ep_rewards=g[f'ep{i}/ep_rewards'],
-                   ep_dones=g[f'ep{i}/ep_dones'], ep_probs=g[f'ep{i}/ep_probs'],
-                   ep_pre_seq_hidden_states=g[f'ep{i}/ep_pre_seq_hidden_states'])
+# same eager ops on the same host give identical bits; these cases run other kernels for the same math: the GRU
+# un-packed (nn_models/layers/recurrent.py), attention heads as batched GEMMs instead of chunk / cat
+INEXACT = ('cfg3', 'attn', 'conv_attn_cur')
 
 
-CASES = {
-    'cfg1': (nn_vec, dict(n_step=1, use_priority=False), (), 2),
-    'cfg2': (nn_vec, dict(n_step=4), (), 2),
-    'cfg3': (nn_rnn, dict(n_step=3, burn_in_step=3, seq_encoder='RNN'), (), 2),
-    'attn': (nn_attn, dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), 2),
-    'hybrid': (nn_vec, dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2), (3, 2), 2),
-}
-
-
-@pytest.mark.parametrize('case', list(CASES))
+@pytest.mark.parametrize('case', list(pu.STEP_CASES))
 def test_f6_full_step(golden_dir, case):
     torch.set_num_threads(1)
     g = np.load(golden_dir / f'f6_step_{case}.npz')
-    nn_mod, kw, d_sizes, c_size = CASES[case]
-    agent = sac_ref.SacRef(['vector'], [(6,)], list(d_sizes), c_size, nn_mod, batch_size=32,
-                           replay_config={'capacity': 512}, **kw)
+    plugin_name, kw, d_sizes, io = pu.STEP_CASES[case]
+    nn_mod = pu.plugin(plugin_name)
+    agent = sac_ref.SacRef(io['obs_names'], io['obs_shapes'], list(d_sizes), io['c_action_size'], nn_mod,
+                           batch_size=io['batch_size'], replay_config={'capacity': io['capacity']}, **kw)
     _load_weights(agent, g, 'w0')
     with torch.no_grad():
         agent.log_c_alpha.copy_(torch.from_numpy(g['w0/log_c_alpha']))
         agent.log_d_alpha.copy_(torch.from_numpy(g['w0/log_d_alpha']))
-    for ep in _episodes(g):
+    for ep in pu.golden_episodes(g, len(io['obs_shapes'])):
         agent.put_episode(**ep)
 
-    # the GRU here runs un-packed (see nn_models/layers/recurrent.py): same math, other kernels
-    exact = case not in ('cfg3', 'attn')   # attention: batched-GEMM head layout differs from chunk/cat
+    exact = case not in INEXACT
     for s in range(int(g['n_steps'])):
         eps = [g[f'step{s}/eps{j}'] for j in range(int(g[f'step{s}/n_eps']))]
         agent.noise = sac_ref.RecordedNoise(u=[g[f'step{s}/u']], eps=eps, perm=list(g[f'step{s}/perm']))
@@ -132,6 +119,19 @@ def test_f6_full_step(golden_dir, case):
         assert np.array_equal(out['is_weights'], g[f'step{s}/is_weights'])
         tol = dict(rtol=0, atol=0) if exact else dict(rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(out['loss_q'].numpy(), g[f'step{s}/loss_q'], **tol)
+        np.testing.assert_allclose(out['loss_policy'].numpy(), g[f'step{s}/loss_policy'], **tol)
+        if f'step{s}/c_entropy' in g.files:
+            np.testing.assert_allclose(out['c_entropy'].numpy(), g[f'step{s}/c_entropy'], **tol)
+        if f'step{s}/loss_curiosity' in g.files:
+            np.testing.assert_allclose(out['loss_curiosity'].numpy(), g[f'step{s}/loss_curiosity'], **tol)
+        if s == 0:      # the first step's gradients: Adam's first moment / (1 - beta1)
+            for oname, opt in agent.named_optimizers().items():
+                for j, p in enumerate(opt.param_groups[0]['params']):
+                    if f'g0/{oname}/{j}' in g.files:
+                        want = g[f'g0/{oname}/{j}']
+                        np.testing.assert_allclose(opt.state[p]['exp_avg'].numpy(), want, rtol=tol['rtol'] * 50,
+                                                   atol=0 if exact else 1e-6 * np.abs(want).max() + 1e-12,
+                                                   err_msg=f'{oname}/{j}')
         if f'step{s}/td_error' in g.files:
             np.testing.assert_allclose(out['td_error'], g[f'step{s}/td_error'], **tol)
             if exact:

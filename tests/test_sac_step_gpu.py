@@ -9,79 +9,81 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from tests import parity_utils as pu  # noqa: E402
-from tests.plugins import nn_attn, nn_rnn, nn_vec  # noqa: E402
+from tests.plugins import nn_vec  # noqa: E402
 
-CASES = {
-    'cfg1': (nn_vec, dict(n_step=1, use_priority=False), (), 2),
-    'cfg2': (nn_vec, dict(n_step=4), (), 2),
-    'cfg3': (nn_rnn, dict(n_step=3, burn_in_step=3, seq_encoder='RNN'), (), 2),
-    'attn': (nn_attn, dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), 2),
-    'hybrid': (nn_vec, dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2), (3, 2), 2),
-}
-
-
-def assert_mostly_close(actual, desired, rtol, atol, frac):
-    """all entries close, except at most `frac` of them (chaotic sign-flip outliers, see below)"""
-    bad = np.abs(actual - desired) > atol + rtol * np.abs(desired)
-    assert bad.mean() <= frac, f'{bad.sum()} / {bad.size} entries differ by more than rtol={rtol}, atol={atol}'
+LR = 3e-4
 
 
 def make_agent(case, use_graph=False):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
-    from algorithm.utils.enums import SEQ_ENCODER
-    nn_mod, kw, d_sizes, c_size = CASES[case]
+    from algorithm.utils.enums import convert_config_to_enum
+    plugin_name, kw, d_sizes, io = pu.STEP_CASES[case]
     kw = dict(kw)
-    if kw.get('seq_encoder'):
-        kw['seq_encoder'] = SEQ_ENCODER[kw['seq_encoder']]
-    return SAC_Base(['vector'], [(6,)], list(d_sizes), c_size, None, nn_mod, device='cuda:0', batch_size=32,
-                    replay_config={'capacity': 512}, hip_config={'use_graph': use_graph}, **kw)
+    convert_config_to_enum(kw)
+    return SAC_Base(io['obs_names'], io['obs_shapes'], list(d_sizes), io['c_action_size'], None, pu.plugin(plugin_name),
+                    device='cuda:0', batch_size=io['batch_size'], replay_config={'capacity': io['capacity']},
+                    hip_config={'use_graph': use_graph}, **kw)
 
 
-@pytest.mark.parametrize('case', list(CASES))
+# Tolerances (fp32; device GEMM / MFMA accumulation order and device libm against the host):
+#   observables of a step (losses, td-errors, priorities, hidden states, alpha)   rtol 2e-4
+#   first-step gradients, entry by entry                                          rtol 2e-3 + 2e-5 * max|tensor|
+#   weights after the steps                                                        rtol 5e-4 + atol 2e-5, except entries whose
+#       reference gradient is (analytically or numerically) zero, see parity_utils.assert_weights_close
+# Cases whose representation is itself trained by the step carry the rounding of one more Adam update into the
+# observables taken after it (td-errors, written-back probabilities): 1e-3 there.
+TRAINED_REP = ('attn', 'conv', 'conv_attn_cur')
+
+
+@pytest.mark.parametrize('case', list(pu.STEP_CASES))
 def test_full_step_vs_reference_golden(golden_dir, case):
     from algorithm.fused import RecordedNoise
     g = np.load(golden_dir / f'f6_step_{case}.npz')
+    io = pu.STEP_CASES[case][3]
     agent = make_agent(case)
     mods = pu.load_golden_weights(agent, g)
-    for ep in pu.golden_episodes(g):
+    for ep in pu.golden_episodes(g, len(io['obs_shapes'])):
         agent.put_episode(**ep)
     rb = agent.replay_buffer
-    # the attention representation is itself updated inside the step: rounding-order differences of the
-    # batched GEMMs / softmax pass through one Adam step before td-errors are taken -> 1e-3
-    rt = 1e-3 if case == 'attn' else 2e-4
-    # Adam's first steps are sign-like (delta ~ -lr*sign(g)): parameters whose gradient is analytically zero
-    # (the key-projection bias under softmax) or at rounding level take +-lr with a device-dependent sign,
-    # i.e. differ by up to 2*lr = 6e-4 from the reference; the policy probabilities written back move with them
-    # (three steps: up to 3 * 2 * lr = 1.8e-3 on such parameters)
-    mu_rt, mu_at, w_at = (5e-2, 1e-3, 2e-3) if case == 'attn' else (1e-3, 1e-6, 2e-5)
-    for s in range(int(g['n_steps'])):
+    rt = 1e-3 if case in TRAINED_REP else 2e-4
+    n_steps = int(g['n_steps'])
+    for s in range(n_steps):
         eps = [g[f'step{s}/eps{j}'] for j in range(int(g[f'step{s}/n_eps']))]
         agent.noise = RecordedNoise([g[f'step{s}/u']], eps, list(g[f'step{s}/perm']))
         rb.uniform_source = agent.noise
+        alpha_before = agent.log_c_alpha.detach().clone()
         assert agent.train() == s + 1
         assert agent.noise.exhausted(), 'every recorded draw must be consumed, in order'
         assert np.array_equal(rb._ids.cpu().numpy(), g[f'step{s}/sample_ids']), f'step {s}: PER index selection'
         np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], g[f'step{s}/is_weights'], rtol=2e-6)
         np.testing.assert_allclose(agent._stats['loss_q'].item(), g[f'step{s}/loss_q'], rtol=rt)
+        # the policy objective and the entropy the reference returns from _train_policy (sac_base.py:1903-1911)
+        agent._refresh_policy_stats(alpha_before)
+        np.testing.assert_allclose(agent._stats['loss_policy'].item(), g[f'step{s}/loss_policy'], rtol=rt, atol=2e-5)
+        if f'step{s}/c_entropy' in g.files:
+            np.testing.assert_allclose(agent._stats['c_entropy'].item(), g[f'step{s}/c_entropy'], rtol=rt, atol=2e-5)
+        if f'step{s}/d_entropy' in g.files:
+            np.testing.assert_allclose(agent._stats['d_entropy'].item(), g[f'step{s}/d_entropy'], rtol=rt, atol=2e-5)
+        if f'step{s}/loss_curiosity' in g.files:
+            np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), g[f'step{s}/loss_curiosity'], rtol=rt)
+        if s == 0:
+            pu.assert_first_step_gradients(agent, g, rtol=2e-3, atol_frac=2e-5)
         if f'step{s}/td_error' in g.files:
             np.testing.assert_allclose(agent._td_error.cpu().numpy()[:, None], g[f'step{s}/td_error'],
                                        rtol=rt, atol=2e-5)
             np.testing.assert_allclose(rb._tree.cpu().numpy(), g[f'step{s}/tree'], rtol=rt, atol=1e-6)
         # stored-action probabilities are exp() of a log-density with 1/sigma^2 gain on f32 noise of loc: 1e-3
-        if case == 'attn':
-            assert_mostly_close(rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob'], mu_rt, mu_at, frac=0.01)
-        else:
-            np.testing.assert_allclose(rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob'], rtol=mu_rt, atol=mu_at)
+        np.testing.assert_allclose(rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob'],
+                                   rtol=5e-3 if case in TRAINED_REP else 1e-3, atol=1e-6)
         if rb._columns['pre_seq_hidden_state'].shape[-1]:
             np.testing.assert_allclose(rb._columns['pre_seq_hidden_state'].cpu().numpy(), g[f'step{s}/hidden'],
                                        rtol=rt, atol=2e-5)
-        np.testing.assert_allclose(agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'], rtol=1e-5 if case != 'attn' else 1e-3)
-    for name, mod in mods.items():
-        for k, v in mod.state_dict().items():
-            if f'w1/{name}/{k}' in g.files:
-                np.testing.assert_allclose(v.cpu().numpy(), g[f'w1/{name}/{k}'], rtol=5e-4, atol=w_at,
-                                           err_msg=f'{name}/{k}')
+        np.testing.assert_allclose(agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'], rtol=1e-5 if case not in TRAINED_REP else 2e-4)
+    if agent.curiosity is not None:
+        mods['model_forward_dynamic'] = agent.model_forward_dynamic
+    slack = pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5)
+    print(f'{case}: tensors with zero-gradient entries (fraction given +-lr slack): {slack}')
     rb.check_health()
     assert rb.check_tree_invariant() == 0
     agent.close()
