@@ -13,7 +13,7 @@ from torch import nn
 
 from asac_amd import native
 
-from .fused_mlp import _flat_alias
+from .fused_mlp import _flat_alias, direct_enabled
 
 __all__ = ['fused_conv_stack', 'conv_stack_desc']
 
@@ -74,7 +74,7 @@ class _ConvStackFn(torch.autograd.Function):
         # the four gradients as one packed block: inside the learner they are consecutive views of the flat
         # gradient buffer, and the reduction kernel adds into them directly (no AccumulateGrad launches)
         flat = None
-        if DIRECT_PARAM_GRADS and all(p.requires_grad and p.grad is not None for p in params):
+        if DIRECT_PARAM_GRADS and direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
         if flat is not None:
             native.conv2_backward(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws, True)

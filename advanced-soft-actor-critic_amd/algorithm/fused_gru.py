@@ -15,9 +15,12 @@ import torch
 
 from asac_amd import native
 
+from .fused_mlp import direct_enabled
+
 __all__ = ['fused_gru', 'fused_gru_supported', 'TwinPass']
 
-# accumulate parameter gradients into existing dense `.grad` tensors from the kernel (see above)
+# accumulate parameter gradients into existing dense `.grad` tensors from the kernel (see above), inside the
+# learner's `fused_mlp.direct_param_grads()` regions
 DIRECT_PARAM_GRADS = True
 
 
@@ -158,7 +161,7 @@ class _GruFn(torch.autograd.Function):
         ws = torch.empty(native.gru_backward_workspace(desc, B), dtype=x.dtype, device=x.device)
         grad_out = None if grad_out is None else grad_out.contiguous()
         grad_hn = None if grad_hn is None else grad_hn.contiguous()
-        direct = DIRECT_PARAM_GRADS and all(
+        direct = DIRECT_PARAM_GRADS and direct_enabled() and all(
             t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32 and t.grad.is_cuda
             for t in weights)
         if direct:

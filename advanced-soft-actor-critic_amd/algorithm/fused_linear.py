@@ -10,7 +10,7 @@ from torch import nn
 
 from asac_amd import native
 
-from .fused_mlp import _flat_alias
+from .fused_mlp import _flat_alias, direct_enabled
 
 __all__ = ['LinearTanhHead', 'fuse_linear_tanh_heads']
 
@@ -41,7 +41,8 @@ class _LinearTanhFn(torch.autograd.Function):
         gx = torch.empty(N, K, dtype=rows.dtype, device=rows.device) if ctx.needs_input_grad[0] else None
         ws = ctx.head._workspace(N, K, O, rows.device)
         flat = None
-        if weight.requires_grad and bias.requires_grad and weight.grad is not None and bias.grad is not None:
+        if (direct_enabled() and weight.requires_grad and bias.requires_grad and weight.grad is not None
+                and bias.grad is not None):
             flat = _flat_alias([weight.grad, bias.grad])     # the learner's flat gradient buffer: add in place
         if flat is not None:
             native.linear_tanh_backward(rows, weight.detach(), y, gy, gx, flat, True, ws)

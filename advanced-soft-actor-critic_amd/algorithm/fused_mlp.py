@@ -5,6 +5,7 @@ pass of the network — or of all E ensemble members at once — is ONE `asac_ml
 Anything else (user-defined models, discrete heads, other activations, widths > 64) keeps the
 generic module path; `describe_*` returns None and the caller falls back.
 """
+import contextlib
 import weakref
 
 import torch
@@ -19,6 +20,30 @@ __all__ = ['StockMLP', 'describe_q', 'describe_policy', 'describe_dense', 'fused
 MAX_WIDTH, MAX_HEAD = 64, 16
 MAX_INPUT = 128         # a first layer may be up to 128 inputs wide when the stack has <= 3 blocks (two K halves)
 FUSED_DENSE = True      # `LinearLayers` stacks that opt in (`fuse = True`: the conv encoders' heads) run fused
+
+# How the fused autograd Functions (this module, fused_conv, fused_gru, fused_linear, layers.attention) deliver
+# PARAMETER gradients.  Default: they are returned to autograd like any op's, so `autograd.grad`, `backward(inputs=
+# ...)` and gradient gating (`sac_aux.calculate_adaptive_weights`) see exactly what PyTorch semantics promise.
+# Inside `direct_param_grads()` the backward kernels instead ADD them straight into the parameters' `.grad` views of
+# the learner's flat gradient buffer (no per-parameter AccumulateGrad launches) and hand autograd nothing: only valid
+# around a backward pass that is meant to accumulate into every parameter it reaches — the learner wraps exactly
+# those (the Q loss, the policy objective, the curiosity loss).  A plain global: the autograd engine runs backward
+# nodes on its own device thread while the caller blocks inside the `with`.
+_direct_depth = 0
+
+
+@contextlib.contextmanager
+def direct_param_grads():
+    global _direct_depth
+    _direct_depth += 1
+    try:
+        yield
+    finally:
+        _direct_depth -= 1
+
+
+def direct_enabled() -> bool:
+    return _direct_depth > 0
 
 
 def _blocks_of(ll: LinearLayers):
@@ -132,7 +157,7 @@ def fused_dense(ll, x):
     """`ll(x)` for a `LinearLayers` stack as ONE launch per pass on the parameters where they live, when the stack
     fits `describe_dense`, its parameters (and gradients, when it trains) are consecutive views of flat buffers
     — true for every module of a `SAC_Base` — and `x` is f32 on the device.  Returns None otherwise (the caller
-    keeps the module path).  The parameter gradients are ADDED into the existing `.grad` views by the kernel."""
+    keeps the module path).  Parameter gradients: see `direct_param_grads`."""
     if not (FUSED_DENSE and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == ll.input_size):
         return None
     params = list(ll.parameters())
@@ -152,7 +177,7 @@ def fused_dense(ll, x):
         flat = _flat_alias([p.data for p in params]) if desc is not None else None
         gflat = _flat_alias([p.grad for p in params]) if (flat is not None and train) else None
         ok = flat is not None and (gflat is not None or not train)
-        cache[key] = StockMLP(desc, flat, gflat, 0, flat.numel(), 1, x.device) if ok else None
+        cache[key] = StockMLP(desc, flat, gflat, 0, flat.numel(), 1, x.device, params) if ok else None
     mlp = cache[key]
     if mlp is None:
         return None
@@ -189,11 +214,26 @@ def describe_policy(pi) -> 'native.MlpDesc | None':
     return desc
 
 
+def _param_grad_target(mlp, param_grads, n_params):
+    """-> (kernel target | None, gradients to return to autograd): the flat `.grad` views in direct mode, else a
+    scratch buffer with the parameters' layout, returned as one view per parameter"""
+    if not param_grads or direct_enabled() or n_params == 0:
+        return None, [None] * n_params
+    scratch = torch.zeros_like(mlp.grad_params)
+    base = mlp.params.storage_offset()
+    views = [scratch[p.data.storage_offset() - base:p.data.storage_offset() - base + p.numel()].view(p.shape)
+             for p in mlp.param_tensors]
+    return scratch, views
+
+
 class _MlpFn(torch.autograd.Function):
+    """inputs: (anchor, x0, x1, mlp, param_grads, *the network's parameters) — the parameters are inputs so that the
+    node is part of every backward / `autograd.grad` that asks for them"""
+
     @staticmethod
-    def forward(ctx, anchor, x0, x1, mlp, param_grads):
+    def forward(ctx, anchor, x0, x1, mlp, param_grads, *params):
         out = mlp._launch_forward(x0, x1)
-        ctx.mlp, ctx.param_grads = mlp, param_grads
+        ctx.mlp, ctx.param_grads, ctx.n_params = mlp, param_grads, len(params)
         ctx.save_for_backward(x0, x1 if x1 is not None else x0.new_empty(0))
         ctx.has_x1 = x1 is not None
         return out
@@ -204,8 +244,10 @@ class _MlpFn(torch.autograd.Function):
         x1 = x1 if ctx.has_x1 else None
         mlp = ctx.mlp
         need0, need1 = ctx.needs_input_grad[1], ctx.has_x1 and ctx.needs_input_grad[2]
-        g0, g1 = mlp._launch_backward(x0, x1, grad_out.contiguous(), need0, need1, ctx.param_grads)
-        return None, g0, g1, None, None
+        target, pg = _param_grad_target(mlp, ctx.param_grads, ctx.n_params)
+        g0, g1 = mlp._launch_backward(x0, x1, grad_out.contiguous(), need0, need1, ctx.param_grads,
+                                      grad_target=target)
+        return (None, g0, g1, None, None, *pg)
 
 
 class _MlpSelectFn(torch.autograd.Function):
@@ -215,10 +257,10 @@ class _MlpSelectFn(torch.autograd.Function):
     (five tiny launches)."""
 
     @staticmethod
-    def forward(ctx, anchor, base, t, x1, mlp, param_grads):
+    def forward(ctx, anchor, base, t, x1, mlp, param_grads, *params):
         x0 = base[:, t]
         out = mlp._launch_forward(x0, x1)
-        ctx.mlp, ctx.param_grads, ctx.t = mlp, param_grads, t
+        ctx.mlp, ctx.param_grads, ctx.t, ctx.n_params = mlp, param_grads, t, len(params)
         ctx.save_for_backward(base, x1 if x1 is not None else base.new_empty(0))
         ctx.has_x1 = x1 is not None
         return out
@@ -229,23 +271,27 @@ class _MlpSelectFn(torch.autograd.Function):
         x1 = x1 if ctx.has_x1 else None
         mlp, t = ctx.mlp, ctx.t
         need0, need1 = ctx.needs_input_grad[1], ctx.has_x1 and ctx.needs_input_grad[3]
+        target, pg = _param_grad_target(mlp, ctx.param_grads, ctx.n_params)
         g0, g1 = mlp._launch_backward(base[:, t], x1, grad_out.contiguous(), need0, need1, ctx.param_grads,
-                                      reduce_members=False)
+                                      reduce_members=False, grad_target=target)
         g_base = None
         if g0 is not None:
             g_base = torch.zeros_like(base)
             torch.sum(g0, dim=0, out=g_base[:, t])
         if g1 is not None and x1.dim() == 2:
             g1 = g1.sum(0) if mlp.E > 1 else g1[0]
-        return None, g_base, None, g1, None, None
+        return (None, g_base, None, g1, None, None, *pg)
 
 
 class StockMLP:
     """E structurally identical stock networks whose parameter segments sit `member_stride` floats
     apart starting at `flat[start]` (gradients at the same offsets of `grad_flat`)."""
 
-    def __init__(self, desc, flat, grad_flat, start, member_stride, E, device):
+    def __init__(self, desc, flat, grad_flat, start, member_stride, E, device, param_tensors=()):
+        """`param_tensors`: the networks' `nn.Parameter`s (views of `flat`, member by member) — the autograd inputs
+        of the differentiable calls; may stay empty for inference-only instances"""
         self.desc, self.E, self.member_stride = desc, E, member_stride
+        self.param_tensors = list(param_tensors)
         self.params = flat[start:start + E * member_stride]
         self.grad_params = None if grad_flat is None else grad_flat[start:start + E * member_stride]
         self.in0, self.in1 = desc.in0, desc.in1
@@ -344,20 +390,26 @@ class StockMLP:
         assert out.shape == (self.E, N, self.out_cols) and out.is_contiguous()
         return native.mlp_job(self.desc, self.params, self.member_stride, self.E, x0, x1, N, out), out
 
-    def _launch_backward(self, x0, x1, grad_out, need0, need1, param_grads, reduce_members=True, defer=False):
+    def _launch_backward(self, x0, x1, grad_out, need0, need1, param_grads, reduce_members=True, defer=False,
+                         grad_target=None):
         """-> (grad_x0, grad_x1).  An input shared by the E members ([N, in]) gets the sum of the members'
         gradients unless `reduce_members` is False (then [E, N, in] comes back for a consumer kernel
-        that sums itself).  `defer`: see `backward_qloss`."""
+        that sums itself).  `defer`: see `backward_qloss`.  `grad_target`: a buffer laid out like the parameters
+        that receives (is overwritten with) the parameter gradients instead of the flat gradient buffer."""
         N = x0.shape[-2]
         E = self.E
         g0 = torch.empty((E, N, self.in0), dtype=torch.float32, device=self.device) if need0 else None
         g1 = torch.empty((E, N, self.in1), dtype=torch.float32, device=self.device) if need1 else None
         gp = ws = None
+        mode = self._reduce_mode(defer and param_grads)
         if param_grads:
             gp, ws = self.grad_params, self._workspace_for(N)
             self._deferred_rows = N if defer else None
+            if grad_target is not None:
+                assert not defer
+                gp, mode = grad_target, native.MLP_REDUCE_OVERWRITE
         native.mlp_backward(self.desc, self.params, self.member_stride, E, x0, x1, N, grad_out, g0, g1, gp, ws,
-                            reduce_mode=self._reduce_mode(defer and param_grads))
+                            reduce_mode=mode)
         if reduce_members:
             if g0 is not None and x0.dim() == 2:
                 g0 = g0.sum(0) if E > 1 else g0[0]     # input shared by the ensemble
@@ -368,7 +420,8 @@ class StockMLP:
     def call_select(self, base, t, x1=None, param_grads=True):
         """`self(base[:, t], x1)` with the window-aware backward (`_MlpSelectFn`)."""
         if torch.is_grad_enabled() and (param_grads or base.requires_grad or (x1 is not None and x1.requires_grad)):
-            return _MlpSelectFn.apply(self._anchor, base, t, x1, self, param_grads and self.grad_params is not None)
+            pg = param_grads and self.grad_params is not None
+            return _MlpSelectFn.apply(self._anchor, base, t, x1, self, pg, *(self.param_tensors if pg else ()))
         return self._launch_forward(base[:, t], x1)
 
     def __call__(self, x0, x1=None, param_grads=True):
@@ -377,7 +430,8 @@ class StockMLP:
             assert not (torch.is_grad_enabled() and (param_grads or x0.t.requires_grad))
             return self._launch_forward(x0, x1)
         if torch.is_grad_enabled() and (param_grads or x0.requires_grad or (x1 is not None and x1.requires_grad)):
-            return _MlpFn.apply(self._anchor, x0, x1, self, param_grads and self.grad_params is not None)
+            pg = param_grads and self.grad_params is not None
+            return _MlpFn.apply(self._anchor, x0, x1, self, pg, *(self.param_tensors if pg else ()))
         return self._launch_forward(x0, x1)
 
 

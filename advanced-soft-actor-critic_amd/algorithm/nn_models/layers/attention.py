@@ -175,7 +175,7 @@ class _AttnProjFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_w, _g_keep):
         from asac_amd import native
-        from algorithm.fused_mlp import _flat_alias
+        from algorithm.fused_mlp import _flat_alias, direct_enabled
         xq, xk, weights, keep, *rest = ctx.saved_tensors
         attn_out = rest[0] if rest else None
         params, tail = ctx.params, ctx.tail
@@ -193,7 +193,7 @@ class _AttnProjFn(torch.autograd.Function):
         pd = [t.detach().contiguous() for t in params]
         gw = None if g_w is None else g_w.contiguous()
         flat = None
-        if all(p.requires_grad and p.grad is not None for p in params):
+        if direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
         if flat is not None:
             native.attention_proj_backward(xq, xk, pd, weights, g_out.contiguous(), gw, g_xq, g_xk, flat, True, ws,

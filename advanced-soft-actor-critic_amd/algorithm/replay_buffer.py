@@ -19,8 +19,9 @@ API kept from the reference: constructor arguments, `add`, `add_with_td_error`, 
   * `sample()` returns the ids as a device int64 tensor (not a NumPy array) and `update*` accept
     device tensors — no D2H round trip on the hot path; NumPy inputs are still accepted
   * a NaN td-error cannot raise synchronously: the update kernel skips the batch and raises a
-    device flag which `check_health()` (called by `close()` / `save()` / periodically) turns into
-    the reference's `Exception('td_error has nan')`
+    device flag which `check_health()` turns into the reference's `Exception('td_error has nan')`;
+    `SAC_Base.train()` calls it every `write_summary_per_step` steps and before every checkpoint,
+    `close()` / `save()` call it too
 The HIP library is mandatory (`asac_amd.native`): there is no CPU fallback.
 """
 import logging
@@ -87,8 +88,10 @@ class PrioritizedReplayBuffer:
             self._slot_ids = torch.zeros(C, dtype=torch.int64, device=dev)
             # scratch: winner map for last-writer-wins (+ spill for > 1024-item updates)
             self._winner = torch.full((C + 2 * max(4096, batch_size),), -1, dtype=torch.int32, device=dev)
-            # a second election scratch so row write-backs may overlap the priority update (own stream)
+            # election scratch of the row write-backs (they may overlap the priority update), and one more for a
+            # write-back issued on a second stream beside another write-back (`side=True`)
             self._winner_rows = torch.full((C,), -1, dtype=torch.int32, device=dev)
+            self._winner_rows_side = None
             self._nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             self._beta = torch.tensor([beta], dtype=torch.float64, device=dev)
             self._max_p = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -271,11 +274,13 @@ class PrioritizedReplayBuffer:
         k = ids.numel()
         if k == 0:
             return
-        if k > 1024 and self._winner.numel() < self.capacity + 2 * k:
-            self._winner = torch.full((self.capacity + 2 * k,), -1, dtype=torch.int32, device=self.device)
-        native.sumtree_update(self._tree, self.capacity, ids, self._slot_ids if stale_check else None,
-                              td, self.alpha, self.td_error_min, self.td_error_max, mode,
-                              self._winner, self._nan_flag)
+        # the election scratch is allocated once (a captured hipGraph holds its address): longer updates go in
+        # pieces, which is equivalent (later writers win, piece after piece)
+        piece = (self._winner.numel() - self.capacity) // 2
+        for s in range(0, k, piece):
+            native.sumtree_update(self._tree, self.capacity, ids[s:s + piece], self._slot_ids if stale_check else None,
+                                  td[s:s + piece], self.alpha, self.td_error_min, self.td_error_max, mode,
+                                  self._winner, self._nan_flag)
 
     def update(self, data_ids, td_error) -> None:
         """priority <- clip(td, min, max)^alpha for ids still resident (replay_buffer.py:412-427)."""
@@ -300,7 +305,7 @@ class PrioritizedReplayBuffer:
                                             self._slot_ids, None, 0, rows, row_bytes, row_bytes, self._winner_rows)
 
     def update_window_transitions(self, sample_ids: torch.Tensor, first_off: int, count: int,
-                                  padding_mask: torch.Tensor, key: str, rows: torch.Tensor) -> None:
+                                  padding_mask: torch.Tensor, key: str, rows: torch.Tensor, side=False) -> None:
         """Fused form used by SAC_Base.train: rows[s, j] -> id = sample_ids[s] + first_off + j for
         j < count, skipping padded positions and overwritten slots (reference sac_base.py:2589-2605
         builds those id lists on the host).  `rows` is [B, >=count, *shape] (a view is fine)."""
@@ -310,10 +315,15 @@ class PrioritizedReplayBuffer:
             return
         assert rows.dtype == col.dtype
         es = rows.element_size()
+        scratch = self._winner_rows
+        if side:    # concurrent with a write-back on another stream: two elections must not share their map
+            if self._winner_rows_side is None:
+                self._winner_rows_side = torch.full_like(self._winner_rows, -1)
+            scratch = self._winner_rows_side
         native.scatter_rows_if_id_match(col, row_bytes, self.capacity, sample_ids, sample_ids.numel(),
                                         first_off, count, self._slot_ids, padding_mask,
                                         padding_mask.stride(0), rows, rows.stride(0) * es,
-                                        rows.stride(1) * es, self._winner_rows)
+                                        rows.stride(1) * es, scratch)
 
     # ------------------------------------------------------------------------------------------
     # random access (used by the option-critic variant) and bookkeeping

@@ -34,7 +34,7 @@ from torch.nn import functional
 from asac_amd import native
 
 from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls
-from .fused_mlp import StockMLP, describe_policy, describe_q
+from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
 from .nn_models.layers.attention import step_mask_cache
 from .nn_models.rep import ModelSimpleRep
@@ -61,7 +61,8 @@ def _masked_mse_backward(pred, target, padding_mask, loss_out):
         flat = d.reshape(-1)
         torch.div(torch.dot(flat, flat), flat.numel(), out=loss_out)
         d.mul_(2. / flat.numel())
-    pred.backward(d)
+    with direct_param_grads():      # detached inputs: the backward reaches the model's own parameters only
+        pred.backward(d)
 
 
 class SAC_Base(AuxHeadsMixin):
@@ -249,6 +250,10 @@ class SAC_Base(AuxHeadsMixin):
         self._graph = None
         self._graph_failed = False
         self._eager_steps = 0
+        # called (eager steps only, never captured) right after the representation / critic update of a step: the
+        # parity tests read the freshly updated weights there, or align them with the reference's so that what
+        # the step computes afterwards is compared from identical weights
+        self.after_rep_q_update = None
 
         self._build_model(nn, nn_config, init_log_alpha, learning_rate)
         self._build_ckpt()
@@ -380,13 +385,13 @@ class SAC_Base(AuxHeadsMixin):
             if all(d is not None for d in dq) and consecutive:
                 tseg = self._target_params.segments
                 self._fq = StockMLP(dq[0], self._params.flat, self._params.grad, seg['q_0'][0], stride,
-                                    self.ensemble_q_num, dev)
+                                    self.ensemble_q_num, dev, [p for q in self.model_q_list for p in q.parameters()])
                 self._ftq = StockMLP(dq[0], self._target_params.flat, None, tseg['q_0'][0], stride,
                                      self.ensemble_q_num, dev)
             dp = describe_policy(self.model_policy)
             if dp is not None:
                 self._fpi = StockMLP(dp, self._params.flat, self._params.grad, seg['policy'][0],
-                                     seg['policy'][1] - seg['policy'][0], 1, dev)
+                                     seg['policy'][1] - seg['policy'][0], 1, dev, list(self.model_policy.parameters()))
         self._logger.info(f'fused stock MLP path: Q={self._fq is not None} policy={self._fpi is not None}')
         # When the stock networks and the temperatures are the only trainable parameters, every gradient
         # slot is written exactly once per step by a kernel: overwrite instead of memset + accumulate.
@@ -529,6 +534,8 @@ class SAC_Base(AuxHeadsMixin):
     def save_model(self, save_replay_buffer=False) -> None:
         if self.ckpt_dir is None:
             return
+        if self.use_replay_buffer and self.train_mode:
+            self.replay_buffer.check_health()      # never write a checkpoint of a run whose td-errors went NaN
         step = self.get_global_step()
         path = self.ckpt_dir.joinpath(f'{step}.pth')
         torch.save({k: (v.detach().clone() if isinstance(v, torch.Tensor) else v.state_dict())
@@ -1041,7 +1048,8 @@ class SAC_Base(AuxHeadsMixin):
                     w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                     native.q_loss_fwd_bwd(c_q.detach().contiguous(), t_q.contiguous(), c_y.reshape(-1), w,
                                           self.clip_epsilon, self._loss_q_e, self._grad_q)
-                    torch.autograd.backward([c_q], [self._grad_q])
+                    with direct_param_grads():
+                        torch.autograd.backward([c_q], [self._grad_q])
                     return self._finish_rep_q(None, None)
                 clipped = t_q + torch.clamp(c_q - t_q, -self.clip_epsilon, self.clip_epsilon)
                 yv = c_y.reshape(1, -1)
@@ -1060,12 +1068,15 @@ class SAC_Base(AuxHeadsMixin):
     def _finish_rep_q(self, total_loss, loss_q0, aux=None, ctx=None):
         if total_loss is not None:
             # the prediction heads differentiate the representation graph again (sac_aux._train_rpm)
-            total_loss.backward(retain_graph=aux is not None and self.use_prediction)
+            # the main loss accumulates into every parameter it reaches (representation + Q ensemble): the fused
+            # layers add their parameter gradients in place
+            with direct_param_grads():
+                total_loss.backward(retain_graph=aux is not None and self.use_prediction)
             self._stats['loss_q'].copy_(loss_q0.detach())
-        if self._dist is not None:
-            self._dist.all_reduce_grads(self._params.grad, *self._params.span('rep', f'q_{self.ensemble_q_num - 1}'))
         start, stop = self._params.span('rep', f'q_{self.ensemble_q_num - 1}')
         if aux is None:
+            if self._dist is not None:
+                self._dist.all_reduce_grads(self._params.grad, start, stop)
             # Q optimizers then the representation optimizer (1589-1603): adjacent segments, one launch
             self.optimizer_q_list[0].step(start, stop)
             return
@@ -1077,12 +1088,18 @@ class SAC_Base(AuxHeadsMixin):
             self._train_siamese_representation_learning(grads_rep_main, grads_q_main, aux['n_indexes'],
                                                         ctx['n_padding_masks'], n_obs, aux['n_pre_actions'],
                                                         aux['n_pre_seq_hidden_states'])
+        # data parallel: every segment is averaged over the ranks AFTER the auxiliary heads have added their (gated)
+        # gradients to it and right before its optimizer steps, so the replicas stay identical
         q_start = self._params.span('q_0')[0]
+        if self._dist is not None:
+            self._dist.all_reduce_grads(self._params.grad, q_start, stop)
         self.optimizer_q_list[0].step(q_start, stop)
         if self.use_prediction:
             self._train_rpm(grads_rep_main, ctx['nx_obses_list'], ctx['nx_states'], aux['nx_target_states'],
                             ctx['nx_actions'][:, :-1], ctx['n_rewards'])
         if self.optimizer_rep is not None:
+            if self._dist is not None:
+                self._dist.all_reduce_grads(self._params.grad, *self._params.span('rep'))
             self.optimizer_rep.step()
 
     def _stock_c_only(self) -> bool:
@@ -1158,7 +1175,9 @@ class SAC_Base(AuxHeadsMixin):
             pi_ent = d_policy.entropy().sum(-1) / self.d_action_branch_size
             loss_d = loss_d + self.d_policy_entropy_penalty * (torch.pow(mu_ent - pi_ent, 2.) / 2.).unsqueeze(-1)
 
-        pi_inputs = [self._fpi._anchor] if self._fpi is not None else list(self.model_policy.parameters())
+        # restricted to the policy: its parameters (and the fused policy's anchor); the Q ensemble only passes the
+        # action gradient through (param_grads=False), so the direct accumulation reaches the policy alone
+        pi_inputs = list(self.model_policy.parameters()) + ([self._fpi._anchor] if self._fpi is not None else [])
         if self.c_action_size and not self.d_action_sizes and plain and not (self.offline_enabled and self.offline_loss):
             # continuous-only fast path: objective, its gradients and the entropy statistic from one
             # launch; back-propagation starts at (logp, q) with the kernel-produced gradients
@@ -1174,7 +1193,8 @@ class SAC_Base(AuxHeadsMixin):
                                        sub if self.ensemble_q_sample != E else None, self.ensemble_q_sample,
                                        self.log_c_alpha, scale.detach(), self._stats['loss_policy'],
                                        self._grad_logp, self._grad_q, self._stats['c_entropy'])
-            torch.autograd.backward([logp, c_qs], [self._grad_logp, self._grad_q], inputs=pi_inputs)
+            with direct_param_grads():
+                torch.autograd.backward([logp, c_qs], [self._grad_logp, self._grad_q], inputs=pi_inputs)
             if self._dist is not None:
                 self._dist.all_reduce_grads(self._params.grad, *self._params.span('policy'))
             self.optimizer_policy.step()
@@ -1203,7 +1223,8 @@ class SAC_Base(AuxHeadsMixin):
                                                       reduction='none').sum(-1, keepdim=True)
 
         loss = torch.mean(loss_c if loss_d is None else (loss_d if loss_c is None else loss_d + loss_c))
-        loss.backward(inputs=pi_inputs)
+        with direct_param_grads():
+            loss.backward(inputs=pi_inputs)
         if self._dist is not None:
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('policy'))
         self.optimizer_policy.step()
@@ -1408,6 +1429,8 @@ class SAC_Base(AuxHeadsMixin):
                           bn_rewards[:, b:], bn_dones[:, b:], bn_mu_probs[:, b:], priority_is, aux,
                           policy_sample=self._stock_c_only() and not rep_trainable,
                           state_base=(bnx_states, b))
+        if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
+            self.after_rep_q_update()
 
         if rep_trainable:   # states under the updated representation (reference 2097-2103)
             with torch.no_grad():
@@ -1467,7 +1490,8 @@ class SAC_Base(AuxHeadsMixin):
                     else:
                         self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
-                rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
+                rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1],
+                                             side=self._parallel_branches)
         if auto_alpha:
             self._train_alpha(obs_b, state_b, ls=None if ls_win is None else ls_win[:, b], logp=alpha_logp)
         if self.curiosity is not None:
@@ -1564,10 +1588,15 @@ class SAC_Base(AuxHeadsMixin):
                 self._device_step()
                 self._eager_steps += 1
 
+        # host synchronisation points the reference has too: here the NaN flag of the priority update kernels is
+        # read back, so a diverged run raises the reference's 'td_error has nan' (replay_buffer.py:418-420) within
+        # `write_summary_per_step` steps instead of training on with frozen priorities
+        if step % self.write_summary_per_step == 0:
+            rb.check_health()
+            if self.summary_writer is not None:
+                self._write_train_summaries(step)
         if step % self.save_model_per_step == 0:
             self.save_model()
-        if self.summary_writer is not None and step % self.write_summary_per_step == 0:
-            self._write_train_summaries(step)
         return self.increase_global_step()
 
     @torch.no_grad()

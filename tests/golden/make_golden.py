@@ -361,9 +361,18 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
     seen = {}
     orig_rq, orig_pol = sac._train_rep_q, sac._train_policy
 
+    rep_trains = any(p.requires_grad for p in sac.model_rep.parameters())
+
     def rq(*a, **k):
         r = orig_rq(*a, **k)
         seen['loss_q'] = r[0].detach().numpy().copy()
+        if rep_trains:
+            # representation and critics right after their Adam updates (sac_base.py:1589-1603): everything the
+            # step computes afterwards starts from these weights
+            for name, m in mods.items():
+                if name == 'model_rep' or name.startswith('model_q_'):
+                    for kk, v in m.state_dict().items():
+                        seen[f'w_rq/{name}/{kk}'] = v.numpy().copy()
         return r
 
     def pol(*a, **k):
@@ -448,6 +457,9 @@ def f6_step(case, nn_rel, sac_kw, ep_lens, n_steps, obs_shapes=((6,),), obs_name
         out[f'step{s}/log_d_alpha'] = sac.log_d_alpha.detach().numpy().copy()
         if 'loss_curiosity' in seen:
             out[f'step{s}/loss_curiosity'] = seen['loss_curiosity']
+        for kk, v in seen.items():
+            if kk.startswith('w_rq/'):
+                out[f'step{s}/{kk}'] = v
     for name, m in mods.items():
         for k, v in m.state_dict().items():
             out[f'w1/{name}/{k}'] = v.numpy().copy()

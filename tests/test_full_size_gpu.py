@@ -6,7 +6,10 @@ Protocol: product learner and `oracle.sac_ref.SacRef` start from identical weigh
 product draws its own numbers on the device (Philox, the graph-capturable source the bench runs with); after each
 step the draws are read back from the step's static buffers and replayed on the oracle, so both sides consume the
 same uniforms, Gaussians and ensemble subsets.  Step 0 runs eager, step 1 is the capture + first replay, step 2 a
-replay.  Required: PER ids bit-exact, IS weights to 2e-6, losses / td-errors / priorities within the fp32
+replay.  After a step has been compared, the oracle's replay state (tree bytes, written-back probabilities and
+hidden states) is set to the product's: index selection is a discontinuous function of the priorities, so a
+1e-4 difference in one td-error would otherwise move a later stratum boundary across a sampled value — every
+step's sampling is compared from identical replay contents, its results within the float tolerances.  Required: PER ids bit-exact, IS weights to 2e-6, losses / td-errors / priorities within the fp32
 tolerances of tests/test_sac_step_gpu.py.  This covers what the small goldens cannot: the multi-workgroup return
 kernel, the fused sampler at 256..1024 strata over 19 tree levels, convolution group tails at 4 608 and 9 216
 frames, the GRU at 256 x 81."""
@@ -93,8 +96,8 @@ def test_baseline_config_full_size_vs_oracle(name):
         oracle.noise = sac_ref.RecordedNoise(u, eps, perm)
         out = oracle.train()
         assert not oracle.noise.eps and not oracle.noise.perm and not oracle.noise.u
-        assert np.array_equal(rb._ids.cpu().numpy(), out['ids']), f'{name} step {step}: PER index selection'
-        np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], out['is_weights'], rtol=2e-6)
+        assert np.array_equal(rb._ids.cpu().numpy(), out['ids']), f'{name} step {step}: PER index selection differs in {int((rb._ids.cpu().numpy() != out["ids"]).sum())} of {B} rows'
+        np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], out['is_weights'], rtol=2e-6, err_msg=f'step {step}')
         np.testing.assert_allclose(agent._stats['loss_q'].item(), float(out['loss_q']), rtol=rt)
         if cfg.get('curiosity'):
             np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), float(out['loss_curiosity']), rtol=rt)
@@ -106,6 +109,9 @@ def test_baseline_config_full_size_vs_oracle(name):
             np.testing.assert_allclose(rb._columns['pre_seq_hidden_state'].cpu().numpy(),
                                        orb.storage.columns['pre_seq_hidden_state'], rtol=rt, atol=5e-5)
         np.testing.assert_allclose(agent.log_c_alpha.item(), oracle.log_c_alpha.item(), rtol=2e-4)
+        orb.tree.tree[:] = rb._tree.cpu().numpy()
+        for key in ('mu_prob', 'pre_seq_hidden_state'):
+            orb.storage.columns[key][...] = rb._columns[key].cpu().numpy()
     rb.check_health()
     assert rb.check_tree_invariant() == 0
     agent.close()

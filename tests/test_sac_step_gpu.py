@@ -31,9 +31,25 @@ def make_agent(case, use_graph=False):
 #   first-step gradients, entry by entry                                          rtol 2e-3 + 2e-5 * max|tensor|
 #   weights after the steps                                                        rtol 5e-4 + atol 2e-5, except entries whose
 #       reference gradient is (analytically or numerically) zero, see parity_utils.assert_weights_close
-# Cases whose representation is itself trained by the step carry the rounding of one more Adam update into the
-# observables taken after it (td-errors, written-back probabilities): 1e-3 there.
-TRAINED_REP = ('attn', 'conv', 'conv_attn_cur')
+# Cases whose representation is itself trained by the step: Adam's sign-like first updates move entries with a
+# rounding-level gradient by +-lr with a device-dependent sign, and everything the step computes after that update
+# (policy step, temperature, written-back probabilities, td-errors) would inherit the difference.  The test therefore
+# (1) compares the freshly updated representation / critic weights with the reference's (`step<s>/w_rq/...`, recorded
+# right after the reference's own update) under the sign-aware bound of `parity_utils.assert_weights_close`, then
+# (2) aligns them with the reference's (`SAC_Base.after_rep_q_update`), so the rest of the step is compared from
+# identical weights at the same tolerances as every other case.
+TRAINED_REP = ('cfg3', 'attn', 'conv', 'conv_attn_cur')
+
+
+# `attn`: the attention output IS the state (no tanh head), |state| reaches 18, the stock policy saturates and its
+# log-std hits the clamp: scale = 6.8e-9 next to |loc| = 5.  The reference evaluates Normal.log_prob(loc + eps * scale)
+# in f32, where (loc + eps * scale) - loc cancels catastrophically (eps * scale < ulp(loc)), and autograd sums
+# +-eps/scale ~ 1e8-sized terms that only cancel analytically: its policy gradient is 2 % away from the exact one.
+# The sampling backward here uses the analytic form (d logp / d scale = -1 / scale, the Normal term's x- and
+# loc-paths cancel): `test_attn_policy_gradient_against_float64` shows it within 1e-5 of a float64 evaluation while
+# the recorded reference gradient is 2e-2 away from the same float64 result.  The policy gradient of this one case is
+# therefore compared there, not against the golden.
+REFERENCE_ILL_CONDITIONED = {'attn': ('optimizer_policy',)}
 
 
 @pytest.mark.parametrize('case', list(pu.STEP_CASES))
@@ -46,9 +62,24 @@ def test_full_step_vs_reference_golden(golden_dir, case):
     for ep in pu.golden_episodes(g, len(io['obs_shapes'])):
         agent.put_episode(**ep)
     rb = agent.replay_buffer
-    rt = 1e-3 if case in TRAINED_REP else 2e-4
+    rt = 2e-4
+    # what the step computes after the policy update inherits the policy's difference where the reference's own
+    # policy gradient is ill-conditioned (see REFERENCE_ILL_CONDITIONED)
+    rt_post = 3e-3 if case in REFERENCE_ILL_CONDITIONED else rt
     n_steps = int(g['n_steps'])
+    step_box, slack_rq = [0], {}
+
+    def align_with_reference():
+        s_ = step_box[0]
+        # one Adam update away from weights that were aligned (or loaded) before it
+        slack_rq.update(pu.assert_weights_close(mods, g, 1, LR, rtol=5e-4, atol=2e-5, prefix=f'step{s_}/w_rq'))
+        pu.load_golden_weights(agent, g, prefix=f'step{s_}/w_rq')
+
+    if case in TRAINED_REP:
+        assert f'step0/w_rq/model_q_0/{next(iter(agent.model_q_list[0].state_dict()))}' in g.files
+        agent.after_rep_q_update = align_with_reference
     for s in range(n_steps):
+        step_box[0] = s
         eps = [g[f'step{s}/eps{j}'] for j in range(int(g[f'step{s}/n_eps']))]
         agent.noise = RecordedNoise([g[f'step{s}/u']], eps, list(g[f'step{s}/perm']))
         rb.uniform_source = agent.noise
@@ -57,35 +88,93 @@ def test_full_step_vs_reference_golden(golden_dir, case):
         assert agent.noise.exhausted(), 'every recorded draw must be consumed, in order'
         assert np.array_equal(rb._ids.cpu().numpy(), g[f'step{s}/sample_ids']), f'step {s}: PER index selection'
         np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], g[f'step{s}/is_weights'], rtol=2e-6)
-        np.testing.assert_allclose(agent._stats['loss_q'].item(), g[f'step{s}/loss_q'], rtol=rt)
+        rt_s = rt if s == 0 else rt_post       # later steps start from the policy the earlier ones left
+        np.testing.assert_allclose(agent._stats['loss_q'].item(), g[f'step{s}/loss_q'], rtol=rt_s)
         # the policy objective and the entropy the reference returns from _train_policy (sac_base.py:1903-1911)
         agent._refresh_policy_stats(alpha_before)
-        np.testing.assert_allclose(agent._stats['loss_policy'].item(), g[f'step{s}/loss_policy'], rtol=rt, atol=2e-5)
+        np.testing.assert_allclose(agent._stats['loss_policy'].item(), g[f'step{s}/loss_policy'], rtol=rt_s, atol=2e-5)
         if f'step{s}/c_entropy' in g.files:
-            np.testing.assert_allclose(agent._stats['c_entropy'].item(), g[f'step{s}/c_entropy'], rtol=rt, atol=2e-5)
+            np.testing.assert_allclose(agent._stats['c_entropy'].item(), g[f'step{s}/c_entropy'], rtol=rt_s, atol=2e-5)
         if f'step{s}/d_entropy' in g.files:
-            np.testing.assert_allclose(agent._stats['d_entropy'].item(), g[f'step{s}/d_entropy'], rtol=rt, atol=2e-5)
+            np.testing.assert_allclose(agent._stats['d_entropy'].item(), g[f'step{s}/d_entropy'], rtol=rt_s, atol=2e-5)
         if f'step{s}/loss_curiosity' in g.files:
-            np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), g[f'step{s}/loss_curiosity'], rtol=rt)
+            np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), g[f'step{s}/loss_curiosity'], rtol=rt_s)
         if s == 0:
-            pu.assert_first_step_gradients(agent, g, rtol=2e-3, atol_frac=2e-5)
+            pu.assert_first_step_gradients(agent, g, rtol=2e-3, atol_frac=2e-5, skip=REFERENCE_ILL_CONDITIONED.get(case, ()))
         if f'step{s}/td_error' in g.files:
             np.testing.assert_allclose(agent._td_error.cpu().numpy()[:, None], g[f'step{s}/td_error'],
-                                       rtol=rt, atol=2e-5)
-            np.testing.assert_allclose(rb._tree.cpu().numpy(), g[f'step{s}/tree'], rtol=rt, atol=1e-6)
+                                       rtol=rt_post, atol=2e-5)
+            np.testing.assert_allclose(rb._tree.cpu().numpy(), g[f'step{s}/tree'], rtol=rt_post, atol=1e-6)
         # stored-action probabilities are exp() of a log-density with 1/sigma^2 gain on f32 noise of loc: 1e-3
-        np.testing.assert_allclose(rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob'],
-                                   rtol=5e-3 if case in TRAINED_REP else 1e-3, atol=1e-6)
+        mu, mu_want = rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob']
+        if case in REFERENCE_ILL_CONDITIONED:   # ... and sigma = 7e-9 there: a density of 1e8 next to 0
+            bad = np.abs(mu - mu_want) > 1e-3 + 5e-2 * np.abs(mu_want)
+            assert bad.mean() <= 0.01, f'{bad.sum()} / {bad.size} written-back probabilities differ'
+        else:
+            np.testing.assert_allclose(mu, mu_want, rtol=1e-3, atol=1e-6)
         if rb._columns['pre_seq_hidden_state'].shape[-1]:
             np.testing.assert_allclose(rb._columns['pre_seq_hidden_state'].cpu().numpy(), g[f'step{s}/hidden'],
-                                       rtol=rt, atol=2e-5)
-        np.testing.assert_allclose(agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'], rtol=1e-5 if case not in TRAINED_REP else 2e-4)
-    if agent.curiosity is not None:
-        mods['model_forward_dynamic'] = agent.model_forward_dynamic
-    slack = pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5)
-    print(f'{case}: tensors with zero-gradient entries (fraction given +-lr slack): {slack}')
+                                       rtol=rt_s, atol=2e-5)
+        np.testing.assert_allclose(agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'], rtol=5e-5 if case in REFERENCE_ILL_CONDITIONED else 1e-5)
+    # the parameters with an analytically zero gradient, by name: the key-projection biases of the attention blocks
+    zero = pu.zero_gradient_tensors(g, mods)
+    assert all('k_proj' in z and z.endswith('bias') for z in zero), zero
+    assert bool(zero) == ('attn' in case)
+    ill = [m for m in mods if any('model_' + o.split('_', 1)[1] == m for o in REFERENCE_ILL_CONDITIONED.get(case, ()))]
+    slack = pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5, only=[m for m in mods if m not in ill])
+    if ill:     # a gradient the reference itself only knows to 2 %: the sign of entries below 10 % of the largest is open
+        slack.update(pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5, small_frac=0.1, only=ill))
+    print(f'{case}: zero-gradient parameters {zero}; entries given +-lr slack after the first update {slack_rq}, '
+          f'after {n_steps} steps {slack}')
     rb.check_health()
     assert rb.check_tree_invariant() == 0
+    agent.close()
+
+
+def test_attn_policy_gradient_against_float64(golden_dir):
+    """The arbiter for REFERENCE_ILL_CONDITIONED: the policy step of the golden `attn` step 0, from the very weights
+    and state the product's policy step sees, evaluated on the host in float64 with the reference's formulas
+    (sac_base.py:1883-1903, operators.py:12-24).  The product's gradient has to sit within 1e-5 (of each tensor's
+    largest entry) of it; the reference's recorded f32 gradient is shown to be >= 100 times further away."""
+    import copy
+    from algorithm.fused import RecordedNoise
+    from oracle import sac_ref
+    g = np.load(golden_dir / 'f6_step_attn.npz')
+    agent = make_agent('attn')
+    pu.load_golden_weights(agent, g)
+    for ep in pu.golden_episodes(g, 1):
+        agent.put_episode(**ep)
+    eps = [g[f'step0/eps{j}'] for j in range(int(g['step0/n_eps']))]
+    agent.noise = RecordedNoise([g['step0/u']], eps, list(g['step0/perm']))
+    agent.replay_buffer.uniform_source = agent.noise
+    agent.after_rep_q_update = lambda: pu.load_golden_weights(agent, g, prefix='step0/w_rq')
+    box, orig = {}, agent._train_policy
+
+    def spy(obs_list, state, action, mu, ls=None):
+        box.update(state=state.detach().cpu().double().clone(), pi=copy.deepcopy(agent.model_policy).cpu().double(),
+                   q=[copy.deepcopy(q).cpu().double() for q in agent.model_q_list],
+                   alpha=agent.log_c_alpha.detach().cpu().double().exp())
+        return orig(obs_list, state, action, mu, ls=ls)
+
+    agent._train_policy = spy
+    agent.train()
+    got = [m.cpu().numpy() / 0.1 for m in pu.product_first_moments(agent)['optimizer_policy']]
+    d_policy, c = box['pi'](box['state'], [None])
+    x = c.loc + torch.from_numpy(g['step0/eps1']).double() * c.scale
+    c_qs = torch.stack([q(box['state'], torch.tanh(x), [None])[1] for q in box['q']])
+    logp = sac_ref.masked_sum_log_prob(sac_ref.squash_log_prob(c, x), keepdim=True)
+    loss = torch.mean(box['alpha'] * logp - c_qs.min(0)[0])
+    assert abs(loss.item() - float(g['step0/loss_policy'])) < 5e-4 * abs(loss.item())
+    exact = [t.numpy() for t in torch.autograd.grad(loss, list(box['pi'].parameters()))]
+    assert float(c.scale.min()) < 1e-7 * float(c.loc.abs().max()), 'the case is ill-conditioned because of this'
+    worst_product = worst_reference = 0.
+    for j, e in enumerate(exact):
+        scale = np.abs(e).max()
+        worst_product = max(worst_product, np.abs(got[j] - e).max() / scale)
+        worst_reference = max(worst_reference, np.abs(g[f'g0/optimizer_policy/{j}'] / 0.1 - e).max() / scale)
+    print(f'policy gradient vs float64: product {worst_product:.2e}, recorded reference {worst_reference:.2e}')
+    assert worst_product < 1e-5
+    assert worst_reference > 100 * worst_product
     agent.close()
 
 
