@@ -669,8 +669,10 @@ class SAC_Base(AuxHeadsMixin):
                     c_action = torch.tanh(c_policy.mean)
                 elif use_rnd:
                     c_action = self.rnd_sample_c_action(state, c_policy)
-                else:
-                    c_action = torch.tanh(c_policy.sample())
+                else:   # `c_policy.sample()` (reference 944) with the Gaussian draw taken from `self.noise`
+                    eps = torch.empty_like(c_policy.loc)
+                    self.noise.normal_(eps)
+                    c_action = torch.tanh(self._rsample(c_policy, eps))
             else:
                 c_action = torch.zeros(0, device=self.device)
             d_action, c_action = self._random_action(d_action, c_action)
