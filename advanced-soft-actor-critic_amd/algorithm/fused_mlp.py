@@ -373,7 +373,7 @@ class StockMLP:
         FlatAdam whose moment buffers cover the same flat layout)."""
         N = self._deferred_rows
         assert N is not None, 'no deferred backward pending'
-        tiles = (N + 31) // 32
+        tiles = native.mlp_backward_tiles(N, self.E)
         s0 = self._start
         s1 = s0 + self.E * self.member_stride
         native.adam_step_partials(self.params, self.grad_params, opt.exp_avg[s0:s1], opt.exp_avg_sq[s0:s1], opt.lr,

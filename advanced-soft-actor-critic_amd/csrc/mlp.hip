@@ -26,72 +26,97 @@
 
 namespace asac {
 
-constexpr int kTM = 32;          // rows per workgroup tile
+// Rows per workgroup tile: TM = 32 (8 waves: 2 row tiles x 4 column tiles) or TM = 16 (4 waves, one per column tile).
+// The f32 MFMA rate of ONE CU is what a layer costs (32 x 64 x 64: 1024 cycles, 0.43 us at 2.4 GHz), so a pass that
+// has few rows (the batch-256 launches of the train step) takes 16-row tiles and twice the workgroups — half the MFMA
+// time per layer on twice as many of the 256 CUs — while long row sets keep 32-row tiles (one resident round).
 constexpr int kP = 66;           // LDS pitch (floats)
 constexpr int kMaxW = 64;        // max layer width / input width
 constexpr int kMaxB = ASAC_MLP_MAX_BLOCKS;
 constexpr int kHeadPad = 16;     // head output columns are padded to one MFMA tile
-constexpr int kThreads = 512;    // 8 waves: 2 row tiles x 4 column tiles
+constexpr int kMaxThreads = 512;
+template <int TM> constexpr int threads_of() { return TM * 16; }    // one thread per (row, 4-column group)
+
+// 16-row tiles while they still fit one resident round of workgroups
+inline int mlp_tile_rows(int64_t N, int E) { return ((N + 15) / 16) * (int64_t)(E > 0 ? E : 1) <= 256 ? 16 : 32; }
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// phase time stamps of workgroup (0, 0) for tools/mlp_phases.hip (100 MHz wall clock); compiled out of the library
+#ifdef ASAC_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[32];
+#define MLP_STAMP(i)                                                                             \
+    do {                                                                                         \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_mlp_stamps[i] = wall_clock64(); \
+    } while (0)
+#else
+#define MLP_STAMP(i)
+#endif
 
 __device__ __forceinline__ int round4(int v) { return (v + 3) & ~3; }
 
 // stage a row-major [rows][cols] global matrix into LDS [64][kP], zero padded to 64 x 64
+template <int THREADS>
 __device__ __forceinline__ void stage_matrix(float* dst, const float* __restrict__ src, int rows, int cols) {
     if (rows == kMaxW && cols == kMaxW && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        constexpr int U = 1024 / THREADS;
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        float4 v[2];
+        float4 v[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) v[u] = s4[threadIdx.x + u * kThreads];
+        for (int u = 0; u < U; ++u) v[u] = s4[threadIdx.x + u * THREADS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = threadIdx.x + u * kThreads;   // float4 index: row q/16, col 4*(q%16)
+        for (int u = 0; u < U; ++u) {
+            const int q = threadIdx.x + u * THREADS;   // float4 index: row q/16, col 4*(q%16)
             float2* d = reinterpret_cast<float2*>(dst + (q >> 4) * kP + ((q & 15) << 2));
             d[0] = make_float2(v[u].x, v[u].y);
             d[1] = make_float2(v[u].z, v[u].w);
         }
         return;
     }
-    float v[8];
+    constexpr int U = 4096 / THREADS;
+    float v[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
         const int r = i >> 6, c = i & 63;
         v[u] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
         dst[(i >> 6) * kP + (i & 63)] = v[u];
     }
 }
 
 // columns [c0, c0 + ncols) of a row-major [rows][cols] global matrix into LDS [64][kP], zero padded to 64 x 64
 // (the two halves of a first layer wider than 64 inputs)
+template <int THREADS>
 __device__ __forceinline__ void stage_matrix_part(float* dst, const float* __restrict__ src, int rows, int cols, int c0,
                                                   int ncols) {
-    float v[8];
+    constexpr int U = 4096 / THREADS;
+    float v[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
         const int r = i >> 6, c = i & 63;
         v[u] = (r < rows && c < ncols) ? src[r * cols + c0 + c] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
         dst[(i >> 6) * kP + (i & 63)] = v[u];
     }
 }
 
 // the (up to two) head Linear layers as one zero-padded [16][64] matrix + bias vector
+template <int THREADS>
 __device__ __forceinline__ void stage_heads(const asac_mlp_desc_t& d, const float* __restrict__ P, int K,
                                             float* head, float* head_bias) {
-    float v[2];
+    constexpr int U = 1024 / THREADS;
+    float v[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * kThreads;       // 1024 = 16 x 64
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;       // 1024 = 16 x 64
         const int o = i >> 6, c = i & 63;
         float x = 0.f;
         if (c < K) {
@@ -101,8 +126,8 @@ __device__ __forceinline__ void stage_heads(const asac_mlp_desc_t& d, const floa
         v[u] = x;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
         head[(i >> 6) * kP + (i & 63)] = v[u];
     }
     if (head_bias && threadIdx.x < kHeadPad) {
@@ -112,6 +137,111 @@ __device__ __forceinline__ void stage_heads(const asac_mlp_desc_t& d, const floa
         else if (o < d.head_cols[0] + d.head_cols[1]) x = P[d.head_b_off[1] + o - d.head_cols[0]];
         head_bias[o] = x;
     }
+}
+
+// A whole network (every block's weight and bias, the heads) global -> registers -> LDS with ALL global loads issued
+// before the first LDS store: one memory round trip for the kernel's staging phase (each stage_* call on its own
+// waits for its loads before it stores — five dependent round trips of ~0.6 us at the head of every launch).
+template <int THREADS>
+struct StagedNet {
+    float w[kMaxB][4096 / THREADS];
+    float head[1024 / THREADS];
+    float bias[kMaxB];
+    float head_bias;
+};
+
+__device__ __forceinline__ bool fast_tile(const float* src, int rows, int cols) {
+    return rows == kMaxW && cols == kMaxW && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+}
+
+// `skip_first`: block 0 is staged by the caller (a first layer wider than 64 inputs)
+template <int THREADS>
+__device__ __forceinline__ void net_fetch(const asac_mlp_desc_t& d, const float* __restrict__ P, int K0, bool skip_first,
+                                          StagedNet<THREADS>& r) {
+    constexpr int U = 4096 / THREADS;
+    int K = K0;
+#pragma unroll
+    for (int l = 0; l < kMaxB; ++l) {
+        if (l < d.n_blocks) {
+            const int W = d.width[l];
+            const float* src = P + d.w_off[l];
+            if (!(l == 0 && skip_first)) {
+                if (fast_tile(src, W, K)) {
+                    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+                    for (int u = 0; u < U / 4; ++u) {
+                        const float4 t = s4[threadIdx.x + u * THREADS];
+                        r.w[l][4 * u] = t.x, r.w[l][4 * u + 1] = t.y, r.w[l][4 * u + 2] = t.z, r.w[l][4 * u + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = threadIdx.x + u * THREADS;
+                        const int rr = i >> 6, c = i & 63;
+                        r.w[l][u] = (rr < W && c < K) ? src[rr * K + c] : 0.f;
+                    }
+                }
+            }
+            r.bias[l] = ((int)threadIdx.x < W && threadIdx.x < kMaxW) ? P[d.b_off[l] + threadIdx.x] : 0.f;
+            K = W;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 1024 / THREADS; ++u) {
+        const int i = threadIdx.x + u * THREADS;       // 1024 = 16 x 64
+        const int o = i >> 6, c = i & 63;
+        float x = 0.f;
+        if (c < K) {
+            if (o < d.head_cols[0]) x = P[d.head_w_off[0] + o * K + c];
+            else if (o < d.head_cols[0] + d.head_cols[1]) x = P[d.head_w_off[1] + (o - d.head_cols[0]) * K + c];
+        }
+        r.head[u] = x;
+    }
+    r.head_bias = 0.f;
+    if (threadIdx.x < kHeadPad) {
+        const int o = threadIdx.x;
+        if (o < d.head_cols[0]) r.head_bias = P[d.head_b_off[0] + o];
+        else if (o < d.head_cols[0] + d.head_cols[1]) r.head_bias = P[d.head_b_off[1] + o - d.head_cols[0]];
+    }
+}
+
+template <int THREADS, typename LDS>
+__device__ __forceinline__ void net_put(const asac_mlp_desc_t& d, const float* __restrict__ P, int K0, bool skip_first,
+                                        const StagedNet<THREADS>& r, LDS& L) {
+    constexpr int U = 4096 / THREADS;
+    int K = K0;
+#pragma unroll
+    for (int l = 0; l < kMaxB; ++l) {
+        if (l < d.n_blocks) {
+            const int W = d.width[l];
+            float* dst = L.w[l];
+            if (!(l == 0 && skip_first)) {
+                if (fast_tile(P + d.w_off[l], W, K)) {
+#pragma unroll
+                    for (int u = 0; u < U / 4; ++u) {
+                        const int q = threadIdx.x + u * THREADS;   // float4 index: row q/16, col 4*(q%16)
+                        float2* o2 = reinterpret_cast<float2*>(dst + (q >> 4) * kP + ((q & 15) << 2));
+                        o2[0] = make_float2(r.w[l][4 * u], r.w[l][4 * u + 1]);
+                        o2[1] = make_float2(r.w[l][4 * u + 2], r.w[l][4 * u + 3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = threadIdx.x + u * THREADS;
+                        dst[(i >> 6) * kP + (i & 63)] = r.w[l][u];
+                    }
+                }
+            }
+            if (threadIdx.x < kMaxW) L.bias[l][threadIdx.x] = r.bias[l];
+            K = W;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 1024 / THREADS; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        L.head[(i >> 6) * kP + (i & 63)] = r.head[u];
+    }
+    if (threadIdx.x < kHeadPad) L.head_bias[threadIdx.x] = r.head_bias;
 }
 
 // D[16 x 16] += A[rt*16.., 0..K) * B^T, B = lds [out col][k]: this wave's tile (rt, ct)
@@ -223,15 +353,15 @@ struct MlpArgs {
     const float* log_alpha;    // dL/dlogp = exp(*log_alpha) / N
 };
 
-// a 32 x 64 input tile, 4 slots per thread: global -> registers (fetch) and registers -> LDS (put), so a tile
+// a TM x 64 input tile, 4 slots per thread: global -> registers (fetch) and registers -> LDS (put), so a tile
 // loop can have the next tile's rows in flight while the current one computes
-template <bool WINDOW = false>
+template <int THREADS, bool WINDOW = false>
 __device__ __forceinline__ void fetch_input_tile(const MlpArgs& a, int e, int64_t row0, float (&v)[4], int c0 = 0) {
-    // 32 x 64 slots / 512 threads = 4 each; columns >= in0+in1 are zero; c0 = 64: the second half of a wide input
+    // TM x 64 slots / (16 TM) threads = 4 each; columns >= in0+in1 are zero; c0 = 64: the second half of a wide input
     const int in0 = a.d.in0, in1 = a.d.in1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+        const int i = threadIdx.x + u * THREADS;
         const int r = i >> 6, c = c0 + (i & 63);
         const int64_t row = row0 + r;
         float x = 0.f;
@@ -251,26 +381,164 @@ __device__ __forceinline__ void fetch_input_tile(const MlpArgs& a, int e, int64_
     }
 }
 
+template <int THREADS>
 __device__ __forceinline__ void put_input_tile(const float (&v)[4], float* xs) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * kThreads;
+        const int i = threadIdx.x + u * THREADS;
         xs[(i >> 6) * kP + (i & 63)] = v[u];
     }
 }
 
-template <bool WINDOW = false>
+template <int THREADS, bool WINDOW = false>
 __device__ __forceinline__ void load_input_tile(const MlpArgs& a, int e, int64_t row0, float* xs, int c0 = 0) {
     float v[4];
-    fetch_input_tile<WINDOW>(a, e, row0, v, c0);
-    put_input_tile(v, xs);
+    fetch_input_tile<THREADS, WINDOW>(a, e, row0, v, c0);
+    put_input_tile<THREADS>(v, xs);
 }
 
+// ---- the fixed-shape path (NB > 0: exactly NB blocks, every block 64 wide, first layer <= 64 inputs, parameters
+// 16-byte aligned — the reference's stock Q / policy networks): staging without a single branch.  Every slot loads
+// from a clamped (always valid) address and selects, so the compiler can issue every scalar and vector load of the
+// phase up front and wait once; the generic path's predicated loads compile to a branch per load and a wait per layer.
+// every scalar the staging phase needs, read from the kernel arguments in ONE batch at kernel entry and pinned in
+// SGPRs (otherwise each is fetched where it is first used: a scalar-memory round trip per use site)
+struct StageScalars {
+    const float *P, *x0, *x1;
+    int64_t N, x0_rs, x0_ms, x1_rs, x1_ms, x0_sb;
+    int32_t in0, in1, x0_T, h0, h1, hw0, hw1, hb0, hb1;
+    int32_t w_off[kMaxB], b_off[kMaxB];
+};
+#define ASAC_PIN(x) asm volatile("" : "+s"(x))
+
+template <int NB>
+__device__ __forceinline__ StageScalars stage_scalars(const MlpArgs& a, int e) {
+    StageScalars q;
+    q.P = a.params + e * a.member_stride;
+    q.x0 = a.x0, q.x1 = a.d.in1 > 0 ? a.x1 : a.x0;
+    q.N = a.N, q.x0_rs = a.x0_rs, q.x0_ms = a.x0_ms, q.x1_rs = a.x1_rs, q.x1_ms = a.x1_ms, q.x0_sb = a.x0_sb;
+    q.in0 = a.d.in0, q.in1 = a.d.in1, q.x0_T = a.x0_T;
+    q.h0 = a.d.head_cols[0], q.h1 = a.d.head_cols[1];
+    q.hw0 = a.d.head_w_off[0], q.hw1 = a.d.head_w_off[1], q.hb0 = a.d.head_b_off[0], q.hb1 = a.d.head_b_off[1];
+#pragma unroll
+    for (int l = 0; l < NB; ++l) q.w_off[l] = a.d.w_off[l], q.b_off[l] = a.d.b_off[l];
+    ASAC_PIN(q.P); ASAC_PIN(q.x0); ASAC_PIN(q.x1);
+    ASAC_PIN(q.N); ASAC_PIN(q.x0_rs); ASAC_PIN(q.x0_ms); ASAC_PIN(q.x1_rs); ASAC_PIN(q.x1_ms); ASAC_PIN(q.x0_sb);
+    ASAC_PIN(q.in0); ASAC_PIN(q.in1); ASAC_PIN(q.x0_T); ASAC_PIN(q.h0); ASAC_PIN(q.h1);
+    ASAC_PIN(q.hw0); ASAC_PIN(q.hw1); ASAC_PIN(q.hb0); ASAC_PIN(q.hb1);
+#pragma unroll
+    for (int l = 0; l < NB; ++l) { ASAC_PIN(q.w_off[l]); ASAC_PIN(q.b_off[l]); }
+    return q;
+}
+
+// Buffer loads (raw buffer resource, byte offsets): an offset beyond the resource's size returns 0 from the hardware's
+// range check, so "this slot is padding" is an offset, not a branch — the whole staging phase is straight-line code.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kOob = 0x80000000u;       // beyond every resource below (sizes <= 0x7fffffff bytes)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes = 0x7fffffffu) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int buf_ld(rsrc_t r, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
+}
+
+template <int THREADS, bool WINDOW>
+__device__ __forceinline__ void fetch_input_tile_fixed(const StageScalars& q, int e, int64_t row0, float (&v)[4]) {
+    const int in0 = q.in0, in1 = q.in1;
+    const rsrc_t r0 = make_rsrc(q.x0 + e * q.x0_ms);
+    const rsrc_t r1 = make_rsrc(q.x1 + e * q.x1_ms, in1 > 0 ? 0x7fffffffu : 0u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        const int r = i >> 6, c = i & 63;
+        const uint32_t row = (uint32_t)row0 + (uint32_t)r;
+        const bool live = (int64_t)row0 + r < q.N;
+        uint32_t off = row * (uint32_t)q.x0_rs;
+        if (WINDOW) {       // rows of a [samples, T, in0] window view: (sample, t) addressing
+            const uint32_t smp = row / (uint32_t)q.x0_T;
+            off = smp * (uint32_t)q.x0_sb + (row - smp * (uint32_t)q.x0_T) * (uint32_t)q.x0_rs;
+        }
+        const unsigned o0 = (live && c < in0) ? (off + (uint32_t)c) * 4u : kOob;
+        const unsigned o1 = (live && c >= in0 && c < in0 + in1) ? (row * (uint32_t)q.x1_rs + (uint32_t)(c - in0)) * 4u : kOob;
+        v[u] = __builtin_bit_cast(float, buf_ld(r0, o0) | buf_ld(r1, o1));       // (one of the two is the zero pattern)
+    }
+}
+
+template <int THREADS, int NB>
+__device__ __forceinline__ void net_fetch_fixed(const StageScalars& q, StagedNet<THREADS>& r) {
+    constexpr int U = 4096 / THREADS;
+    const rsrc_t rp = make_rsrc(q.P);
+    const int K0 = q.in0 + q.in1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        const int rr = i >> 6, c = i & 63;
+        r.w[0][u] = __builtin_bit_cast(float, buf_ld(rp, c < K0 ? (unsigned)(q.w_off[0] + rr * K0 + c) * 4u : kOob));
+    }
+#pragma unroll
+    for (int l = 1; l < NB; ++l) {
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rp, (q.w_off[l] + 4 * (int)(threadIdx.x + u * THREADS)) * 4, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.w[l][4 * u + k] = __builtin_bit_cast(float, (int)t[k]);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < NB; ++l) r.bias[l] = __builtin_bit_cast(float, buf_ld(rp, (unsigned)(q.b_off[l] + (threadIdx.x & 63)) * 4u));
+    const int h0 = q.h0, h1 = q.h1;
+#pragma unroll
+    for (int u = 0; u < 1024 / THREADS; ++u) {
+        const int i = threadIdx.x + u * THREADS;       // 1024 = 16 x 64
+        const int o = i >> 6, c = i & 63;
+        const bool first = o < h0, second = !first && o < h0 + h1;
+        const int idx = second ? q.hw1 + (o - h0) * kMaxW + c : q.hw0 + o * kMaxW + c;
+        r.head[u] = __builtin_bit_cast(float, buf_ld(rp, (first || second) ? (unsigned)idx * 4u : kOob));
+    }
+    {
+        const int o = threadIdx.x & 15;
+        const bool first = o < h0, second = !first && o < h0 + h1;
+        const int idx = second ? q.hb1 + o - h0 : q.hb0 + o;
+        r.head_bias = __builtin_bit_cast(float, buf_ld(rp, (first || second) ? (unsigned)idx * 4u : kOob));
+    }
+}
+
+template <int THREADS, int NB, typename LDS>
+__device__ __forceinline__ void net_put_fixed(const StagedNet<THREADS>& r, LDS& L) {
+    constexpr int U = 4096 / THREADS;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        L.w[0][(i >> 6) * kP + (i & 63)] = r.w[0][u];
+    }
+#pragma unroll
+    for (int l = 1; l < NB; ++l) {
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) {
+            const int q = threadIdx.x + u * THREADS;   // float4 index: row q/16, col 4*(q%16)
+            float2* o2 = reinterpret_cast<float2*>(L.w[l] + (q >> 4) * kP + ((q & 15) << 2));
+            o2[0] = make_float2(r.w[l][4 * u], r.w[l][4 * u + 1]);
+            o2[1] = make_float2(r.w[l][4 * u + 2], r.w[l][4 * u + 3]);
+        }
+    }
+    if (threadIdx.x < kMaxW) {
+#pragma unroll
+        for (int l = 0; l < NB; ++l) L.bias[l][threadIdx.x] = r.bias[l];
+    }
+#pragma unroll
+    for (int u = 0; u < 1024 / THREADS; ++u) {
+        const int i = threadIdx.x + u * THREADS;
+        L.head[(i >> 6) * kP + (i & 63)] = r.head[u];
+    }
+    if (threadIdx.x < kHeadPad) L.head_bias[threadIdx.x] = r.head_bias;
+}
+
+template <int TM>
 struct MlpLds {
     float head[kHeadPad * kP];
     float bias[kMaxB][kMaxW];
     float head_bias[kHeadPad];
-    float xs[2][kTM * kP];           // activation ping-pong
+    float xs[2][TM * kP];            // activation ping-pong
     float w[kMaxB][kMaxW * kP];      // every block's weight [out j][in k], zero padded to 64 x 64; LAST: a launch
 };                                   // only allocates the blocks its networks have (mlp_fwd_lds_bytes)
 
@@ -278,65 +546,81 @@ struct MlpLds {
 // activation phase on the long window launches
 // A first layer with more than 64 inputs (up to 128) runs as two 64-column halves: its second weight half takes
 // the tile after the network's blocks, the second input half one more activation tile behind that.
-inline size_t mlp_fwd_lds_bytes(int n_blocks, bool wide = false) {
-    return offsetof(MlpLds, w) + (size_t)(n_blocks + (wide ? 1 : 0)) * kMaxW * kP * sizeof(float) +
-           (wide ? (size_t)kTM * kP * sizeof(float) : 0);
+inline size_t mlp_fwd_lds_bytes(int n_blocks, bool wide = false, int TM = 32) {
+    const size_t head = TM == 16 ? offsetof(MlpLds<16>, w) : offsetof(MlpLds<32>, w);
+    return head + (size_t)(n_blocks + (wide ? 1 : 0)) * kMaxW * kP * sizeof(float) +
+           (wide ? (size_t)TM * kP * sizeof(float) : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
 // One workgroup evaluates member e on the row tiles tile0, tile0 + tile_stride, ...: every layer's weights
 // are staged into LDS ONCE and reused by all of them (for window-sized inputs — tens of thousands of rows —
-// re-staging 36 KB of weights per 32-row tile would be most of the traffic).
-template <bool WINDOW, bool WIDE = false>
+// re-staging 36 KB of weights per tile would be most of the traffic).
+template <int TM, bool WINDOW, bool WIDE = false, int NB = 0>
 __device__ __forceinline__ void mlp_fwd_tiles(const MlpArgs& a, const int e, const int tile0, const int tile_stride,
-                                              MlpLds& L) {
+                                              MlpLds<TM>& L) {
+    constexpr int THREADS = threads_of<TM>();
+    constexpr int RT = TM / 16;                               // row tiles of a workgroup tile
+    constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
+    static_assert(!(fixed && WIDE), "the fixed-shape path has a first layer of <= 64 inputs");
     const float* P = a.params + e * a.member_stride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rt = wave & 1, ct = wave >> 1;
-    const int nb = a.d.n_blocks;
+    const int rt = wave % RT, ct = wave / RT;
+    const int nb = fixed ? NB : a.d.n_blocks;
     const int K0 = a.d.in0 + a.d.in1;
-    const int n_tiles = (int)((a.N + kTM - 1) / kTM);
+    const int n_tiles = (int)((a.N + TM - 1) / TM);
 
     // one staging phase (with the first input tile), one barrier
     constexpr bool wide = WIDE;                              // K0 > 64 (the stock networks' instantiation carries none of it)
     float* w_hi = &L.w[0][0] + nb * kMaxW * kP;              // second half of a wide first layer
     float* x_hi = w_hi + kMaxW * kP;                         // ... and of its input tile
-    load_input_tile<WINDOW>(a, e, (int64_t)tile0 * kTM, L.xs[0]);
-    if (wide) load_input_tile<WINDOW>(a, e, (int64_t)tile0 * kTM, x_hi, kMaxW);
-    int K_last = K0;
-    {
-        int K = K0;
-        for (int l = 0; l < nb; ++l) {
-            const int W = a.d.width[l];
-            if (l == 0 && wide) {
-                stage_matrix_part(L.w[0], P + a.d.w_off[0], W, K0, 0, kMaxW);
-                stage_matrix_part(w_hi, P + a.d.w_off[0], W, K0, kMaxW, K0 - kMaxW);
-            } else {
-                stage_matrix(L.w[l], P + a.d.w_off[l], W, K);
-            }
-            if (threadIdx.x < kMaxW) L.bias[l][threadIdx.x] = (int)threadIdx.x < W ? P[a.d.b_off[l] + threadIdx.x] : 0.f;
-            K = W;
+    StageScalars q;
+    if constexpr (fixed) {
+        q = stage_scalars<NB>(a, e);
+        float in_lo[4];
+        fetch_input_tile_fixed<THREADS, WINDOW>(q, e, (int64_t)tile0 * TM, in_lo);
+        StagedNet<THREADS> regs;
+        net_fetch_fixed<THREADS, NB>(q, regs);
+        put_input_tile<THREADS>(in_lo, L.xs[0]);
+        net_put_fixed<THREADS, NB>(regs, L);
+    } else {
+        float in_lo[4], in_hi[4];
+        fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)tile0 * TM, in_lo);
+        if (wide) fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)tile0 * TM, in_hi, kMaxW);
+        StagedNet<THREADS> regs;
+        net_fetch<THREADS>(a.d, P, K0, wide, regs);
+        put_input_tile<THREADS>(in_lo, L.xs[0]);
+        if (wide) {
+            put_input_tile<THREADS>(in_hi, x_hi);
+            stage_matrix_part<THREADS>(L.w[0], P + a.d.w_off[0], a.d.width[0], K0, 0, kMaxW);
+            stage_matrix_part<THREADS>(w_hi, P + a.d.w_off[0], a.d.width[0], K0, kMaxW, K0 - kMaxW);
         }
-        stage_heads(a.d, P, K, L.head, L.head_bias);
-        K_last = K;
+        net_put<THREADS>(a.d, P, K0, wide, regs, L);
     }
+    const int K_last = fixed ? kMaxW : a.d.width[nb - 1];
     __syncthreads();
 
     const int O = a.d.head_cols[0] + a.d.head_cols[1];
     int cur = 0;                   // the buffer holding the current tile's input
     for (int tile = tile0; tile < n_tiles; tile += tile_stride) {
-        const int64_t row0 = (int64_t)tile * kTM;
+        const int64_t row0 = (int64_t)tile * TM;
         // the next tile's rows travel while this tile computes; they land in the buffer the head phase leaves free
         const bool more = tile + tile_stride < n_tiles;
         float nxt[4], nxt_hi[4];
-        if (more) fetch_input_tile<WINDOW>(a, e, (int64_t)(tile + tile_stride) * kTM, nxt);
-        if (more && wide) fetch_input_tile<WINDOW>(a, e, (int64_t)(tile + tile_stride) * kTM, nxt_hi, kMaxW);
+        if (more) {
+            if constexpr (fixed) fetch_input_tile_fixed<THREADS, WINDOW>(q, e, (int64_t)(tile + tile_stride) * TM, nxt);
+            else fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)(tile + tile_stride) * TM, nxt);
+        }
+        if (more && wide) fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)(tile + tile_stride) * TM, nxt_hi, kMaxW);
         int K = K0;
-        for (int l = 0; l < nb; ++l) {
-            const int W = a.d.width[l];
+#pragma unroll
+        for (int l = 0; l < (fixed ? NB : kMaxB); ++l) {
+            if (l >= nb) break;
+            const int W = fixed ? kMaxW : a.d.width[l];
             const float* xin = L.xs[cur];
             float* xout = L.xs[cur ^ 1];
-            f32x4 acc = gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
+            f32x4 acc = (fixed && l > 0) ? gemm_tile(xin, L.w[l], kMaxW, rt, ct)
+                                         : gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
             if (l == 0 && wide) acc += gemm_tile(x_hi, w_hi, round4(K0 - kMaxW), rt, ct);
             const int col = ct * 16 + (lane & 15);
             const float bias = L.bias[l][col];
@@ -356,10 +640,10 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpArgs& a, const int e, con
             cur ^= 1;
             K = W;
         }
-        if (more) put_input_tile(nxt, L.xs[cur ^ 1]);
-        if (more && wide) put_input_tile(nxt_hi, x_hi);
-        // heads: one padded column tile, waves 0/1 (the two row tiles)
-        if (wave < 2) {
+        if (more) put_input_tile<THREADS>(nxt, L.xs[cur ^ 1]);
+        if (more && wide) put_input_tile<THREADS>(nxt_hi, x_hi);
+        // heads: one padded column tile, the first wave of every row tile
+        if (wave < RT) {
             const f32x4 acc = gemm_tile(L.xs[cur], L.head, round4(K_last), wave, 0);
             const int col = lane & 15;
 #pragma unroll
@@ -374,14 +658,10 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpArgs& a, const int e, con
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_mlp_fwd(const MlpArgs a) {
+template <int TM, bool WIDE, int NB>
+__global__ __launch_bounds__(TM * 16) void k_mlp_fwd(const MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    mlp_fwd_tiles<false>(a, blockIdx.y, blockIdx.x, gridDim.x, *reinterpret_cast<MlpLds*>(smem_raw));
-}
-
-__global__ __launch_bounds__(kThreads) void k_mlp_fwd_wide(const MlpArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    mlp_fwd_tiles<false, true>(a, blockIdx.y, blockIdx.x, gridDim.x, *reinterpret_cast<MlpLds*>(smem_raw));
+    mlp_fwd_tiles<TM, false, WIDE, NB>(a, blockIdx.y, blockIdx.x, gridDim.x, *reinterpret_cast<MlpLds<TM>*>(smem_raw));
 }
 
 // Several independent forward passes (different networks / inputs) in ONE launch: blocks are dealt to the
@@ -394,13 +674,14 @@ struct MlpMultiArgs {
 
 // workgroups along the row-tile axis: one per tile while that keeps the whole grid within about one
 // resident wave of workgroups (one per CU: the LDS footprint), else a fixed number that loop over tiles
-inline int mlp_tile_groups(int64_t N, int E, int per_cu = 1) {
-    const int tiles = (int)((N + kTM - 1) / kTM);
+inline int mlp_tile_groups(int64_t N, int E, int per_cu, int TM) {
+    const int tiles = (int)((N + TM - 1) / TM);
     const int cap = 256 * per_cu / (E > 0 ? E : 1);
     return tiles <= (cap > 1 ? cap : 1) ? tiles : (cap > 1 ? cap : 1);
 }
 
-__global__ __launch_bounds__(kThreads) void k_mlp_fwd_multi(const MlpMultiArgs m) {
+template <int TM, int NB>
+__global__ __launch_bounds__(TM * 16) void k_mlp_fwd_multi(const MlpMultiArgs m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int k = 0;
 #pragma unroll
@@ -408,113 +689,149 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd_multi(const MlpMultiArgs m
         if (q < m.n && (int)blockIdx.x >= m.first_block[q]) k = q;
     const int local = (int)blockIdx.x - m.first_block[k];
     const int E = m.E[k];
-    MlpLds& L = *reinterpret_cast<MlpLds*>(smem_raw);
+    MlpLds<TM>& L = *reinterpret_cast<MlpLds<TM>*>(smem_raw);
     if (m.job[k].x0_T > 0)
-        mlp_fwd_tiles<true>(m.job[k], local % E, local / E, m.tile_stride[k], L);
+        mlp_fwd_tiles<TM, true, false, NB>(m.job[k], local % E, local / E, m.tile_stride[k], L);
     else
-        mlp_fwd_tiles<false>(m.job[k], local % E, local / E, m.tile_stride[k], L);
+        mlp_fwd_tiles<TM, false, false, NB>(m.job[k], local % E, local / E, m.tile_stride[k], L);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Backward.  LDS: block inputs x[0..nb] (x_0 = network input, x_l = output of block l), every
 // weight, one delta tile.  Registers: this wave's fragment of every pre-activation z_l.
 // ------------------------------------------------------------------------------------------------
+template <int TM>
 struct MlpBwdLds {
     float w[kMaxB][kMaxW * kP];
     float head[kHeadPad * kP];
-    float x[kMaxB + 1][kTM * kP];
-    float delta[kTM * kP];
+    float x[kMaxB + 1][TM * kP];
+    float delta[TM * kP];
     float bias[kMaxB][kMaxW];
     float head_bias[kHeadPad];
 };
 
 // partial dW[j][k] = sum_rows delta[row][jbase + j] * xprev[row][k]  -> out[j*K + k]
-// wave w: j tile w>>1, k tiles 2*(w&1) and 2*(w&1)+1
+// 8 waves (TM = 32): wave w owns j tile w>>1, k tiles 2*(w&1) and 2*(w&1)+1; 4 waves (TM = 16): j tile w, all k tiles.
+// The MFMA computes the TRANSPOSED tile (A = xprev^T, B = delta): a lane then holds four consecutive k of one row j,
+// i.e. one 16-byte store per tile instead of four scattered 4-byte ones (the stores were 2/3 of this phase).
+template <int TM>
 __device__ __forceinline__ void grad_weight(const float* __restrict__ delta, int jbase,
                                             const float* __restrict__ xprev, int J, int K,
                                             float* __restrict__ out, int out_stride = 0) {
+    constexpr int RT = TM / 16, KT = 4 / RT, STEPS = TM / 4;
     if (out_stride == 0) out_stride = K;           // (a 64-column half of a wider matrix passes the full width)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    const int jt = wave >> 1;
+    const int jt = wave / RT;
     if (jt * 16 >= J) return;
+    const bool vec = (out_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    float dv[STEPS];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kt = 2 * (wave & 1) + h;
+    for (int i = 0; i < STEPS; ++i) dv[i] = delta[(4 * i + lk) * kP + jbase + jt * 16 + lr];   // B[kk = row][jj = j]
+#pragma unroll
+    for (int h = 0; h < KT; ++h) {
+        const int kt = KT * (wave % RT) + h;
         if (kt * 16 >= K) continue;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        float av[8], bv[8];
+        float xv[STEPS];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            av[i] = delta[(4 * i + lk) * kP + jbase + jt * 16 + lr];   // A[i = j][kk = row]
-            bv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];           // B[kk = row][jj = k]
+        for (int i = 0; i < STEPS; ++i) xv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];       // A[i = k][kk = row]
+#pragma unroll
+        for (int i = 0; i < STEPS; i += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], dv[i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i + 1], dv[i + 1], acc1, 0, 0, 0);
         }
+        const f32x4 acc = acc0 + acc1;      // acc[r] = dW[j = jt*16 + lr][k = kt*16 + 4*lk + r]
+        const int j = jt * 16 + lr, k0 = kt * 16 + 4 * lk;
+        if (j >= J) continue;
+        float* o = out + j * out_stride + k0;
+        if (vec && k0 + 3 < K) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1], bv[i + 1], acc1, 0, 0, 0);
-        }
-        const f32x4 acc = acc0 + acc1;
-        const int k = kt * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = jt * 16 + 4 * lk + r;
-            if (j < J && k < K) out[j * out_stride + k] = acc[r];
+            for (int r = 0; r < 4; ++r)
+                if (k0 + r < K) o[r] = acc[r];
         }
     }
 }
 
+// partial db[j] = sum_rows delta[row][jbase + j]: wave w < 4 owns columns 16w..16w+15, a lane TM/4 rows of one
+// column, the four row groups meet through two shuffles
+template <int TM>
 __device__ __forceinline__ void grad_bias(const float* __restrict__ delta, int jbase, int J,
                                           float* __restrict__ out) {
-    if ((int)threadIdx.x < J) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < kTM; ++r) s += delta[r * kP + jbase + threadIdx.x];
-        out[threadIdx.x] = s;
-    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= 4 || wave * 16 >= J) return;
+    const int c = wave * 16 + (lane & 15), r0 = (lane >> 4) * (TM / 4);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < TM / 4; ++r) s += delta[(r0 + r) * kP + jbase + c];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 16 && c < J) out[c] = s;
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
+template <int TM, bool WIDE, int NB>
+__global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
+    constexpr int THREADS = threads_of<TM>();
+    constexpr int RT = TM / 16;
+    constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
+    static_assert(!(fixed && WIDE), "the fixed-shape path has a first layer of <= 64 inputs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    MlpBwdLds& L = *reinterpret_cast<MlpBwdLds*>(smem_raw);
+    MlpBwdLds<TM>& L = *reinterpret_cast<MlpBwdLds<TM>*>(smem_raw);
     const int e = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * kTM;
+    const int64_t row0 = (int64_t)blockIdx.x * TM;
     const float* P = a.params + e * a.member_stride;
     float* part = a.partial ? a.partial + ((int64_t)blockIdx.x * gridDim.y + e) * a.member_stride : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rt = wave & 1, ct = wave >> 1;
-    const int nb = a.d.n_blocks;
+    const int rt = wave % RT, ct = wave / RT;
+    const int nb = fixed ? NB : a.d.n_blocks;
     const int K0 = a.d.in0 + a.d.in1;
     const int O = a.d.head_cols[0] + a.d.head_cols[1];
     const int col = ct * 16 + (lane & 15);
 
+    MLP_STAMP(0);
     // ---- staging: input tile, every weight, the incoming gradient tile (padded to 16 columns) -------
     // (a first layer wider than 64 inputs: second halves in the spare tiles x[kMaxB] / w[nb], desc_ok keeps nb < kMaxB)
     constexpr bool wide = WIDE;              // K0 > 64
     float* x_hi = L.x[kMaxB];
     float* w_hi = L.w[nb < kMaxB ? nb : kMaxB - 1];
-    load_input_tile(a, e, row0, L.x[0]);
-    if (wide) load_input_tile(a, e, row0, x_hi, kMaxW);
-    {
-        int Kc = K0;
-        for (int l = 0; l < nb; ++l) {
-            const int W = a.d.width[l];
-            if (l == 0 && wide) {
-                stage_matrix_part(L.w[0], P + a.d.w_off[0], W, K0, 0, kMaxW);
-                stage_matrix_part(w_hi, P + a.d.w_off[0], W, K0, kMaxW, K0 - kMaxW);
-            } else {
-                stage_matrix(L.w[l], P + a.d.w_off[l], W, Kc);
-            }
-            if (threadIdx.x < kMaxW) L.bias[l][threadIdx.x] = (int)threadIdx.x < W ? P[a.d.b_off[l] + threadIdx.x] : 0.f;
-            Kc = W;
-        }
-        stage_heads(a.d, P, Kc, L.head, L.head_bias);
-        const int r = threadIdx.x >> 4, c = threadIdx.x & 15;     // 32 x 16 = 512 slots
+    if constexpr (fixed) {
+        const StageScalars q = stage_scalars<NB>(a, e);
+        float in_lo[4];
+        fetch_input_tile_fixed<THREADS, false>(q, e, row0, in_lo);
+        const int r = threadIdx.x >> 4, c = threadIdx.x & 15;     // TM x 16 = THREADS slots
         const int64_t row = row0 + r;
-        L.delta[r * kP + c] = (a.gout && row < a.N && c < O) ? a.gout[((int64_t)e * a.N + row) * O + c] : 0.f;
+        float gin = 0.f;
+        if (a.gout) {       // (uniform)
+            const float t = a.gout[((int64_t)e * a.N + (row < a.N ? row : a.N - 1)) * O + (c < O ? c : O - 1)];
+            gin = (row < a.N && c < O) ? t : 0.f;
+        }
+        StagedNet<THREADS> regs;
+        net_fetch_fixed<THREADS, NB>(q, regs);
+        put_input_tile<THREADS>(in_lo, L.x[0]);
+        net_put_fixed<THREADS, NB>(regs, L);
+        L.delta[r * kP + c] = gin;
+    } else {
+        float in_lo[4], in_hi[4];
+        fetch_input_tile<THREADS>(a, e, row0, in_lo);
+        if (wide) fetch_input_tile<THREADS>(a, e, row0, in_hi, kMaxW);
+        const int r = threadIdx.x >> 4, c = threadIdx.x & 15;     // TM x 16 = THREADS slots
+        const int64_t row = row0 + r;
+        const float gin = (a.gout && row < a.N && c < O) ? a.gout[((int64_t)e * a.N + row) * O + c] : 0.f;
+        StagedNet<THREADS> regs;
+        net_fetch<THREADS>(a.d, P, K0, wide, regs);
+        put_input_tile<THREADS>(in_lo, L.x[0]);
+        if (wide) {
+            put_input_tile<THREADS>(in_hi, x_hi);
+            stage_matrix_part<THREADS>(L.w[0], P + a.d.w_off[0], a.d.width[0], K0, 0, kMaxW);
+            stage_matrix_part<THREADS>(w_hi, P + a.d.w_off[0], a.d.width[0], K0, kMaxW, K0 - kMaxW);
+        }
+        net_put<THREADS>(a.d, P, K0, wide, regs, L);
+        L.delta[r * kP + c] = gin;
     }
     __syncthreads();
+    MLP_STAMP(1);
 
     // ---- forward recompute ----------------------------------------------------------------------------
     f32x4 z[kMaxB];          // gelu'(pre-activation) of this wave's fragment, per block
@@ -522,10 +839,11 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
 #pragma unroll
     for (int l = 0; l < kMaxB; ++l) {
         if (l < nb) {
-            const int W = a.d.width[l];
+            const int W = fixed ? kMaxW : a.d.width[l];
             const float* xin = L.x[l];
             float* xout = L.x[l + 1];
-            f32x4 acc = gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
+            f32x4 acc = (fixed && l > 0) ? gemm_tile(xin, L.w[l], kMaxW, rt, ct)
+                                         : gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
             if (l == 0 && wide) acc += gemm_tile(x_hi, w_hi, round4(K0 - kMaxW), rt, ct);
             const float bias = L.bias[l][col];
             const bool res = a.d.residual[l] != 0;
@@ -548,19 +866,20 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
         }
     }
     const int H = K;   // width of the last hidden layer
+    MLP_STAMP(2);
 
     // policy-sample mode (Gaussian head): raw head values -> (loc, scale) -> gradient of the sampled action /
     // log-prob chain -> chain rule through the head transform, all on this tile
     if (!a.gout && a.eps) {
         const int A = a.d.head_cols[0];
-        if (wave < 2) {
+        if (wave < RT) {
             const f32x4 raw = gemm_tile(L.x[nb], L.head, round4(H), wave, 0);
             const int hc = lane & 15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) L.delta[(wave * 16 + 4 * (lane >> 4) + r) * kP + hc] = raw[r] + L.head_bias[hc];
         }
         __syncthreads();
-        if ((int)threadIdx.x < kTM * A) {
+        if ((int)threadIdx.x < TM * A) {
             const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
             const int64_t row = row0 + lrow;
             float g_loc = 0.f, g_scale = 0.f;
@@ -586,7 +905,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
     // policy mode: the gradient of mean_b(-min_{e in subset} q_e) w.r.t. this member's q: -1/N on the rows
     // where it is the (first) arg-min of the subset, else 0 (reference sac_base.py:1896-1903)
     if (!a.gout && !a.eps && a.q_table) {
-        if (threadIdx.x < kTM) {
+        if (threadIdx.x < TM) {
             const int64_t row = row0 + threadIdx.x;
             float g = 0.f;
             if (row < a.N) {
@@ -608,8 +927,8 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
     }
     // Q-loss mode: q = head(x) for this tile, delta[:, 0] = d(mean_b l)/dq, per-tile loss sum
     if (!a.gout && !a.eps && !a.q_table) {
-        __shared__ float loss_red[8];
-        if (wave < 2) {
+        __shared__ float loss_red[4 * RT];
+        if (wave < RT) {
             const f32x4 raw = gemm_tile(L.x[nb], L.head, round4(H), wave, 0);
             float part = 0.f;
             if ((lane & 15) == 0) {
@@ -630,7 +949,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             float s = 0.f;
-            for (int i = 0; i < 8; ++i) s += loss_red[i];
+            for (int i = 0; i < 4 * RT; ++i) s += loss_red[i];
             a.loss_partial[(int64_t)blockIdx.x * gridDim.y + e] = s;
         }
     }
@@ -638,7 +957,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
     // transformed head: the incoming gradient is w.r.t. the transformed outputs; recompute the raw
     // head values for this tile and apply the chain rule in place on the delta tile
     if (a.d.head_transform != 0 && a.gout) {
-        if (wave < 2) {
+        if (wave < RT) {
             const f32x4 raw = gemm_tile(L.x[nb], L.head, round4(H), wave, 0);
             const int hc = lane & 15;
 #pragma unroll
@@ -650,26 +969,28 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
         __syncthreads();
     }
 
+    MLP_STAMP(3);
     // ---- head: parameter grads, then g = gout * Wh -------------------------------------------------------
     if (part) {
         int jb = 0;
         for (int h = 0; h < 2; ++h) {
             if (a.d.head_cols[h] > 0) {
-                grad_weight(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
-                grad_bias(L.delta, jb, a.d.head_cols[h], part + a.d.head_b_off[h]);
+                grad_weight<TM>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
+                grad_bias<TM>(L.delta, jb, a.d.head_cols[h], part + a.d.head_b_off[h]);
             }
             jb += a.d.head_cols[h];
         }
     }
     f32x4 g = gemm_tile_nt(L.delta, L.head, kHeadPad, rt, ct);      // g[row][k], k over H
+    MLP_STAMP(4);
 
     // ---- blocks in reverse ---------------------------------------------------------------------------------
     f32x4 g_hi = {0.f, 0.f, 0.f, 0.f};       // input gradient of columns 64.. (wide first layer)
 #pragma unroll
     for (int l = kMaxB - 1; l >= 0; --l) {
         if (l < nb) {
-            const int W = a.d.width[l];
-            const int Kin = (l == 0) ? K0 : a.d.width[l - 1];
+            const int W = fixed ? kMaxW : a.d.width[l];
+            const int Kin = (l == 0) ? K0 : (fixed ? kMaxW : a.d.width[l - 1]);
             __syncthreads();   // readers of the previous delta tile are done
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -677,19 +998,23 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
                 L.delta[row * kP + col] = col < W ? g[r] * z[l][r] : 0.f;     // z holds gelu'(pre-activation)
             }
             __syncthreads();
+            if (l == 2) MLP_STAMP(16);
             if (part) {
                 if (l == 0 && wide) {
-                    grad_weight(L.delta, 0, L.x[0], W, kMaxW, part + a.d.w_off[0], K0);
-                    grad_weight(L.delta, 0, x_hi, W, K0 - kMaxW, part + a.d.w_off[0] + kMaxW, K0);
+                    grad_weight<TM>(L.delta, 0, L.x[0], W, kMaxW, part + a.d.w_off[0], K0);
+                    grad_weight<TM>(L.delta, 0, x_hi, W, K0 - kMaxW, part + a.d.w_off[0] + kMaxW, K0);
                 } else {
-                    grad_weight(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
+                    grad_weight<TM>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 }
-                grad_bias(L.delta, 0, W, part + a.d.b_off[l]);
+                if (l == 2) MLP_STAMP(17);
+                grad_bias<TM>(L.delta, 0, W, part + a.d.b_off[l]);
+                if (l == 2) MLP_STAMP(18);
             }
             if (l == 0 && wide && (a.gx0 || a.gx1)) g_hi = gemm_tile_nt(L.delta, w_hi, round4(W), rt, ct);
-            f32x4 gin = gemm_tile_nt(L.delta, L.w[l], round4(W), rt, ct);   // d x_{l-1}[row][k]
+            f32x4 gin = gemm_tile_nt(L.delta, L.w[l], fixed ? kMaxW : round4(W), rt, ct);   // d x_{l-1}[row][k]
             if (a.d.residual[l]) gin += g;
             g = gin;
+            MLP_STAMP(5 + (kMaxB - 1 - l));
         }
     }
     // ---- input gradients --------------------------------------------------------------------------------------
@@ -713,6 +1038,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_bwd(const MlpArgs a) {
             }
         }
     }
+    MLP_STAMP(10);
 }
 
 // grad[e*stride + i] (+)= sum_tiles partial[tile][e][i]   (fixed order: deterministic)
@@ -816,6 +1142,122 @@ static MlpArgs make_args(const asac_mlp_desc_t* desc, const float* params, int64
 
 using namespace asac;
 
+// the fixed-shape instantiation (NB = 3: the reference's stock networks) applies when the description is exactly
+// three 64-wide blocks on <= 64 inputs and every 64 x 64 weight sits on a 16-byte boundary
+static bool stock3(const asac_mlp_desc_t& d, const float* params, int64_t member_stride) {
+    if (d.n_blocks != 3 || d.in0 + d.in1 > kMaxW) return false;
+    for (int l = 0; l < 3; ++l)
+        if (d.width[l] != kMaxW) return false;
+    if ((reinterpret_cast<uintptr_t>(params) & 15) || (member_stride & 3) || (d.w_off[1] & 3) || (d.w_off[2] & 3)) return false;
+    return true;
+}
+// ... and its 32-bit byte offsets need every row of the inputs within 2 GiB of the base
+static bool offsets32(const MlpArgs& a) {
+    const int64_t lim = 0x7fffffffLL / 4;
+    const int64_t span0 = a.x0_T > 0 ? (a.N / a.x0_T + 1) * a.x0_sb : a.N * a.x0_rs;
+    return span0 + kMaxW < lim && a.N * a.x1_rs + kMaxW < lim && a.member_stride < lim;
+}
+
+template <int TM>
+static int launch_forward(const asac_mlp_desc_t* desc, const MlpArgs& a, int E, int64_t N, hipStream_t s) {
+    const bool wide = desc->in0 + desc->in1 > kMaxW;
+    const size_t lds = mlp_fwd_lds_bytes(desc->n_blocks, wide, TM);
+    const dim3 grid((unsigned)mlp_tile_groups(N, E, lds <= 80 * 1024 ? 2 : 1, TM), (unsigned)E);
+    static bool attr_done = false, attr_wide = false, attr_stock = false;
+    if (wide) {
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd<TM, true, 0>),
+                                   mlp_fwd_lds_bytes(kMaxB - 1, true, TM), attr_wide, "asac_mlp_forward: hipFuncSetAttribute"))
+            return rc;
+        ASAC_LAUNCH((k_mlp_fwd<TM, true, 0>), grid, dim3(threads_of<TM>()), lds, s, a);
+    } else if (stock3(*desc, a.params, a.member_stride) && offsets32(a)) {
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd<TM, false, 3>), sizeof(MlpLds<TM>), attr_stock,
+                                   "asac_mlp_forward: hipFuncSetAttribute"))
+            return rc;
+        ASAC_LAUNCH((k_mlp_fwd<TM, false, 3>), grid, dim3(threads_of<TM>()), lds, s, a);
+    } else {
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd<TM, false, 0>), sizeof(MlpLds<TM>), attr_done,
+                                   "asac_mlp_forward: hipFuncSetAttribute"))
+            return rc;
+        ASAC_LAUNCH((k_mlp_fwd<TM, false, 0>), grid, dim3(threads_of<TM>()), lds, s, a);
+    }
+    return finish_launch("asac_mlp_forward");
+}
+
+template <int TM, int NB>
+static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, hipStream_t s) {
+    static bool attr_done = false;
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi<TM, NB>), sizeof(MlpLds<TM>), attr_done,
+                               "asac_mlp_forward_multi: hipFuncSetAttribute"))
+        return rc;
+    MlpMultiArgs m{};
+    m.n = n_jobs;
+    int blocks = 0;
+    size_t lds = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const size_t need = mlp_fwd_lds_bytes(jobs[k].desc->n_blocks, false, TM);
+        lds = need > lds ? need : lds;
+    }
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    for (int k = 0; k < n_jobs; ++k) {
+        const asac_mlp_job_t& j = jobs[k];
+        m.job[k] = make_args(j.desc, j.params, j.member_stride, j.x0, j.x0_row_stride, j.x0_member_stride, j.x1,
+                             j.x1_row_stride, j.x1_member_stride, j.N);
+        m.job[k].x0_T = j.x0_window_T;
+        m.job[k].x0_sb = j.x0_sample_stride;
+        m.job[k].out = j.out;
+        m.E[k] = j.E;
+        m.first_block[k] = blocks;
+        m.tile_stride[k] = mlp_tile_groups(j.N, j.E, per_cu, TM);
+        blocks += m.tile_stride[k] * j.E;
+    }
+    ASAC_LAUNCH((k_mlp_fwd_multi<TM, NB>), dim3((unsigned)blocks), dim3(threads_of<TM>()), lds, s, m);
+    return finish_launch("asac_mlp_forward_multi");
+}
+
+template <int TM>
+static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int tiles, hipStream_t s) {
+    static bool attr_done = false, attr_wide = false, attr_stock = false;
+    const bool wide = desc->in0 + desc->in1 > kMaxW;
+    const bool stock = !wide && stock3(*desc, a.params, a.member_stride) && offsets32(a);
+    if (int rc = wide    ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, true, 0>), sizeof(MlpBwdLds<TM>), attr_wide, where)
+                 : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3>), sizeof(MlpBwdLds<TM>), attr_stock, where)
+                         : set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 0>), sizeof(MlpBwdLds<TM>), attr_done, where))
+        return rc;
+    if (wide)
+        ASAC_LAUNCH((k_mlp_bwd<TM, true, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+    else if (stock)
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+    else
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+    return 0;
+}
+
+static int mlp_backward_common(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int64_t N,
+                               int64_t member_stride, float* grad_params, float* workspace, int reduce_mode,
+                               float* loss_out, hipStream_t s) {
+    const int tiles = (int)asac_mlp_backward_tiles(N, E);
+    a.partial = grad_params ? workspace : nullptr;
+    a.loss_partial = workspace ? workspace + (int64_t)tiles * E * member_stride : nullptr;
+    if (int rc = mlp_tile_rows(N, E) == 16 ? launch_backward<16>(where, desc, a, E, tiles, s)
+                                           : launch_backward<32>(where, desc, a, E, tiles, s))
+        return rc;
+    if (grad_params && reduce_mode != ASAC_MLP_REDUCE_DEFER) {
+        const int64_t used = asac_mlp_param_extent(desc);
+        // launched once (not under the repeat knob: it may accumulate)
+        if (tiles >= kSlicedFrom)
+            hipLaunchKernelGGL(k_mlp_reduce_partials_sliced, dim3((unsigned)((used + 63) / 64), (unsigned)E),
+                               dim3(64 * kReduceSlices), 0, s, workspace, tiles, E, member_stride, used, grad_params,
+                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, loss_out ? a.loss_partial : nullptr,
+                               loss_out, 1.f / (float)N);
+        else
+            hipLaunchKernelGGL(k_mlp_reduce_partials, dim3((unsigned)((used + 255) / 256), (unsigned)E), dim3(256), 0, s,
+                               workspace, tiles, E, member_stride, used, grad_params,
+                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, loss_out ? a.loss_partial : nullptr,
+                               loss_out, 1.f / (float)N);
+    }
+    return finish_launch(where);
+}
+
 extern "C" {
 
 int asac_mlp_forward(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,
@@ -827,62 +1269,38 @@ int asac_mlp_forward(const asac_mlp_desc_t* desc, const float* params, int64_t m
     MlpArgs a = make_args(desc, params, member_stride, x0, x0_row_stride, x0_member_stride, x1, x1_row_stride,
                           x1_member_stride, N);
     a.out = out;
-    const bool wide = desc->in0 + desc->in1 > kMaxW;
-    const size_t lds = mlp_fwd_lds_bytes(desc->n_blocks, wide);
-    const dim3 grid((unsigned)mlp_tile_groups(N, E, lds <= 80 * 1024 ? 2 : 1), (unsigned)E);
-    static bool attr_done = false, attr_wide = false;
-    if (wide) {
-        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_wide), mlp_fwd_lds_bytes(kMaxB - 1, true),
-                                   attr_wide, "asac_mlp_forward: hipFuncSetAttribute"))
-            return rc;
-        ASAC_LAUNCH(k_mlp_fwd_wide, grid, dim3(kThreads), lds, as_stream(stream), a);
-    } else {
-        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd), sizeof(MlpLds), attr_done,
-                                   "asac_mlp_forward: hipFuncSetAttribute"))
-            return rc;
-        ASAC_LAUNCH(k_mlp_fwd, grid, dim3(kThreads), lds, as_stream(stream), a);
-    }
-    return finish_launch("asac_mlp_forward");
+    return mlp_tile_rows(N, E) == 16 ? launch_forward<16>(desc, a, E, N, as_stream(stream))
+                                     : launch_forward<32>(desc, a, E, N, as_stream(stream));
 }
 
 int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > ASAC_MLP_MAX_JOBS) return bad_arg("asac_mlp_forward_multi");
-    static bool attr_done = false;
-    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi), sizeof(MlpLds), attr_done,
-                               "asac_mlp_forward_multi: hipFuncSetAttribute"))
-        return rc;
-    MlpMultiArgs m{};
-    m.n = n_jobs;
-    int blocks = 0;
-    size_t lds = 0;
-    for (int k = 0; k < n_jobs; ++k) {
-        if (!jobs[k].desc || !desc_ok(*jobs[k].desc) || jobs[k].desc->in0 + jobs[k].desc->in1 > kMaxW)
-            return bad_arg("asac_mlp_forward_multi: job");          // (wide inputs: asac_mlp_forward only)
-        const size_t need = mlp_fwd_lds_bytes(jobs[k].desc->n_blocks);
-        lds = need > lds ? need : lds;
-    }
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int64_t groups16 = 0;       // workgroups of the whole launch with 16-row tiles
+    bool all_stock = true;
     for (int k = 0; k < n_jobs; ++k) {
         const asac_mlp_job_t& j = jobs[k];
-        if (!j.desc || !desc_ok(*j.desc) || j.E <= 0 || j.N <= 0 || !j.x0 || (j.desc->in1 > 0 && !j.x1) || !j.out)
+        if (!j.desc || !desc_ok(*j.desc) || j.desc->in0 + j.desc->in1 > kMaxW)
+            return bad_arg("asac_mlp_forward_multi: job");          // (wide inputs: asac_mlp_forward only)
+        if (j.E <= 0 || j.N <= 0 || !j.x0 || (j.desc->in1 > 0 && !j.x1) || !j.out || j.x0_window_T < 0)
             return bad_arg("asac_mlp_forward_multi: job");
-        m.job[k] = make_args(j.desc, j.params, j.member_stride, j.x0, j.x0_row_stride, j.x0_member_stride, j.x1,
-                             j.x1_row_stride, j.x1_member_stride, j.N);
-        if (j.x0_window_T < 0) return bad_arg("asac_mlp_forward_multi: window");
-        m.job[k].x0_T = j.x0_window_T;
-        m.job[k].x0_sb = j.x0_sample_stride;
-        m.job[k].out = j.out;
-        m.E[k] = j.E;
-        m.first_block[k] = blocks;
-        m.tile_stride[k] = mlp_tile_groups(j.N, j.E, per_cu);
-        blocks += m.tile_stride[k] * j.E;
+        groups16 += ((j.N + 15) / 16) * j.E;
+        all_stock = all_stock && stock3(*j.desc, j.params, j.member_stride) && j.N * (j.x0_row_stride + j.x1_row_stride + 1) < 0x1fffffffLL &&
+                    (j.x0_window_T == 0 || (j.N / j.x0_window_T + 1) * j.x0_sample_stride < 0x1fffffffLL);
     }
-    ASAC_LAUNCH(k_mlp_fwd_multi, dim3((unsigned)blocks), dim3(kThreads), lds, as_stream(stream), m);
-    return finish_launch("asac_mlp_forward_multi");
+    hipStream_t s = as_stream(stream);
+    if (groups16 <= 256)
+        return all_stock ? launch_forward_multi<16, 3>(jobs, n_jobs, s) : launch_forward_multi<16, 0>(jobs, n_jobs, s);
+    return all_stock ? launch_forward_multi<32, 3>(jobs, n_jobs, s) : launch_forward_multi<32, 0>(jobs, n_jobs, s);
+}
+
+/* row tiles (= workgroups along the row axis, = per-tile partial slabs) the backward of this shape uses */
+int64_t asac_mlp_backward_tiles(int64_t N, int E) {
+    const int TM = mlp_tile_rows(N, E);
+    return (N + TM - 1) / TM;
 }
 
 int64_t asac_mlp_backward_workspace(int64_t member_stride, int E, int64_t N) {
-    const int64_t tiles = (N + kTM - 1) / kTM;
+    const int64_t tiles = asac_mlp_backward_tiles(N, E);
     return tiles * (int64_t)E * member_stride + tiles * E;   // floats: parameter partials | loss partials
 }
 
@@ -906,39 +1324,6 @@ int64_t asac_mlp_param_extent(const asac_mlp_desc_t* desc) {
         used = be > used ? be : used;
     }
     return used;
-}
-
-static int mlp_backward_common(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int64_t N,
-                               int64_t member_stride, float* grad_params, float* workspace, int reduce_mode,
-                               float* loss_out, hipStream_t s) {
-    static bool attr_done = false;
-    static bool attr_wide = false;
-    const bool wide = desc->in0 + desc->in1 > kMaxW;
-    if (int rc = wide ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<true>), sizeof(MlpBwdLds), attr_wide, where)
-                      : set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<false>), sizeof(MlpBwdLds), attr_done, where))
-        return rc;
-    const int tiles = (int)((N + kTM - 1) / kTM);
-    a.partial = grad_params ? workspace : nullptr;
-    a.loss_partial = workspace ? workspace + (int64_t)tiles * E * member_stride : nullptr;
-    if (wide)
-        ASAC_LAUNCH(k_mlp_bwd<true>, dim3(tiles, E), dim3(kThreads), sizeof(MlpBwdLds), s, a);
-    else
-        ASAC_LAUNCH(k_mlp_bwd<false>, dim3(tiles, E), dim3(kThreads), sizeof(MlpBwdLds), s, a);
-    if (grad_params && reduce_mode != ASAC_MLP_REDUCE_DEFER) {
-        const int64_t used = asac_mlp_param_extent(desc);
-        // launched once (not under the repeat knob: it may accumulate)
-        if (tiles >= kSlicedFrom)
-            hipLaunchKernelGGL(k_mlp_reduce_partials_sliced, dim3((unsigned)((used + 63) / 64), (unsigned)E),
-                               dim3(64 * kReduceSlices), 0, s, workspace, tiles, E, member_stride, used, grad_params,
-                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, loss_out ? a.loss_partial : nullptr,
-                               loss_out, 1.f / (float)N);
-        else
-            hipLaunchKernelGGL(k_mlp_reduce_partials, dim3((unsigned)((used + 255) / 256), (unsigned)E), dim3(256), 0, s,
-                               workspace, tiles, E, member_stride, used, grad_params,
-                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, loss_out ? a.loss_partial : nullptr,
-                               loss_out, 1.f / (float)N);
-    }
-    return finish_launch(where);
 }
 
 int asac_mlp_backward(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,
@@ -985,7 +1370,7 @@ int asac_mlp_backward_policy_sample(const asac_mlp_desc_t* desc, const float* pa
     if (!desc || !desc_ok(*desc) || N <= 0 || !x0 || desc->in1 != 0 || !eps || !grad_a || grad_a_members < 1 ||
         !log_alpha || !grad_params || !workspace)
         return bad_arg("asac_mlp_backward_policy_sample");
-    if (desc->head_transform != 1 || desc->head_cols[0] != desc->head_cols[1] || kTM * desc->head_cols[0] > kThreads)
+    if (desc->head_transform != 1 || desc->head_cols[0] != desc->head_cols[1] || desc->head_cols[0] > 16)
         return bad_arg("asac_mlp_backward_policy_sample: not a Gaussian-head policy");
     MlpArgs a = make_args(desc, params, member_stride, x0, x0_row_stride, 0, nullptr, 0, 0, N);
     a.eps = eps;

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -133,6 +133,7 @@ _SIGNATURES = {
                                    C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'asac_mlp_forward_multi': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.c_void_p]),
     'asac_mlp_backward_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int64]),
+    'asac_mlp_backward_tiles': (C.c_int64, [C.c_int64, C.c_int]),
     'asac_mlp_backward': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -590,6 +591,11 @@ def mlp_forward_multi(jobs):
 
 def mlp_backward_workspace(member_stride, E, N) -> int:
     return int(load().asac_mlp_backward_workspace(member_stride, E, N))
+
+
+def mlp_backward_tiles(N, E) -> int:
+    """row tiles (= per-tile partial slabs) the backward of an [E][N] pass uses"""
+    return int(load().asac_mlp_backward_tiles(N, E))
 
 
 MLP_REDUCE_OVERWRITE, MLP_REDUCE_ACCUMULATE, MLP_REDUCE_DEFER = 0, 1, 2

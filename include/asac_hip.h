@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 32
+#define ASAC_ABI_VERSION 33
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -359,6 +359,10 @@ int asac_mlp_forward_multi(const asac_mlp_job_t* jobs_host, int n_jobs, void* st
 #define ASAC_MLP_REDUCE_ACCUMULATE 1
 #define ASAC_MLP_REDUCE_DEFER 2
 int64_t asac_mlp_backward_workspace(int64_t member_stride, int E, int64_t N);
+/* Row tiles the backward of an [E][N] pass is cut into (16-row tiles while E * ceil(N / 16) workgroups fit one
+ * resident round on the 256 CUs, else 32-row tiles): the number of per-tile partial slabs in `workspace`, i.e. the
+ * `tiles` argument asac_adam_step_partials needs after an ASAC_MLP_REDUCE_DEFER backward. */
+int64_t asac_mlp_backward_tiles(int64_t N, int E);
 
 /* Backward of the above (the forward is recomputed on chip; nothing is saved between the two).
  *   grad_out     [E][N][head columns]
