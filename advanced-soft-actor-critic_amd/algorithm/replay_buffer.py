@@ -325,6 +325,19 @@ class PrioritizedReplayBuffer:
                                         padding_mask.stride(0), rows, rows.stride(0) * es,
                                         rows.stride(1) * es, scratch)
 
+    def window_scatter_sidecars(self, sample_ids: torch.Tensor, first_off: int, count: int,
+                                padding_mask: torch.Tensor, key: str, rows: torch.Tensor):
+        """`update_window_transitions` as two sidecar jobs (`native.Sidecar`: elect, write) for launches that
+        already sit on the step's critical path; the write job must ride a LATER launch than the elect job."""
+        col = self._columns[key]
+        row_bytes = col[0].numel() * col.element_size()
+        assert row_bytes > 0 and rows.dtype == col.dtype
+        es = rows.element_size()
+        args = (col, row_bytes, self.capacity, sample_ids, sample_ids.numel(), first_off, count, self._slot_ids,
+                padding_mask, padding_mask.stride(0), rows, rows.stride(0) * es, rows.stride(1) * es, self._winner_rows)
+        return (native.sidecar_scatter(native.SIDECAR_SCATTER_ELECT, *args),
+                native.sidecar_scatter(native.SIDECAR_SCATTER_WRITE, *args))
+
     # ------------------------------------------------------------------------------------------
     # random access (used by the option-critic variant) and bookkeeping
     # ------------------------------------------------------------------------------------------

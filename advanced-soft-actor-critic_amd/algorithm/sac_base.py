@@ -210,6 +210,7 @@ class SAC_Base(AuxHeadsMixin):
         self._parallel_branches = bool(hip_config.get('parallel_branches', False))
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
+        self._use_sidecars = bool(hip_config.get('sidecars', True))
 
         self._set_logger()
 
@@ -1306,6 +1307,20 @@ class SAC_Base(AuxHeadsMixin):
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('alpha'))
         self.optimizer_alpha.step()
 
+    def _alpha_sidecar(self, logp):
+        """the continuous-only temperature step (`_train_alpha`'s one-launch form) as a sidecar job, or None when
+        that form does not apply (data parallel, an optimizer over more than the two temperatures)"""
+        seg0, seg1 = self._params.segments['alpha']
+        opt = self.optimizer_alpha
+        if self._dist is not None or (opt.start, opt.stop) != (seg0, seg1) or self.d_action_sizes:
+            return None
+        g = self._params
+        last = self.curiosity is None and not self.use_rnd      # the step's last optimizer launch advances the counter
+        self._counter_advanced = last
+        return native.sidecar_alpha_adam(logp, self.target_c_alpha * -float(self.c_action_size), 1, g.flat[seg0:seg1],
+                                         g.grad[seg0:seg1], opt.exp_avg[seg0:seg1], opt.exp_avg_sq[seg0:seg1], opt.lr,
+                                         opt.betas[0], opt.betas[1], opt.eps, opt.steps_done, advance_counter=last)
+
     def _train_curiosity(self, n_padding_masks, nx_states, n_actions):
         # the reference differentiates w.r.t. the model's parameters only (`backward(inputs=parameters)`,
         # sac_base.py:1951-1976): same gradients from detached inputs, which lets the fused stack add its
@@ -1452,6 +1467,10 @@ class SAC_Base(AuxHeadsMixin):
         # online one (parameter-free rep), the TD-error target (rows >= b)
         ls_win = alpha_logp = probs_win = td_sample = None
         auto_alpha = self.use_auto_alpha and ((self.d_action_sizes and not self.discrete_dqn_like) or self.c_action_size)
+        # Launches off the step's critical path ride as sidecar workgroups of launches that are on it (csrc/
+        # asac_sidecar.h): the mu-probability write-back elects in the sampling launch and writes in the TD error's
+        # forward launch, which also carries the temperature step
+        sc_elect = sc_write = sc_alpha = None
         if stock and self.use_n_step_is:
             with torch.no_grad():
                 B_, L_, A = *bnx_states.shape[:2], self.c_action_size
@@ -1472,7 +1491,11 @@ class SAC_Base(AuxHeadsMixin):
                     self.noise.normal_(self._eps_td)
                     td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
                     jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
-                native.squash_multi(jobs)
+                if td_sample is not None and self._use_sidecars and not self._parallel_branches:
+                    sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
+                    if auto_alpha:
+                        sc_alpha = self._alpha_sidecar(alpha_logp)
+                native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
         # side stream from here to the end of the step: the TD error's online Q and the mu-probability
         # write-back (its own election scratch) beside the temperature step / TD target / tree update
         side_cq = td_q_table = None
@@ -1487,13 +1510,17 @@ class SAC_Base(AuxHeadsMixin):
                         job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
                         job_tq, td_q_table = self._ftq.job(StockMLP._rows(bnx_target_states, self.state_size),
                                                           StockMLP._rows(td_sample[0], self.c_action_size))
-                        native.mlp_forward_multi([job_q, job_tq])
+                        native.mlp_forward_multi([job_q, job_tq],
+                                                 sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None] or None)
                         td_q_table = td_q_table.view(self.ensemble_q_num, *bnx_states.shape[:2])
                     else:
                         self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
-                rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1],
-                                             side=self._parallel_branches)
+                if sc_write is None:
+                    rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1],
+                                                 side=self._parallel_branches)
+        if sc_alpha is not None:
+            auto_alpha = False      # done by the sidecar
         if auto_alpha:
             self._train_alpha(obs_b, state_b, ls=None if ls_win is None else ls_win[:, b], logp=alpha_logp)
         if self.curiosity is not None:

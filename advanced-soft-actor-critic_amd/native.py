@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -64,6 +64,22 @@ class MlpJob(C.Structure):
 
 
 MLP_MAX_JOBS = 2
+
+
+class Sidecar(C.Structure):
+    """asac_sidecar_t: a small off-critical-path job that rides as extra workgroups of a hosting launch"""
+    _fields_ = [('kind', C.c_int32),
+                ('logp', C.c_void_p), ('B', C.c_int32), ('target', C.c_float), ('slot', C.c_int32),
+                ('param', C.c_void_p), ('grad', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p),
+                ('n', C.c_int32), ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float),
+                ('steps_done', C.c_void_p), ('advance_counter', C.c_int32),
+                ('ring', C.c_void_p), ('row_bytes', C.c_int32), ('capacity', C.c_int32), ('ids', C.c_void_p),
+                ('batch', C.c_int32), ('first_off', C.c_int32), ('count', C.c_int32), ('slot_ids', C.c_void_p),
+                ('padding_mask', C.c_void_p), ('mask_sample_stride', C.c_int32), ('rows', C.c_void_p),
+                ('rows_sample_stride_bytes', C.c_int64), ('rows_row_stride_bytes', C.c_int64), ('winner', C.c_void_p)]
+
+
+SIDECAR_ALPHA_ADAM, SIDECAR_SCATTER_ELECT, SIDECAR_SCATTER_WRITE, MAX_SIDECARS = 1, 2, 3, 4
 
 
 class SquashJob(C.Structure):
@@ -120,7 +136,7 @@ _SIGNATURES = {
     'asac_squash_sample_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int64, C.c_void_p]),
-    'asac_squash_multi': (C.c_int, [C.POINTER(SquashJob), C.c_int, C.c_void_p]),
+    'asac_squash_multi': (C.c_int, [C.POINTER(SquashJob), C.c_int, C.POINTER(Sidecar), C.c_int, C.c_void_p]),
     'asac_squash_prob': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64, C.c_int64,
                                    C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                    C.c_void_p]),
@@ -131,7 +147,7 @@ _SIGNATURES = {
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_mlp_forward': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    'asac_mlp_forward_multi': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.c_void_p]),
+    'asac_mlp_forward_multi': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.POINTER(Sidecar), C.c_int, C.c_void_p]),
     'asac_mlp_backward_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int64]),
     'asac_mlp_backward_tiles': (C.c_int64, [C.c_int64, C.c_int]),
     'asac_mlp_backward': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -482,12 +498,41 @@ def squash_job(loc, scale, eps=None, a_out=None, logp_out=None, action=None, act
     return j
 
 
+def _sidecar_array(sidecars):
+    sidecars = list(sidecars or ())
+    assert len(sidecars) <= MAX_SIDECARS
+    return ((Sidecar * len(sidecars))(*sidecars) if sidecars else None), len(sidecars)
+
+
+def sidecar_alpha_adam(logp, target, slot, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, steps_done,
+                       advance_counter=True) -> Sidecar:
+    """`alpha_adam_step` as a sidecar of a hosting launch (keeps the tensors alive through `_keep`)"""
+    sc = Sidecar(kind=SIDECAR_ALPHA_ADAM, logp=_p(logp), B=logp.numel(), target=float(target), slot=int(slot),
+                 param=_p(param), grad=_p(grad), exp_avg=_p(exp_avg), exp_avg_sq=_p(exp_avg_sq), n=param.numel(),
+                 lr=float(lr), beta1=float(beta1), beta2=float(beta2), eps=float(eps), steps_done=_p(steps_done),
+                 advance_counter=int(bool(advance_counter)))
+    sc._keep = (logp, param, grad, exp_avg, exp_avg_sq, steps_done)
+    return sc
+
+
+def sidecar_scatter(kind, ring, row_bytes, capacity, ids, batch, first_off, count, slot_ids, padding_mask,
+                    mask_sample_stride, rows, rows_sample_stride_bytes, rows_row_stride_bytes, winner) -> Sidecar:
+    """one pass (`SIDECAR_SCATTER_ELECT` / `SIDECAR_SCATTER_WRITE`) of `scatter_rows_if_id_match` as a sidecar"""
+    sc = Sidecar(kind=kind, ring=_p(ring), row_bytes=row_bytes, capacity=capacity, ids=_p(ids), batch=batch,
+                 first_off=first_off, count=count, slot_ids=_p(slot_ids), padding_mask=_p(padding_mask),
+                 mask_sample_stride=mask_sample_stride, rows=_p(rows), rows_sample_stride_bytes=rows_sample_stride_bytes,
+                 rows_row_stride_bytes=rows_row_stride_bytes, winner=_p(winner))
+    sc._keep = (ring, ids, slot_ids, padding_mask, rows, winner)
+    return sc
+
+
 @_profiled
-def squash_multi(jobs):
-    """Run 1..SQUASH_MAX_JOBS `squash_job`s in one launch."""
+def squash_multi(jobs, sidecars=None):
+    """Run 1..SQUASH_MAX_JOBS `squash_job`s in one launch (+ sidecar jobs as extra workgroups)."""
     assert 1 <= len(jobs) <= SQUASH_MAX_JOBS
     arr = (SquashJob * len(jobs))(*jobs)
-    _check(load().asac_squash_multi(arr, len(jobs), _stream()), 'asac_squash_multi')
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_squash_multi(arr, len(jobs), sc, n_sc, _stream()), 'asac_squash_multi')
 
 
 @_profiled
@@ -581,12 +626,13 @@ def mlp_job(desc, params, member_stride, E, x0, x1, N, out) -> MlpJob:
 
 
 @_profiled
-def mlp_forward_multi(jobs):
+def mlp_forward_multi(jobs, sidecars=None):
     global _last_work
     _last_work = sum(mlp_flops(j.desc.contents, j.E, j.N) for j in jobs)
     assert 1 <= len(jobs) <= MLP_MAX_JOBS
     arr = (MlpJob * len(jobs))(*jobs)
-    _check(load().asac_mlp_forward_multi(arr, len(jobs), _stream()), 'asac_mlp_forward_multi')
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_mlp_forward_multi(arr, len(jobs), sc, n_sc, _stream()), 'asac_mlp_forward_multi')
 
 
 def mlp_backward_workspace(member_stride, E, N) -> int:

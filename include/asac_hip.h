@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 33
+#define ASAC_ABI_VERSION 34
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -192,6 +192,42 @@ int asac_squash_sample_bwd(const float* loc, const float* scale, int64_t ls_row_
                            const float* grad_logp, const float* log_alpha, int64_t rows, int A,
                            float* grad_loc, float* grad_scale, int64_t grad_row_stride, void* stream);
 
+/* Sidecar jobs: small, off-critical-path launches of the train step executed by EXTRA workgroups of a hosting
+ * launch (asac_squash_multi, asac_mlp_forward_multi) instead of paying a dependent kernel boundary of their own.
+ * A sidecar is ordered after everything launched before its host and before everything launched after it; it must
+ * not touch what the host launch itself reads or writes.  Fields as the arguments of the stand-alone entry points:
+ *   ASAC_SIDECAR_ALPHA_ADAM      asac_alpha_adam_step (reference sac_base.py:1913-1949)
+ *   ASAC_SIDECAR_SCATTER_ELECT   pass 1 of asac_scatter_rows_if_id_match (replay_buffer.py:429-434)
+ *   ASAC_SIDECAR_SCATTER_WRITE   pass 2; needs a launch boundary after the ELECT job of the same scatter */
+#define ASAC_SIDECAR_ALPHA_ADAM 1
+#define ASAC_SIDECAR_SCATTER_ELECT 2
+#define ASAC_SIDECAR_SCATTER_WRITE 3
+#define ASAC_MAX_SIDECARS 4
+typedef struct {
+    int32_t kind;
+    /* ALPHA_ADAM */
+    const float* logp;
+    int32_t B;
+    float target;
+    int32_t slot;
+    float *param, *grad, *exp_avg, *exp_avg_sq;
+    int32_t n;
+    float lr, beta1, beta2, eps;
+    int64_t* steps_done;
+    int32_t advance_counter;
+    /* SCATTER_ELECT / SCATTER_WRITE */
+    void* ring;
+    int32_t row_bytes, capacity;
+    const int64_t* ids;
+    int32_t batch, first_off, count;
+    const int64_t* slot_ids;
+    const uint8_t* padding_mask;
+    int32_t mask_sample_stride;
+    const void* rows;
+    int64_t rows_sample_stride_bytes, rows_row_stride_bytes;
+    int32_t* winner;
+} asac_sidecar_t;
+
 /* Up to ASAC_SQUASH_MAX_JOBS independent jobs of the two kinds above / below in ONE launch (a train
  * step samples for the target, for the policy step, for the temperature step and for the TD error, and
  * scores the stored actions, on outputs of at most two policy forwards).  Fields as the arguments of
@@ -214,7 +250,8 @@ typedef struct {
     int64_t prob_stride_b, prob_stride_t;
     int32_t action_offset, prob_offset;
 } asac_squash_job_t;
-int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, void* stream);
+int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, const asac_sidecar_t* sidecars_host,
+                      int n_sidecars, void* stream);
 
 /* Per-dimension tanh-squashed policy probability of STORED actions:
  *   x = atanh(clamp(a, -0.999, 0.999)); prob_d = exp(N.log_prob(x_d)) / prod_e max(1-tanh(x_e)^2, 1e-2)
@@ -353,7 +390,8 @@ typedef struct {
     int32_t x0_window_T;
     int64_t x0_sample_stride;
 } asac_mlp_job_t;
-int asac_mlp_forward_multi(const asac_mlp_job_t* jobs_host, int n_jobs, void* stream);
+int asac_mlp_forward_multi(const asac_mlp_job_t* jobs_host, int n_jobs, const asac_sidecar_t* sidecars_host,
+                           int n_sidecars, void* stream);
 
 #define ASAC_MLP_REDUCE_OVERWRITE 0
 #define ASAC_MLP_REDUCE_ACCUMULATE 1

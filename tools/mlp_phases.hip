@@ -47,7 +47,7 @@ int main() {
     hipMalloc(&ws, wsn * 4); hipMalloc(&grad, E * stride * 4); hipMalloc(&loss, E * 4);
     const asac_mlp_desc_t dq = stock(S, A, 1, 0, 0), dp = stock(S, 0, A, A, 1);
     for (int mode = 0; mode < 3; ++mode) {
-        double acc[16] = {0};
+        double acc[24] = {0};
         const int reps = 200;
         for (int r = 0; r < reps; ++r) {
             if (mode == 0)
@@ -67,11 +67,14 @@ int main() {
             acc[11] += (double)(st[17] - st[16]) / 100.0;
             acc[12] += (double)(st[18] - st[17]) / 100.0;
             acc[13] += (double)(st[6] - st[18]) / 100.0;
+            for (int i = 0; i < 4; ++i) acc[14 + i] += (double)(st[21 + i] - st[20 + i]) / 100.0;
         }
         static const char* names[] = {"", "staging", "recompute", "loss / head mode", "head grads + g", "reverse L3", "reverse L2",
                                       "reverse L1", "input grads / end"};
         printf("%s: workgroup (0,0) total %.2f us\n", mode == 0 ? "backward_qloss" : mode == 1 ? "backward_policy_q" : "backward_policy_sample", acc[0] / reps);
         for (int i = 1; i < 9; ++i) printf("   %-18s %6.2f us\n", names[i], acc[i] / reps);
+        printf("   recompute layer 2 in detail: gemm %.2f, gelu %.2f, LDS write %.2f, barrier %.2f\n", acc[14] / reps, acc[15] / reps,
+               acc[16] / reps, acc[17] / reps);
         if (mode != 1)
             printf("   reverse L3 in detail: delta tile + barriers %.2f, grad_weight %.2f, grad_bias %.2f, dX gemm %.2f\n",
                    acc[10] / reps, acc[11] / reps, acc[12] / reps, acc[13] / reps);
