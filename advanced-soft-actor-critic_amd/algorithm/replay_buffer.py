@@ -245,15 +245,17 @@ class PrioritizedReplayBuffer:
         self.sample_into_static()
         return self._ids, self._batch, self._w.unsqueeze(-1)
 
-    def sample_into_static(self) -> None:
-        """The device part of `sample()` (no host logic; safe inside graph capture)."""
+    def sample_into_static(self, sampled: bool = False) -> None:
+        """The device part of `sample()` (no host logic; safe inside graph capture).  `sampled`: the tree walk
+        (leaf, p, ids, IS weights) has already been done by the caller's fused prologue launch."""
         B, C = self.batch_size, self.capacity
-        self.uniform_source.fill(self._u)
         reducer = self.min_ratio_reducer
-        native.sumtree_sample(self._tree, C, B, self._u, self._slot_ids, self._beta,
-                              self.beta_increment_per_sampling, self._leaf, self._p, self._ids,
-                              self._w if reducer is None else None, self._min_p)
-        if reducer is not None:
+        if not sampled:
+            self.uniform_source.fill(self._u)
+            native.sumtree_sample(self._tree, C, B, self._u, self._slot_ids, self._beta,
+                                  self.beta_increment_per_sampling, self._leaf, self._p, self._ids,
+                                  self._w if reducer is None else None, self._min_p)
+        if reducer is not None and not sampled:
             # sharded replay: weights are normalised by the GLOBAL minimum sampling ratio
             # (parallel.py): local min(p)/sum(p) -> MIN all-reduce -> stand-alone weight kernel
             torch.div(self._min_p[0:1], self._tree[0:1], out=self._min_p[1:2])

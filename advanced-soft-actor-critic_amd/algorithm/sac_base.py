@@ -1409,10 +1409,13 @@ class SAC_Base(AuxHeadsMixin):
         polyak = None
         if self.update_target_per_step == 1 and self._polyak_len > 0:
             polyak = (self._target_params.flat[:self._polyak_len], self._params.flat[:self._polyak_len], self.tau)
-        self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
-                              self._subsets_all, self.ensemble_q_num, polyak=polyak,
-                              zero=None if self._grads_overwrite else self._params.grad)
-        rb.sample_into_static()
+        zero = None if self._grads_overwrite else self._params.grad
+        sampled = self._use_sidecars and self.noise.begin_step_with_sample(
+            self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+        if not sampled:
+            self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
+                                  self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+        rb.sample_into_static(sampled=sampled)
         batch, ids = rb._batch, rb._ids
         priority_is = rb._w.unsqueeze(-1) if self.use_priority else None
 

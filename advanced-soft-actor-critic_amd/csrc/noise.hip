@@ -6,109 +6,16 @@
 // the Philox4x32-10 counter is (lane index, *step_counter) with the counter read from device memory,
 // so the same frozen launch yields a new block of numbers after every train step.
 #include "asac_common.h"
+#include "asac_noise.h"
 
 #include <cmath>
 
 namespace asac {
 
-struct Philox {
-    uint32_t c[4];
-};
-
-__device__ __forceinline__ Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                                uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return Philox{{c0, c1, c2, c3}};
-}
-
-// lanes [0, ceil(n_normal/4)): four N(0,1) each (Box-Muller);  the next ceil(n_u/2) lanes: two U[0,1) f64 each;
-// the next n_subsets lanes: one random ensemble subset each (the first E_sample entries of a uniformly
-// random permutation of range(E): partial Fisher-Yates, reference `torch.randperm(E)[:E_sample]`,
-// sac_base.py:1434)
-// The leading `polyak_blocks` workgroups (if any) apply the step's Polyak update instead, the next `zero_blocks`
-// clear the step's gradient buffer: the independent launches every captured step begins with, as one.
-__global__ __launch_bounds__(256) void k_noise_fill(uint64_t seed, const int64_t* __restrict__ step,
-                                                    double* __restrict__ u, int64_t n_u,
-                                                    float* __restrict__ normal, int64_t n_normal,
-                                                    int32_t* __restrict__ subsets, int n_subsets, int E_sample, int E,
-                                                    int polyak_blocks, float* __restrict__ target,
-                                                    const float* __restrict__ source, int64_t n_polyak,
-                                                    float one_m_tau, float tau, int zero_blocks,
-                                                    float* __restrict__ zero_out, int64_t n_zero) {
-    if ((int)blockIdx.x < polyak_blocks) {
-        polyak_span(target, source, n_polyak, one_m_tau, tau, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
-                    (int64_t)polyak_blocks * blockDim.x);
-        return;
-    }
-    if ((int)blockIdx.x < polyak_blocks + zero_blocks) {
-        const int64_t first = (int64_t)(blockIdx.x - polyak_blocks) * blockDim.x + threadIdx.x;
-        const int64_t stride = (int64_t)zero_blocks * blockDim.x;
-        if ((reinterpret_cast<uintptr_t>(zero_out) & 15) == 0) {
-            float4* z4 = reinterpret_cast<float4*>(zero_out);
-            for (int64_t k = first; k < n_zero / 4; k += stride) z4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int64_t k = (n_zero & ~(int64_t)3) + first; k < n_zero; k += stride) zero_out[k] = 0.f;
-        } else {
-            for (int64_t k = first; k < n_zero; k += stride) zero_out[k] = 0.f;
-        }
-        return;
-    }
-    const int64_t i = (int64_t)(blockIdx.x - polyak_blocks - zero_blocks) * blockDim.x + threadIdx.x;
-    const int64_t normal_lanes = (n_normal + 3) / 4, u_lanes = (n_u + 1) / 2;
-    if (i >= normal_lanes + u_lanes + n_subsets) return;
-    const uint64_t s = (uint64_t)*step;
-    if (i >= normal_lanes + u_lanes) {
-        const int k = (int)(i - normal_lanes - u_lanes);
-        int perm[ASAC_MAX_ENSEMBLE];
-        for (int e = 0; e < E; ++e) perm[e] = e;
-        Philox x{};
-        for (int e = 0; e < E_sample; ++e) {
-            if ((e & 3) == 0)      // a distinct counter block per subset lane: bit 63 of the lane index set
-                x = philox4x32_10((uint32_t)k, 0x80000000u | (uint32_t)(e >> 2), (uint32_t)s, (uint32_t)(s >> 32),
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
-            const int j = e + (int)(x.c[e & 3] % (uint32_t)(E - e));
-            const int tmp = perm[e];
-            perm[e] = perm[j];
-            perm[j] = tmp;
-            subsets[k * E_sample + e] = perm[e];
-        }
-        return;
-    }
-    const Philox x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)s, (uint32_t)(s >> 32),
-                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-    if (i < normal_lanes) {
-        float out[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float u1 = ((float)x.c[2 * h] + 1.f) * 2.3283064365386963e-10f;     // (0, 1]
-            const float u2 = (float)x.c[2 * h + 1] * 2.3283064365386963e-10f;         // [0, 1]
-            const float r = sqrtf(-2.f * logf(u1));
-            float sn, cs;
-            sincosf(6.283185307179586f * u2, &sn, &cs);
-            out[2 * h] = r * cs;
-            out[2 * h + 1] = r * sn;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (4 * i + k < n_normal) normal[4 * i + k] = out[k];
-    } else {
-        const int64_t j = i - normal_lanes;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint64_t bits = ((uint64_t)x.c[2 * h] << 32) | x.c[2 * h + 1];
-            if (2 * j + h < n_u) u[2 * j + h] = (double)(bits >> 11) * 1.1102230246251565e-16;   // 2^-53: [0, 1)
-        }
-    }
-}
+__global__ __launch_bounds__(256) void k_noise_fill(const PrologueArgs a) { prologue_block(a, (int)blockIdx.x, false); }
 
 }  // namespace asac
+
 
 using namespace asac;
 
@@ -123,9 +30,9 @@ int asac_noise_fill(uint64_t seed, const int64_t* step_counter, double* uniform_
     if (n_subsets > 0 && (!subsets_out || E_sample < 1 || E_sample > E || E > ASAC_MAX_ENSEMBLE))
         return bad_arg("asac_noise_fill: subsets");
     const int64_t lanes = (n_normal + 3) / 4 + (n_uniform + 1) / 2 + n_subsets;
-    ASAC_LAUNCH(k_noise_fill, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, as_stream(stream), seed,
-                step_counter, uniform_out, n_uniform, normal_out, n_normal, subsets_out, n_subsets, E_sample, E, 0,
-                nullptr, nullptr, 0, 0.f, 0.f, 0, nullptr, 0);
+    const PrologueArgs a{seed, step_counter, uniform_out, n_uniform, normal_out, n_normal, subsets_out, n_subsets, E_sample, E,
+                         0, nullptr, nullptr, 0, 0.f, 0.f, 0, nullptr, 0};
+    ASAC_LAUNCH(k_noise_fill, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, as_stream(stream), a);
     return finish_launch("asac_noise_fill");
 }
 
@@ -140,19 +47,15 @@ int asac_step_prologue(float* target, const float* source, int64_t n_polyak, flo
     if (n_subsets > 0 && (!subsets_out || E_sample < 1 || E_sample > E || E > ASAC_MAX_ENSEMBLE))
         return bad_arg("asac_step_prologue: subsets");
     const int64_t lanes = (n_normal + 3) / 4 + (n_uniform + 1) / 2 + n_subsets;
-    auto span_blocks = [](int64_t n) {
-        int64_t nb = (n / 4 + 255) / 256;
-        return n == 0 ? (int64_t)0 : (nb < 1 ? (int64_t)1 : (nb > 2048 ? (int64_t)2048 : nb));
-    };
-    const int64_t pb = span_blocks(n_polyak), zb = span_blocks(n_zero);
+    const int64_t pb = prologue_span_blocks(n_polyak), zb = prologue_span_blocks(n_zero);
     const float one_m_tau = (float)(1.0 - (double)tau);   // python: (1. - tau) in double, cast by ATen
     // under the measurement repeat knob Polyak (not idempotent) runs in the first repetition only
     for (int rep = 0; rep < g_launch_repeat; ++rep) {
         const int blocks_p = rep == 0 ? (int)pb : 0;
+        const PrologueArgs a{seed, step_counter, uniform_out, n_uniform, normal_out, n_normal, subsets_out, n_subsets, E_sample,
+                             E, blocks_p, target, source, n_polyak, one_m_tau, tau, (int)zb, zero_out, n_zero};
         hipLaunchKernelGGL(k_noise_fill, dim3((unsigned)(blocks_p + zb + (lanes + 255) / 256)), dim3(256), 0,
-                           as_stream(stream), seed, step_counter, uniform_out, n_uniform, normal_out, n_normal,
-                           subsets_out, n_subsets, E_sample, E, blocks_p, target, source, n_polyak, one_m_tau, tau,
-                           (int)zb, zero_out, n_zero);
+                           as_stream(stream), a);
     }
     return finish_launch("asac_step_prologue");
 }

@@ -6,6 +6,7 @@
 // XCD L2s / Infinity Cache; the top 12 levels (4095 nodes, 16 KiB) are staged into LDS once per
 // workgroup for the descent.
 #include "asac_common.h"
+#include "asac_noise.h"
 
 #include <cmath>
 #include <cstdio>
@@ -44,12 +45,20 @@ __device__ __forceinline__ float is_weight(float p, float total, float min_ratio
 // plain loads hit L1 / coalesce anyway.
 constexpr int kFusedSampleMax = 1024;   // batches up to here: ONE workgroup samples, reduces and weights
 
-template <bool FUSE_WEIGHTS, bool STAGE_TOP>
-__global__ __launch_bounds__(kSampleBlock) void k_sumtree_sample(
+// `DRAW`: the uniforms are not read from `u` but drawn here (prologue_uniform: the numbers the step's noise fill would
+// have stored there) and written to `u` for whoever inspects the step's draws
+struct SampleDraw {
+    uint64_t seed;
+    const int64_t* step;
+    int64_t n_normal;
+};
+
+template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false>
+__device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
-    const double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
+    double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
     double beta_increment, int32_t* __restrict__ leaf_out, float* __restrict__ p_out,
-    int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out) {
+    int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out, const SampleDraw draw = SampleDraw{}) {
     __shared__ float top[kLdsNodes + 1];
     __shared__ float red[kSampleBlock / kWave];
     __shared__ double s_beta;
@@ -75,7 +84,14 @@ __global__ __launch_bounds__(kSampleBlock) void k_sumtree_sample(
         const float seg = root / (float)batch;                 // np.float32(root / B)
         const double lo = (double)i * (double)seg;             // int64 * float32 -> float64
         const double hi = (double)(i + 1) * (double)seg;
-        double v = lo + (hi - lo) * u[i];                      // np.random.uniform(lo, hi)
+        double ui;
+        if (DRAW) {
+            ui = prologue_uniform(draw.seed, (uint64_t)*draw.step, draw.n_normal, i);
+            u[i] = ui;
+        } else {
+            ui = u[i];
+        }
+        double v = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
         int node = 0, l = 0;
         float p = root;
         // one level of the reference's descent: left/right sums a, b of the current node's children
@@ -154,6 +170,31 @@ __global__ __launch_bounds__(kSampleBlock) void k_sumtree_sample(
             if (i < batch) w_out[i] = is_weight(p_reg[trip], root, min_ratio, s_beta);
         }
     }
+}
+
+template <bool FUSE_WEIGHTS, bool STAGE_TOP>
+__global__ __launch_bounds__(kSampleBlock) void k_sumtree_sample(
+    const float* __restrict__ tree, int capacity, int levels, int batch,
+    const double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
+    double beta_increment, int32_t* __restrict__ leaf_out, float* __restrict__ p_out,
+    int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out) {
+    sumtree_sample_body<FUSE_WEIGHTS, STAGE_TOP>(tree, capacity, levels, batch, const_cast<double*>(u), slot_ids, beta_state,
+                                                 beta_increment, leaf_out, p_out, ids_out, w_out, min_p_out);
+}
+
+// The first launch of a captured train step: workgroup 0 is the fused single-workgroup sampler (drawing its own
+// stratified uniforms), the others are the step prologue's workers (Polyak, gradient memset, Gaussian draws, ensemble
+// subsets): nothing the sampler reads is written by them.
+__global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
+    const PrologueArgs pa, const float* __restrict__ tree, int capacity, int levels, int batch,
+    const int64_t* __restrict__ slot_ids, double* beta_state, double beta_increment, int32_t* __restrict__ leaf_out,
+    float* __restrict__ p_out, int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out) {
+    if (blockIdx.x == 0)
+        sumtree_sample_body<true, true, true>(tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment,
+                                              leaf_out, p_out, ids_out, w_out, min_p_out,
+                                              SampleDraw{pa.seed, pa.step, pa.n_normal});
+    else
+        prologue_block(pa, (int)blockIdx.x - 1, true);
 }
 
 __global__ void k_fill_u32(unsigned int* p, unsigned int v) { *p = v; }
@@ -383,6 +424,35 @@ int asac_sumtree_sample(const float* tree, int capacity, int batch, const double
         ASAC_LAUNCH(k_advance_beta, dim3(1), dim3(1), 0, s, beta_state, beta_increment);
     }
     return finish_launch("asac_sumtree_sample");
+}
+
+int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                              int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                              float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                              int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                              double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
+                              int64_t* ids_out, float* is_weights_out, float* min_p_out, void* stream) {
+    if (!step_counter || n_normal < 0 || n_subsets < 0 || n_polyak < 0 || n_zero < 0 || !uniform_out ||
+        (n_polyak > 0 && (!target || !source)) || (n_zero > 0 && !zero_out) || (n_normal > 0 && !normal_out))
+        return bad_arg("asac_step_prologue_sample");
+    if (n_subsets > 0 && (!subsets_out || E_sample < 1 || E_sample > E || E > ASAC_MAX_ENSEMBLE))
+        return bad_arg("asac_step_prologue_sample: subsets");
+    if (capacity <= 0 || (capacity & (capacity - 1)) || batch <= 0 || batch > kFusedSampleMax || !is_weights_out ||
+        !min_p_out || !tree || !slot_ids || !beta_state)
+        return bad_arg("asac_step_prologue_sample: sampler");
+    const int64_t lanes = (n_normal + 3) / 4 + (batch + 1) / 2 + n_subsets;
+    const int64_t pb = prologue_span_blocks(n_polyak), zb = prologue_span_blocks(n_zero);
+    const float one_m_tau = (float)(1.0 - (double)tau);   // python: (1. - tau) in double, cast by ATen
+    // under the measurement repeat knob Polyak and the beta advance (not idempotent) run in the first repetition only
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {
+        const int blocks_p = rep == 0 ? (int)pb : 0;
+        const PrologueArgs a{seed, step_counter, uniform_out, batch, normal_out, n_normal, subsets_out, n_subsets, E_sample,
+                             E, blocks_p, target, source, n_polyak, one_m_tau, tau, (int)zb, zero_out, n_zero};
+        hipLaunchKernelGGL(k_prologue_sample, dim3((unsigned)(1 + blocks_p + zb + (lanes + 255) / 256)),
+                           dim3(kSampleBlock), 0, as_stream(stream), a, tree, capacity, ilog2(capacity), batch, slot_ids,
+                           beta_state, rep == 0 ? beta_increment : 0.0, leaf_out, p_out, ids_out, is_weights_out, min_p_out);
+    }
+    return finish_launch("asac_step_prologue_sample");
 }
 
 int asac_per_is_weights(const float* p, int batch, const float* total, const float* min_ratio,

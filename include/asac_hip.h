@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 34
+#define ASAC_ABI_VERSION 35
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -649,6 +649,17 @@ int asac_step_prologue(float* target, const float* source, int64_t n_polyak, flo
                        int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
                        int64_t n_uniform, float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets,
                        int E_sample, int E, void* stream);
+
+/* asac_step_prologue and the single-workgroup form of asac_sumtree_sample (batch <= 1024, IS weights fused) as ONE
+ * launch, the first of a captured train step: workgroup 0 samples, drawing its n = `batch` stratified uniforms itself
+ * (the very numbers asac_step_prologue would have stored in uniform_out, which it also fills), the other
+ * workgroups are the prologue's.  replay_buffer.py:185-205, 347-354 + sac_base.py:745-764. */
+int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                              int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                              float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                              int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                              double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
+                              int64_t* ids_out, float* is_weights_out, float* min_p_out, void* stream);
 
 /* hipGraphLaunch of an instantiated graph (the captured train step) on `stream`. */
 int asac_graph_launch(void* graph_exec, void* stream);
