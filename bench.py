@@ -6,15 +6,20 @@ buffer pre-filled with 2^18 transitions (episode length 100) and priorities rand
 update pass (SURVEY.md §8d "Synthetic inputs").  One "step" = one `SAC_Base.train()`:
 PER sample of 256 windows + every gradient/optimizer step + Polyak + priority / mu-prob write-back.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL): every rank owns a replay
-shard (capacity 524288/N) and samples its own batch of 256; gradients are mean all-reduced.
-`value` = batch-256 train steps processed by all ranks per second (weak scaling: per-GPU work is
-fixed, the global batch is 256*N).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+N > 1: one rank per GPU over RCCL — under torch.distributed.run, or spawned by this script itself when it is started
+plainly with --gpus N.  Every rank owns a replay shard (capacity 524288/N); gradients are mean all-reduced.
+  weak   (default)  every rank samples its own batch of 256: `value` = batch-256 steps of all ranks per second
+  strong the GLOBAL batch is 256, 256/N rows per rank: `value` = global-batch steps per second
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      dominant hot-path HIP kernel: algorithmic bytes / HIP-event time vs HBM peak
-  kernels       the same accounting for every libasac_hip launch of the step
+  roofline      the dominant KERNEL of the step (launches grouped by kernel name, mean launch time from HIP events on
+                the launch stream): algorithmic flops or bytes / time vs the gfx950 peak, PMC traffic
+  roofline_hbm  the north-star's "sample + return" kernels K1-K4 (sample + IS weights, window gather, return / min / V)
+                as one group: algorithmic bytes / time vs the HBM peak at this batch size, PMC traffic and its ratio
+  sweep         the same kernels at saturating sizes (tools/kernel_sweep.py), where the HBM fraction is meaningful
+  configs       train steps/s of the other BASELINE configurations (cfg3 / cfg4 / cfg5), each in its own process
+  kernels       the per-entry-point accounting for every libasac_hip launch of the step
   cpu_baseline  the CPU oracle (`oracle/sac_ref.py`, a port of the reference's step) timed on this
                 host's cores on the same workload (bounded sample)
 """
@@ -56,7 +61,8 @@ CONFIGS = {
                  plugin='nn_conv_attn', n_step=3, burn_in_step=5, batch_size=1024, ensemble_q_num=2,
                  ensemble_q_sample=2, capacity=65536, fill=2 ** 15, episode_len=100, hidden=(8,), seq_encoder='ATTN',
                  curiosity='FORWARD',
-                 desc='cfg5: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, PER capacity 65536'),
+                 desc='cfg5: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, PER capacity 65536; '
+                      'use_prediction: omitted (the reference itself raises with a trainable representation)'),
 }
 CFG = dict(CONFIGS['cfg2'])
 
@@ -72,27 +78,40 @@ def synthetic_episode(rng, T):
                 ep_pre_seq_hidden_states=rng.standard_normal((1, T, *CFG['hidden'])).astype(np.float32))
 
 
-_PMC_KERNEL = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_backward': 'asac::k_mlp_bwd',
-               'asac_window_gather_pad': 'asac::k_window_gather_pad', 'asac_vtrace_return_min': 'asac::k_vtrace_return_min',
-               'asac_sumtree_sample': 'asac::k_sumtree_sample', 'asac_sumtree_update': 'asac::k_sumtree_update',
-               'asac_squash_sample_fwd': 'asac::k_squash_sample_fwd', 'asac_gru_forward': 'asac::k_gru_fwd',
-               'asac_gru_backward': 'asac::k_gru_bwd', 'asac_scatter_rows_if_id_match': 'asac::k_scatter_write',
-               'asac_conv2_forward': 'asac::k_conv2_fwd', 'asac_conv2_backward': 'asac::k_conv2_bwd',
-               'asac_attention_proj_forward': 'asac::k_attn_proj_fwd', 'asac_attention_proj_backward': 'asac::k_attn_proj_bwd',
-               'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd'}
+# entry point -> the kernel that does its work (rocprofv3 names; template arguments dropped)
+_KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': 'asac::k_mlp_fwd_multi',
+              'asac_mlp_backward': 'asac::k_mlp_bwd', 'asac_mlp_backward_qloss': 'asac::k_mlp_bwd',
+              'asac_mlp_backward_policy_q': 'asac::k_mlp_bwd', 'asac_mlp_backward_policy_sample': 'asac::k_mlp_bwd',
+              'asac_window_gather_pad': 'asac::k_window_gather_pad', 'asac_vtrace_return_min': 'asac::k_vtrace_return_min',
+              'asac_sumtree_sample': 'asac::k_sumtree_sample', 'asac_step_prologue_sample': 'asac::k_prologue_sample',
+              'asac_sumtree_update': 'asac::k_sumtree_update', 'asac_squash_multi': 'asac::k_squash_multi',
+              'asac_squash_sample_fwd': 'asac::k_squash_sample_fwd', 'asac_gru_forward': 'asac::k_gru_fwd',
+              'asac_gru_backward': 'asac::k_gru_bwd', 'asac_scatter_rows_if_id_match': 'asac::k_scatter_write',
+              'asac_conv2_forward': 'asac::k_conv2_fwd', 'asac_conv2_backward': 'asac::k_conv2_bwd',
+              'asac_attention_proj_forward': 'asac::k_attn_proj_fwd', 'asac_attention_proj_backward': 'asac::k_attn_proj_bwd',
+              'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd',
+              'asac_adam_step_partials': 'asac::k_adam_partials', 'asac_adam_step': 'asac::k_adam',
+              'asac_step_prologue': 'asac::k_noise_fill'}
+SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min')
+ROUND = 'r02'
 
 
-def pmc_traffic(config: str, entry_point: str):
-    """(bytes per launch, source) for an entry point's main kernel, or (None, None): the PMC passes run
-    under rocprofv3, not inside this process, so the committed summary of the same command is read."""
-    path = Path(__file__).resolve().parent / 'profiles' / f'r01_{config}_pmc_traffic.json'
-    k = _PMC_KERNEL.get(entry_point)
-    if k is None or not path.exists():
-        return None, None
-    rec = json.loads(path.read_text()).get(k)
-    if rec is None or rec.get('fetch_bytes_corrected') is None:
-        return None, None
-    return round(rec['fetch_bytes_corrected'] + (rec.get('write_bytes_raw') or 0.0)), f'profiles/{path.name}'
+def pmc_traffic(config: str, kernel: str):
+    """(HBM bytes per launch, source) of a kernel (all template instances, launch-weighted), or (None, None): the PMC
+    passes run under rocprofv3, not inside this process, so the committed summary of the same command is read
+    (profiles/<round>_<config>_pmc_traffic.json, tools/summarize_pmc.py: FETCH_SIZE x2 (gfx950) + WRITE_SIZE)."""
+    for rnd in (ROUND, 'r01'):
+        path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_pmc_traffic.json'
+        if not path.exists():
+            continue
+        recs = [v for k, v in json.loads(path.read_text()).items()
+                if (k == kernel or k.startswith(kernel + '<')) and v.get('fetch_bytes_corrected') is not None]
+        if not recs:
+            continue
+        calls = sum(r.get('launches', 1) for r in recs) or 1
+        tot = sum((r['fetch_bytes_corrected'] + (r.get('write_bytes_raw') or 0.0)) * r.get('launches', 1) for r in recs)
+        return round(tot / calls), f'profiles/{path.name}'
+    return None, None
 
 
 def _gru_bytes(B, L):
@@ -224,13 +243,42 @@ def cpu_baseline(budget_s=24.0):
                       f'{ {t: round(v, 1) for t, v in sweep.items()} }), host cpu_count={os.cpu_count()}'}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def other_configs(names=('cfg3', 'cfg4', 'cfg5'), steps=300, warmup=40) -> dict:
+    """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
+    hipGraph), same timing contract, fewer steps"""
+    import subprocess
+    out = {}
+    for name in names:
+        cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name, '--steps', str(steps), '--warmup',
+               str(warmup), '--no-cpu-baseline', '--profile-steps', '0', '--no-extras']
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            out[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                         'warmup': d['warmup'], 'workload': d['config']['workload'], 'hipgraph': d['config']['hipgraph']}
+        except Exception as e:   # a failed side run must not lose the main line
+            out[name] = {'error': repr(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: batch 256 per GPU; strong: global batch 256, 256/N rows per GPU (SURVEY 8d)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the saturating-size sweep and the cfg3-5 side runs')
     ap.add_argument('--profile-steps', type=int, default=50)
     ap.add_argument('--fill', type=int, default=None, help='transitions resident before timing')
     ap.add_argument('--force-dist', action='store_true',
@@ -243,13 +291,25 @@ def main():
     if args.fill is None:
         args.fill = CFG['fill']
 
+    # --gpus N started plainly (no launcher): spawn the N ranks ourselves, one per GPU, and hand their line through
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    global_batch = CFG['batch_size']
+    if args.scaling == 'strong':
+        if CFG['batch_size'] % world:
+            raise SystemExit(f'strong scaling needs the batch ({CFG["batch_size"]}) divisible by the ranks ({world})')
+        CFG['batch_size'] //= world
 
     dist_ctx = None
     if world > 1 or args.force_dist:
@@ -277,6 +337,10 @@ def main():
             dist_ctx.barrier()
             torch.cuda.synchronize()
 
+    # the hipGraph is captured after `graph_warmup` eager steps: make sure that happens before the W warm-up steps
+    # even when the caller asks for very few of them (untimed either way)
+    for _ in range(max(0, agent._graph_warmup + 3 - args.warmup)):
+        agent.train()
     for _ in range(args.warmup):
         agent.train()
     sync_all()
@@ -293,7 +357,7 @@ def main():
     agent.replay_buffer.check_health()
 
     # ---- per-kernel HIP-event timing of the same step, eager, on the launch stream -------------
-    kernels, roofline, roofline_hbm = {}, None, None
+    kernels, by_kernel, roofline, roofline_hbm = {}, {}, None, None
     summ = None
     if args.profile_steps > 0:
         # EVERY rank runs these eager steps (their gradient all-reduces are collectives); only rank 0 times
@@ -312,70 +376,109 @@ def main():
         sync_all()
     if summ is not None:
         P_polyak = agent._polyak_len
-        seg = {n_: agent._params.span(n_) for n_ in agent._params.segments}
         P_rq = agent._params.span('rep', f'q_{agent.ensemble_q_num - 1}')
         alg = algorithmic_bytes(P_polyak, P_rq[1] - P_rq[0])
-        for name, st in sorted(summ.items(), key=lambda kv: -kv[1]['med_us'] * kv[1]['calls']):
+        B = CFG['batch_size']
+        # the fused first launch: sampler (K1 + K2) + Polyak (K5) + the step's draws
+        alg['asac_step_prologue_sample'] = alg['asac_sumtree_sample'] + alg['asac_polyak'] + 8 * B + 4 * agent._eps_all.numel()
+        for name, st in sorted(summ.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['calls']):
             by = alg.get(name)
             calls_per_step = st['calls'] / args.profile_steps
             kernels[name] = {'avg_us': round(st['avg_us'], 3), 'min_us': round(st['min_us'], 3),
                              'med_us': round(st['med_us'], 3),
                              'launches_per_step': round(calls_per_step, 2),
                              'alg_bytes_per_launch': by,
-                             'achieved_GBs': None if by is None else round(by / (st['med_us'] * 1e-6) / 1e9, 3)}
+                             'achieved_GBs': None if by is None else round(by / (st['avg_us'] * 1e-6) / 1e9, 3)}
             if 'tflops' in st:
                 kernels[name]['alg_flops_per_launch'] = round(st['flops_per_launch'])
                 kernels[name]['achieved_TFLOPs'] = round(st['tflops'], 3)
-        # dominant = the hot-path kernel with the largest total device time per step
-        dom = next(iter(kernels))
-        d = kernels[dom]
-        small = (f'batch {CFG["batch_size"]} gives the launches of the Q / policy networks tens of MFLOP at most: latency-bound by construction '
-                 '(SURVEY.md §8d); profiles/r01_kernel_sweep.txt holds the saturating-size sweep')
-        if d.get('achieved_TFLOPs') is not None:
-            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': d['achieved_TFLOPs'], 'peak': MFMA_F32_PEAK_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': round(d['achieved_TFLOPs'] / MFMA_F32_PEAK_TFLOPS, 6),
-                        'traffic': None, 'alg_flops_per_launch': d['alg_flops_per_launch'],
-                        'avg_launch_us': d['med_us'], 'launches_per_step': d['launches_per_step'], 'note': small}
-        elif d['achieved_GBs'] is not None:
-            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': d['achieved_GBs'], 'peak': HBM_PEAK_GBS,
-                        'unit': 'GB/s', 'frac': round(d['achieved_GBs'] / HBM_PEAK_GBS, 6), 'traffic': None,
-                        'alg_bytes_per_launch': d['alg_bytes_per_launch'], 'avg_launch_us': d['med_us'],
-                        'launches_per_step': d['launches_per_step'], 'note': small}
+            # the same launches grouped by the KERNEL that runs them (the backward has three entry points)
+            g = by_kernel.setdefault(_KERNEL_OF.get(name, name), {'entry_points': [], 'launches_per_step': 0.0, 'us_per_step': 0.0,
+                                                                  'flops_per_step': 0.0, 'bytes_per_step': 0.0, 'sized': True})
+            g['entry_points'].append(name)
+            g['launches_per_step'] += calls_per_step
+            g['us_per_step'] += st['avg_us'] * calls_per_step
+            if 'tflops' in st:
+                g['flops_per_step'] += st['flops_per_launch'] * calls_per_step
+            elif by is not None:
+                g['bytes_per_step'] += by * calls_per_step
+            else:
+                g['sized'] = False
+        small = (f'batch {CFG["batch_size"]} gives a launch of the Q / policy networks tens of MFLOP at most: latency-bound by '
+                 'construction (SURVEY.md §8d); `sweep` holds the saturating-size runs of the HBM-bound kernels')
+        # dominant = the kernel with the largest device time per step; mean launch time throughout
+        dom, d = max(by_kernel.items(), key=lambda kv: kv[1]['us_per_step'])
+        mean_us = d['us_per_step'] / d['launches_per_step']
+        common = {'kernel': dom, 'entry_points': d['entry_points'], 'avg_launch_us': round(mean_us, 3),
+                  'launches_per_step': round(d['launches_per_step'], 2), 'us_per_step': round(d['us_per_step'], 2),
+                  'timing': 'mean over launches, HIP events on the launch stream', 'note': small}
+        if d['flops_per_step'] > 0:
+            ach = d['flops_per_step'] / (d['us_per_step'] * 1e-6) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': round(ach, 4), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 6), 'traffic': None,
+                        'alg_flops_per_launch': round(d['flops_per_step'] / d['launches_per_step']), **common}
+        elif d['sized']:
+            ach = d['bytes_per_step'] / (d['us_per_step'] * 1e-6) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': round(ach, 3), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(ach / HBM_PEAK_GBS, 6), 'traffic': None,
+                        'alg_bytes_per_launch': round(d['bytes_per_step'] / d['launches_per_step']), **common}
+        if roofline is not None:
+            roofline['traffic'], roofline['traffic_source'] = pmc_traffic(args.config, dom)
 
-        # the dominant HBM-bound hot-path kernel as well (the metric's roofline for sample / gather /
-        # return / update kernels is HBM bandwidth)
-        for name, kd in kernels.items():
-            if kd.get('achieved_GBs') is not None and name not in ('asac_adam_step', 'asac_polyak'):
-                roofline_hbm = {'kernel': name, 'bound': 'hbm', 'achieved': kd['achieved_GBs'], 'peak': HBM_PEAK_GBS,
-                                'unit': 'GB/s', 'frac': round(kd['achieved_GBs'] / HBM_PEAK_GBS, 6), 'traffic': None,
-                                'alg_bytes_per_launch': kd['alg_bytes_per_launch'], 'avg_launch_us': kd['med_us'],
-                                'launches_per_step': kd['launches_per_step']}
-                break
+        # the north-star's "sample + return kernels" (K1-K4) as ONE group at this batch size
+        members = [n_ for n_ in SAMPLE_RETURN if n_ in kernels]
+        if members:
+            by_step = sum(kernels[m]['alg_bytes_per_launch'] * kernels[m]['launches_per_step'] for m in members)
+            us_step = sum(kernels[m]['avg_us'] * kernels[m]['launches_per_step'] for m in members)
+            traffic, srcs = 0, set()
+            for m in members:
+                tr, src = pmc_traffic(args.config, _KERNEL_OF[m])
+                if tr is None:
+                    traffic = None
+                    break
+                traffic += tr * kernels[m]['launches_per_step']
+                srcs.add(src)
+            ach = by_step / (us_step * 1e-6) / 1e9
+            roofline_hbm = {'kernels': [_KERNEL_OF[m] for m in members], 'bound': 'hbm', 'achieved': round(ach, 3),
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 6),
+                            'alg_bytes_per_step': int(by_step), 'us_per_step': round(us_step, 2),
+                            'traffic': None if traffic is None else int(traffic),
+                            'traffic_over_algorithmic': None if traffic is None else round(traffic / by_step, 2),
+                            'traffic_source': sorted(srcs) if traffic is not None else None,
+                            'note': 'K1+K2 sample / IS weights (with the step prologue fused into the same launch: Polyak '
+                                    'and the draws are counted in its bytes), K3 window gather, K4 return + ensemble min '
+                                    '(both launches); SURVEY.md §8d: at this batch the group moves < 1 MB per step, '
+                                    'three orders below what HBM delivers in one launch latency — see `sweep`'}
 
-        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-        # (profiles/*_pmc_traffic.json, tools/summarize_pmc.py): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE
-        for obj in (roofline, roofline_hbm):
-            if obj is not None:
-                obj['traffic'], obj['traffic_source'] = pmc_traffic(args.config, obj['kernel'])
+    sweep = configs = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        agent._graph = None
+        torch.cuda.empty_cache()
+        from tools import kernel_sweep
+        sweep = kernel_sweep.saturating_sweep()
+        configs = other_configs()
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline()
 
     if rank == 0:
-        value = world * args.steps / dt
+        value = (world if args.scaling == 'weak' else 1) * args.steps / dt
         out = {
-            'metric': f'SAC train steps/sec (PER sample + grad step), batch {CFG["batch_size"]}',
+            'metric': f'SAC train steps/sec (PER sample + grad step), batch {global_batch}',
             'value': round(value, 2), 'unit': 'train_steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{CFG["desc"]}, batch {CFG["batch_size"]} per GPU, {args.fill} transitions resident',
-                       'per_gpu_batch': CFG['batch_size'], 'global_batch': CFG['batch_size'] * world,
+                       'per_gpu_batch': CFG['batch_size'],
+                       'global_batch': CFG['batch_size'] * world,
                        'replay_shard_capacity': CFG['capacity'] // world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
+                       'ranks': world, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
                        'hipgraph': bool(graph_used)},
-            'roofline': roofline, 'roofline_hbm': roofline_hbm, 'kernels': kernels, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_hbm': roofline_hbm, 'sweep': sweep, 'configs': configs,
+            'kernels': kernels, 'cpu_baseline': cpu,
         }
         # libraries (RCCL's version banner) hold text in the C stdio buffer until exit: push it out first so
         # the JSON record is the last line on stdout

@@ -19,6 +19,11 @@ PEAK = 8000.0
 dev = torch.device('cuda')
 
 
+RECORDS = []        # what `timed` measured, for callers that want the numbers (bench.py's `sweep` section)
+QUIET = False
+ONLY_SATURATING = False     # bench.py: only the sizes where the HBM roofline is meaningful
+
+
 def timed(name, fn, bytes_per_launch, repeat=20, rounds=5):
     for _ in range(2):
         fn()
@@ -26,14 +31,19 @@ def timed(name, fn, bytes_per_launch, repeat=20, rounds=5):
         for _ in range(rounds):
             fn()
     s = prof.summary()
-    us = min(v['min_us'] for v in s.values()) if len(s) == 1 else sum(v['avg_us'] for v in s.values())
+    # mean over the rounds (each a HIP-event bracket around `repeat` back-to-back launches)
+    us = sum(v['avg_us'] for v in s.values())
     gbs = bytes_per_launch / (us * 1e-6) / 1e9
-    print(f'{name:58s} {bytes_per_launch / 1e6:10.2f} MB {us:10.2f} us {gbs:9.1f} GB/s  {100 * gbs / PEAK:5.1f}% of HBM peak')
+    RECORDS.append({'kernel': name, 'alg_bytes_per_launch': int(bytes_per_launch), 'avg_launch_us': round(us, 3),
+                    'achieved_GBs': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / PEAK, 4)})
+    if not QUIET:
+        print(f'{name:58s} {bytes_per_launch / 1e6:10.2f} MB {us:10.2f} us {gbs:9.1f} GB/s  {100 * gbs / PEAK:5.1f}% of HBM peak')
 
 
 def sweep_gather():
     # cfg4 shape: vector(10) + image(3,30,30) f32 rows (10.9 KB), L = 9 (b=5, n=3), B = 512
-    for B, L, C in ((512, 9, 2 ** 15), (1024, 9, 2 ** 15), (4096, 9, 2 ** 15)):
+    for B, L, C in (((1024, 9, 2 ** 15), (4096, 9, 2 ** 15)) if ONLY_SATURATING else
+                    ((512, 9, 2 ** 15), (1024, 9, 2 ** 15), (4096, 9, 2 ** 15))):
         img = torch.randn(C, 3, 30, 30, device=dev)
         vec = torch.randn(C, 10, device=dev)
         index = (torch.arange(C, device=dev, dtype=torch.int32) % 100)
@@ -62,7 +72,7 @@ def sweep_sample():
     slot_ids = torch.arange(C, device=dev, dtype=torch.int64)
     beta = torch.tensor([0.4], dtype=torch.float64, device=dev)
     minp = torch.zeros(2, device=dev)
-    for B in (256, 2 ** 14, 2 ** 18, 2 ** 20):
+    for B in ((2 ** 18, 2 ** 20) if ONLY_SATURATING else (256, 2 ** 14, 2 ** 18, 2 ** 20)):
         u = torch.rand(B, dtype=torch.float64, device=dev)
         leaf = torch.empty(B, dtype=torch.int32, device=dev)
         p = torch.empty(B, device=dev)
@@ -72,14 +82,14 @@ def sweep_sample():
               lambda: native.sumtree_sample(tree, C, B, u, slot_ids, beta, 0.0, leaf, p, ids, w, minp),
               B * (8 + 8 * 19 + 8) + 8 * B)
     out = torch.zeros(1, device=dev)
-    for Cx in (2 ** 19, 2 ** 24, 2 ** 26):
+    for Cx in ((2 ** 26,) if ONLY_SATURATING else (2 ** 19, 2 ** 24, 2 ** 26)):
         t2 = torch.rand(2 * Cx - 1, device=dev)
         timed(f'sumtree_leaf_max C={Cx}', lambda: native.sumtree_leaf_max(t2, Cx, out), 4 * Cx)
 
 
 def sweep_return():
     E, A = 2, 2
-    for B, n in ((256, 4), (2 ** 16, 4), (2 ** 20, 4), (2 ** 16, 40)):
+    for B, n in (((2 ** 20, 4), (2 ** 16, 40)) if ONLY_SATURATING else ((256, 4), (2 ** 16, 4), (2 ** 20, 4), (2 ** 16, 40))):
         q = torch.randn(E, B, n + 1, device=dev)
         logp = torch.randn(B, n + 1, device=dev)
         la = torch.tensor([-2.3], device=dev)
@@ -117,6 +127,19 @@ def sweep_params():
         g, m, v = torch.randn(P, device=dev), torch.zeros(P, device=dev), torch.zeros(P, device=dev)
         steps = torch.zeros(1, dtype=torch.int64, device=dev)
         timed(f'adam_step P={P}', lambda: native.adam_step(t, g, m, v, 3e-4, 0.9, 0.999, 1e-8, steps), 28 * P)
+
+
+def saturating_sweep() -> list:
+    """K1-K4 (+K8) at sizes where one launch has enough work for the HBM roofline to mean something -> records"""
+    global QUIET, ONLY_SATURATING
+    QUIET, ONLY_SATURATING = True, True
+    RECORDS.clear()
+    native.load()
+    sweep_gather()
+    sweep_sample()
+    sweep_return()
+    torch.cuda.empty_cache()
+    return list(RECORDS)
 
 
 if __name__ == '__main__':
