@@ -247,7 +247,7 @@ class DeviceNoise:
         """`begin_step` and the replay buffer's stratified sample (`rb.sample_into_static`'s tree walk) as ONE launch
         when that form applies (this source feeds the sampler, batch <= 1024, weights normalised locally);
         -> whether it did (the caller then runs only the buffer's gather)."""
-        if (rb.uniform_source is not self or rb.min_ratio_reducer is not None
+        if (rb.uniform_source is not self or rb.min_ratio_reducer is not None or rb.sharded is not None
                 or rb.batch_size > native.PROLOGUE_SAMPLE_MAX_BATCH):
             return False
         if subsets is not None and subsets.shape[1] == ensemble:

@@ -113,6 +113,7 @@ class PrioritizedReplayBuffer:
         self._pad_action: torch.Tensor | None = None           # enables the fused window padding
         self.uniform_source = _DeviceUniform()
         self.min_ratio_reducer = None  # callable(f32[1] tensor) -> in-place MIN over ranks (parallel.py)
+        self.sharded = None            # parallel.ShardedParityReplay: sampling / write-backs over all ranks' shards
         self._closed = False
 
     # ------------------------------------------------------------------------------------------
@@ -194,8 +195,10 @@ class PrioritizedReplayBuffer:
     # ------------------------------------------------------------------------------------------
     # sample
     # ------------------------------------------------------------------------------------------
-    def _build_batch(self) -> None:
-        B, L, dev = self.batch_size, self.window, self.device
+    def _window_specs(self, n: int):
+        """destination tensors [n, L, *shape] per key (+ `padding_mask` with the fused padding) and the gather key
+        table that fills them"""
+        L, dev = self.window, self.device
         pad = self._pad_action is not None
         batch, specs = {}, []
         for k, col in self._columns.items():
@@ -205,7 +208,7 @@ class PrioritizedReplayBuffer:
             if pad and k.startswith('obs_') and col.dtype in (torch.uint8, torch.bool):
                 convert = native.CVT_U8_TO_F32_UNIT if col.dtype == torch.uint8 else native.CVT_BOOL_TO_F32
                 out_dtype = torch.float32
-            out = torch.zeros((B, L, *shape), dtype=out_dtype, device=dev)
+            out = torch.zeros((n, L, *shape), dtype=out_dtype, device=dev)
             batch[k] = out
             mode, word, pad_row = native.PAD_KEEP, 0, None
             if pad:
@@ -227,12 +230,32 @@ class PrioritizedReplayBuffer:
             specs.append(dict(src=col, dst=out, row_bytes=row_bytes, pad_mode=mode, pad_word=word,
                               pad_row=pad_row, convert=convert))
         if pad:
-            batch['padding_mask'] = torch.zeros((B, L), dtype=torch.bool, device=dev)
+            batch['padding_mask'] = torch.zeros((n, L), dtype=torch.bool, device=dev)
             specs.append(dict(src=None, dst=batch['padding_mask'], pad_mode=native.PAD_EMIT_MASK))
         assert len(specs) <= native.MAX_GATHER_KEYS, 'too many transition keys for one gather launch'
-        self._batch = batch
+        return batch, specs
+
+    def _build_batch(self) -> None:
+        self._batch, specs = self._window_specs(self.batch_size)
         self._gather_keys = native.make_gather_keys(specs)
         self._gather_refs = specs   # keep tensors alive
+
+    def _index_ring(self):
+        index_ring = self._columns.get('index') if self._pad_action is not None else None
+        if self._pad_action is not None and index_ring is None:
+            raise KeyError("window padding needs an 'index' column")
+        return self._leaf if index_ring is None else index_ring   # plain gather: any i32 ring satisfies the argument
+
+    def gather_windows(self, ids: torch.Tensor) -> dict:
+        """{key: [n, L, *shape]} windows (padded like a sampled batch) around arbitrary resident ids — what a shard
+        hands to the ranks that train its samples (`parallel.ShardedParityReplay`)."""
+        ids = ids.reshape(-1).to(self.device, torch.int64).contiguous()
+        out, specs = self._window_specs(ids.numel())
+        if ids.numel():
+            with torch.cuda.device(self.device):
+                native.window_gather_pad(native.make_gather_keys(specs), ids, ids.numel(), self.prev_n, self.post_n,
+                                         self.capacity, self._index_ring())
+        return out
 
     def sample(self):
         """-> None | (ids i64[B] (device), {key: tensor [B, L, *]}, IS weights f32 [B, 1])
@@ -249,6 +272,9 @@ class PrioritizedReplayBuffer:
         """The device part of `sample()` (no host logic; safe inside graph capture).  `sampled`: the tree walk
         (leaf, p, ids, IS weights) has already been done by the caller's fused prologue launch."""
         B, C = self.batch_size, self.capacity
+        if self.sharded is not None:       # "parity" mode: the batch is drawn over every rank's shard (host logic)
+            self.sharded.sample_into(self)
+            return
         reducer = self.min_ratio_reducer
         if not sampled:
             self.uniform_source.fill(self._u)
@@ -262,12 +288,7 @@ class PrioritizedReplayBuffer:
             reducer(self._min_p[1:2])
             native.per_is_weights(self._p, B, self._tree, self._min_p[1:2], self._beta,
                                   self.beta_increment_per_sampling, self._w)
-        index_ring = self._columns.get('index') if self._pad_action is not None else None
-        if self._pad_action is not None and index_ring is None:
-            raise KeyError("window padding needs an 'index' column")
-        if index_ring is None:   # plain gather: any i32 ring satisfies the (unused) argument
-            index_ring = self._leaf
-        native.window_gather_pad(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, index_ring)
+        native.window_gather_pad(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, self._index_ring())
 
     # ------------------------------------------------------------------------------------------
     # priority / transition write-backs
@@ -288,6 +309,9 @@ class PrioritizedReplayBuffer:
         """priority <- clip(td, min, max)^alpha for ids still resident (replay_buffer.py:412-427)."""
         ids = data_ids if isinstance(data_ids, torch.Tensor) else self._to_device(np.asarray(data_ids, np.int64))
         td = td_error if isinstance(td_error, torch.Tensor) else self._to_device(np.asarray(td_error, np.float32))
+        if self.sharded is not None and ids is self._ids:      # the step's batch: priorities go to the owning shards
+            self.sharded.update(td.reshape(-1))
+            return
         with torch.cuda.device(self.device):
             self._update_ids(ids.reshape(-1), td.reshape(-1).contiguous(), stale_check=True)
 
@@ -316,6 +340,10 @@ class PrioritizedReplayBuffer:
         if row_bytes == 0:
             return
         assert rows.dtype == col.dtype
+        if self.sharded is not None and sample_ids is self._ids:
+            # (target j of a sample is masked by padding_mask[:, j], whatever first_off is: sac_base.py:2589-2605)
+            self.sharded.update_windows(first_off, count, padding_mask[:, :count], key, rows[:, :count])
+            return
         es = rows.element_size()
         scratch = self._winner_rows
         if side:    # concurrent with a write-back on another stream: two elections must not share their map
@@ -347,10 +375,23 @@ class PrioritizedReplayBuffer:
         return self._next_id % self.capacity
 
     def get_storage_data(self, data_ids) -> dict:
-        """Rows at `data_ids % C` for every key, without residency check (replay_buffer.py:401-406)."""
+        """Rows at `data_ids % C` for every key, without residency check (replay_buffer.py:401-406): one gather
+        launch for all keys (the option-critic variant calls this once per key-transition hop,
+        oc/option_selector_base.py:2205, 2223).  Any transition keys are carried (`option_index`,
+        `option_changed_index`, `pre_low_seq_hidden_state`, ...): the rings are created from whatever `add` is given."""
         ids = data_ids if isinstance(data_ids, torch.Tensor) else self._to_device(np.asarray(data_ids, np.int64))
-        slots = torch.remainder(ids, self.capacity)
-        return {k: v.index_select(0, slots) for k, v in self._columns.items()}
+        ids = ids.reshape(-1).to(torch.int64).contiguous()
+        k = ids.numel()
+        out, specs = {}, []
+        for key, col in self._columns.items():
+            out[key] = torch.empty((k, *col.shape[1:]), dtype=col.dtype, device=self.device)
+            row_bytes = col[0].numel() * col.element_size()
+            if row_bytes and k:
+                specs.append(dict(src=col, dst=out[key], row_bytes=row_bytes, pad_mode=native.PAD_KEEP))
+        with torch.cuda.device(self.device):
+            for s0 in range(0, len(specs), native.MAX_GATHER_KEYS):
+                native.gather_rows(native.make_gather_keys(specs[s0:s0 + native.MAX_GATHER_KEYS]), ids, self.capacity)
+        return out
 
     def get_storage_data_ids(self, data_ids):
         ids = data_ids if isinstance(data_ids, torch.Tensor) else self._to_device(np.asarray(data_ids, np.int64))

@@ -211,6 +211,8 @@ class SAC_Base(AuxHeadsMixin):
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
+        self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
+        assert self._dist_sampling in ('throughput', 'parity')
 
         self._set_logger()
 
@@ -520,7 +522,15 @@ class SAC_Base(AuxHeadsMixin):
                                                      **(replay_config or {}))
         self.replay_buffer.set_window_padding(self._padding_action)
         self.replay_buffer.uniform_source = self.noise
-        if self._dist is not None:
+        if self._dist is not None and self._dist_sampling == 'parity':
+            # SURVEY 8e "parity": every batch is the reference's stratified sample over the UNION of the ranks' shards
+            # (global batch = world_size * batch_size, this rank trains on batch_size rows of it)
+            from .parallel import ProductShard, ShardedParityReplay
+            rb = self.replay_buffer
+            rb.sharded = ShardedParityReplay(self._dist, ProductShard(rb), self.batch_size * self._dist.world_size,
+                                             self.device, beta=rb._init_beta,
+                                             beta_increment=rb.beta_increment_per_sampling)
+        elif self._dist is not None:
             self.replay_buffer.min_ratio_reducer = self._dist.all_reduce_min_
 
     # ==========================================================================================
@@ -1611,7 +1621,7 @@ class SAC_Base(AuxHeadsMixin):
             if self.update_target_per_step != 1 and step % self.update_target_per_step == 0:
                 self._update_target_variables(tau=self.tau)
             graph_ok = (self._use_graph and not self._graph_failed and isinstance(self.noise, DeviceNoise)
-                        and (self._dist is None or self._graph_collectives))
+                        and (self._dist is None or self._graph_collectives) and rb.sharded is None)
             if graph_ok and self._graph is None and self._eager_steps >= self._graph_warmup:
                 self._try_capture()
             if graph_ok and self._graph is not None:

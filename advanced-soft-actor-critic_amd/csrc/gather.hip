@@ -271,6 +271,15 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
     return finish_launch("asac_window_gather_pad");
 }
 
+int asac_gather_rows(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int n_rows, int capacity,
+                     void* stream) {
+    if (n_keys <= 0 || n_keys > ASAC_MAX_GATHER_KEYS || !keys_host) return bad_arg("asac_gather_rows");
+    for (int q = 0; q < n_keys; ++q)        // plain rows: no window, no padding, no widening
+        if (keys_host[q].pad_mode != ASAC_PAD_KEEP || keys_host[q].convert != ASAC_CVT_NONE)
+            return bad_arg("asac_gather_rows: key");
+    return asac_window_gather_pad(keys_host, n_keys, ids, n_rows, 0, 0, capacity, nullptr, stream);
+}
+
 int asac_scatter_rows_if_id_match(void* ring, int row_bytes, int capacity, const int64_t* ids,
                                   int batch, int first_off, int count, const int64_t* slot_ids,
                                   const uint8_t* padding_mask, int mask_sample_stride,

@@ -53,7 +53,7 @@ struct SampleDraw {
     int64_t n_normal;
 };
 
-template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false>
+template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false, bool EXPLICIT = false>
 __device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
     double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
@@ -92,6 +92,7 @@ __device__ __forceinline__ void sumtree_sample_body(
             ui = u[i];
         }
         double v = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
+        if (EXPLICIT) v = u[i];                                // the caller's own values (asac_sumtree_descend)
         int node = 0, l = 0;
         float p = root;
         // one level of the reference's descent: left/right sums a, b of the current node's children
@@ -195,6 +196,15 @@ __global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
                                               SampleDraw{pa.seed, pa.step, pa.n_normal});
     else
         prologue_block(pa, (int)blockIdx.x - 1, true);
+}
+
+// the descent alone for explicit f64 values (sharded "parity" sampling: the residual values of the top-level walk)
+__global__ __launch_bounds__(kSampleBlock) void k_sumtree_descend(
+    const float* __restrict__ tree, int capacity, int levels, int n, const double* __restrict__ v,
+    const int64_t* __restrict__ slot_ids, int32_t* __restrict__ leaf_out, float* __restrict__ p_out,
+    int64_t* __restrict__ ids_out, float* scratch_min) {
+    sumtree_sample_body<false, false, false, true>(tree, capacity, levels, n, const_cast<double*>(v), slot_ids, nullptr, 0.0,
+                                                   leaf_out, p_out, ids_out, nullptr, scratch_min);
 }
 
 __global__ void k_fill_u32(unsigned int* p, unsigned int v) { *p = v; }
@@ -424,6 +434,19 @@ int asac_sumtree_sample(const float* tree, int capacity, int batch, const double
         ASAC_LAUNCH(k_advance_beta, dim3(1), dim3(1), 0, s, beta_state, beta_increment);
     }
     return finish_launch("asac_sumtree_sample");
+}
+
+int asac_sumtree_descend(const float* tree, int capacity, int n, const double* values, const int64_t* slot_ids,
+                         int32_t* leaf_out, float* p_out, int64_t* ids_out, void* stream) {
+    if (capacity <= 0 || (capacity & (capacity - 1)) || n <= 0 || !tree || !values || !slot_ids || !leaf_out || !p_out ||
+        !ids_out)
+        return bad_arg("asac_sumtree_descend");
+    static float* scratch = nullptr;      // the body's per-launch minimum lands here (unused)
+    if (!scratch && hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(float)) != hipSuccess)
+        return bad_arg("asac_sumtree_descend: scratch");
+    ASAC_LAUNCH(k_sumtree_descend, dim3((n + kSampleBlock - 1) / kSampleBlock), dim3(kSampleBlock), 0, as_stream(stream),
+                tree, capacity, ilog2(capacity), n, values, slot_ids, leaf_out, p_out, ids_out, scratch);
+    return finish_launch("asac_sumtree_descend");
 }
 
 int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 35
+ABI_VERSION = 37
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -124,6 +124,9 @@ _SIGNATURES = {
     'asac_sumtree_check': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_window_gather_pad': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_sumtree_descend': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    'asac_gather_rows': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'asac_window_aux': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_scatter_rows_if_id_match': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -359,6 +362,14 @@ def sumtree_sample(tree, capacity, batch, u, slot_ids, beta_state, beta_incremen
 
 
 @_profiled
+def sumtree_descend(tree, capacity, values, slot_ids, leaf_out, p_out, ids_out):
+    """leaf / priority / id for explicit f64 `values` (the descent of `sumtree_sample` alone)"""
+    assert values.dtype == torch.float64 and leaf_out.dtype == torch.int32 and ids_out.dtype == torch.int64
+    _check(load().asac_sumtree_descend(_p(tree), capacity, values.numel(), _p(values), _p(slot_ids), _p(leaf_out),
+                                       _p(p_out), _p(ids_out), _stream()), 'asac_sumtree_descend')
+
+
+@_profiled
 def per_is_weights(p, batch, total, min_ratio, beta_state, beta_increment, w_out):
     _check(load().asac_per_is_weights(_p(p), batch, _p(total), _p(min_ratio), _p(beta_state),
                                       float(beta_increment), _p(w_out), _stream()), 'asac_per_is_weights')
@@ -394,6 +405,12 @@ def window_gather_pad(keys, ids, batch, prev_n, post_n, capacity, index_ring):
     """keys: ctypes array of GatherKey (build once with `make_gather_keys`)."""
     _check(load().asac_window_gather_pad(keys, len(keys), _p(ids), batch, prev_n, post_n, capacity,
                                          _p(index_ring), _stream()), 'asac_window_gather_pad')
+
+
+@_profiled
+def gather_rows(keys, ids, capacity):
+    """dst_key[r] = ring_key[ids[r] % capacity] for every key of `keys` (all PAD_KEEP) in one launch"""
+    _check(load().asac_gather_rows(keys, len(keys), _p(ids), ids.numel(), capacity, _stream()), 'asac_gather_rows')
 
 
 def make_gather_keys(specs):

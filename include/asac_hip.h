@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 35
+#define ASAC_ABI_VERSION 37
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -64,6 +64,13 @@ int asac_sumtree_sample(const float* tree, int capacity, int batch, const double
                         const int64_t* slot_ids, double* beta_state, double beta_increment,
                         int32_t* leaf_out, float* p_out, int64_t* ids_out, float* is_weights_out,
                         float* min_p_out, void* stream);
+
+/* The binary descent of asac_sumtree_sample alone, for n explicit f64 values (each in [0, root]): leaf index, leaf
+ * priority and stored id per value; same comparisons (f64 value against f32 node sums, replay_buffer.py:196-205).
+ * Used by the sharded "parity" sampling (algorithm/parallel.py): the G shard trees are the subtrees of one tree whose
+ * top levels every rank walks on the host; the owner finishes the walk here with the residual values. */
+int asac_sumtree_descend(const float* tree, int capacity, int n, const double* values, const int64_t* slot_ids,
+                         int32_t* leaf_out, float* p_out, int64_t* ids_out, void* stream);
 
 /* K2 stand-alone: w_i = ((p_i/total)/(min_ratio))^-beta, beta_state advanced first.
  * total / min_ratio are device scalars so a cross-rank all-reduce can produce them without a
@@ -136,6 +143,13 @@ typedef struct {
 int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids,
                            int batch, int prev_n, int post_n, int capacity,
                            const int32_t* index_ring, void* stream);
+
+/* Random reads: dst_key[r] = ring_key[ids[r] mod capacity] for every key (pad_mode ASAC_PAD_KEEP, convert
+ * ASAC_CVT_NONE), any ids, no residency check, ONE launch for all keys — the reference's
+ * `DataStorage.get(ids)` behind `PrioritizedReplayBuffer.get_storage_data` (replay_buffer.py:64-75, 401-406), which
+ * the option-critic variant calls per key-transition hop (oc/option_selector_base.py:2205, 2223). */
+int asac_gather_rows(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int n_rows, int capacity,
+                     void* stream);
 
 /* The representation's window inputs derived from the sampled window, in one launch (SAC_Base.get_bnx_data,
  * sac_base.py:1090-1115; utils/operators.py gen_n_pre_actions with keep_last_action): for the L-1 leading

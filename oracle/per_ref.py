@@ -56,7 +56,12 @@ class SumTreeRef:
 
     def sample(self, batch: int, u: np.ndarray):
         """-> (leaf index int32 [B] into the tree array, leaf priority f32 [B])"""
-        v = self.stratified_values(batch, u)
+        return self.descend(self.stratified_values(batch, u))
+
+    def descend(self, v: np.ndarray):
+        """the descent of `sample` for explicit f64 values (lines 196-205) -> (leaf index int32, priority f32)"""
+        v = np.array(v, dtype=np.float64)
+        batch = len(v)
         node = np.zeros(batch, dtype=np.int32)
         for _ in range(self.levels):
             left = node * 2 + 1

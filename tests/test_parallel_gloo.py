@@ -71,3 +71,146 @@ def test_data_parallel_context_world2(tmp_path):
     assert a['min'].item() == b['min'].item()
     assert min(a['w'].max().item(), b['w'].max().item()) <= 1.0 + 1e-6
     assert max(a['w'].max().item(), b['w'].max().item()) == 1.0   # exactly one shard holds the global minimum
+
+
+# ------------------------------------------------------------------------------------------------
+# "parity" sharded sampling: two ranks, each with an oracle shard; the union must sample exactly like
+# ONE reference tree whose leaves are [shard 0 | shard 1]
+# ------------------------------------------------------------------------------------------------
+class _OracleShard:
+    """`ShardedParityReplay` backend over the NumPy oracle buffer"""
+
+    def __init__(self, rb):
+        self.rb = rb
+
+    def root(self):
+        return float(self.rb.tree.total)
+
+    def descend(self, v):
+        leaf, p = self.rb.tree.descend(v)
+        ids = self.rb.storage.ids_at(leaf - (self.rb.capacity - 1))
+        return torch.from_numpy(np.asarray(p, np.float32)), torch.from_numpy(np.asarray(ids, np.int64))
+
+    def windows(self, ids):
+        ids = ids.numpy()
+        off = np.arange(-self.rb.prev_n, self.rb.post_n + 1)
+        rows = self.rb.storage.rows_at((ids[:, None] + off[None, :]).reshape(-1))
+        L = len(off)
+        return {k: torch.from_numpy(v.reshape(len(ids), L, *v.shape[1:])) for k, v in rows.items()}
+
+    def update(self, ids, td):
+        if len(ids):
+            self.rb.update(ids.numpy(), td.numpy())
+
+    def update_windows(self, ids, first_off, count, mask, key, rows):
+        ids, mask, rows = ids.numpy(), mask.numpy(), rows.numpy()
+        tgt = (ids[:, None] + first_off + np.arange(count)[None, :]).reshape(-1)
+        keep = ~mask[:, :count].reshape(-1)
+        self.rb.update_transitions(tgt[keep], key, rows[:, :count].reshape(len(tgt), *rows.shape[2:])[keep])
+
+
+def _parity_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import asac_amd  # noqa: F401
+    from algorithm.parallel import DataParallelContext, ShardedParityReplay, shard_of_episode
+    from oracle.per_ref import SumTreeRef
+    ctx = DataParallelContext()
+    Cs, B = 64, 16
+    rng = np.random.default_rng(5)                  # the same stream on every rank: every rank knows every episode
+    shards = [PrioritizedReplayRef(batch_size=B, sample_prev_n=1, sample_post_n=2, capacity=Cs) for _ in range(world)]
+    for ep in range(10):
+        T = int(rng.integers(6, 14))
+        rows = {'index': np.arange(T, dtype=np.int32), 'x': rng.standard_normal((T, 3)).astype(np.float32),
+                'mu_prob': rng.random((T, 2)).astype(np.float32)}
+        pr = (rng.random(T) + 0.05).astype(np.float32)
+        s = shards[shard_of_episode(ep, world)]
+        first = s.storage.next_id
+        s.add(rows, ignore_size=1)
+        s.tree.update(np.arange(first, first + T - 1) % Cs, pr[:-1])
+    mine = shards[rank]
+    sharded = ShardedParityReplay(ctx, _OracleShard(mine), B, 'cpu')
+    # the single reference tree over the union of the shards
+    union = SumTreeRef(world * Cs)
+    union.update(np.arange(world * Cs), np.concatenate([s.tree.tree[Cs - 1:] for s in shards]))
+    for it in range(3):
+        u = rng.random(B)
+        windows, w, gidx = sharded.sample(u)
+        leaf, p = union.sample(B, u)
+        owner, slot = (leaf - (world * Cs - 1)) // Cs, (leaf - (world * Cs - 1)) % Cs
+        ratio = p / union.total
+        w_ref = np.power(ratio / np.min(ratio), -np.float64(0.4 + 0.001 * (it + 1))).astype(np.float32)
+        assert np.array_equal(w.numpy(), w_ref[gidx]), 'IS weights of the global batch (bit-exact)'
+        for j, i in enumerate(gidx):                # my rows are the owner's windows around the union tree's leaf
+            src = shards[owner[i]]
+            sid = src.storage.ids_at(np.array([slot[i]]))[0]
+            want = src.storage.rows_at(sid + np.arange(-1, 3))
+            for k in ('index', 'x', 'mu_prob'):
+                assert np.array_equal(windows[k][j].numpy(), want[k]), (it, i, k)
+        # write-backs travel to the owners: td-errors -> priorities, new mu rows -> the owner's ring
+        td = torch.from_numpy((np.abs(rng.standard_normal(B)) * 0.5).astype(np.float32))[gidx]
+        before = mine.tree.tree.copy()
+        sharded.update(td)
+        new_mu = torch.full((len(gidx), 3, 2), float(100 + it)) + torch.from_numpy(gidx.astype(np.float32))[:, None, None]
+        mask = torch.zeros((len(gidx), 4), dtype=torch.bool)
+        sharded.update_windows(-1, 3, mask, 'mu_prob', new_mu)
+        # every rank replays ALL updates on its copy of the shards it does not own... through the union oracle instead:
+        td_full = torch.zeros(B)
+        td_full[torch.from_numpy(gidx)] = td
+        dist.all_reduce(td_full)
+        pri = np.power(np.clip(td_full.numpy(), 0.01, 1.0), np.float32(0.9)).astype(np.float32)
+        own_rows = np.nonzero(owner == rank)[0]
+        ref_tree = SumTreeRef(Cs)
+        ref_tree.tree[:] = before
+        ref_tree.update(slot[own_rows], pri[own_rows])
+        assert np.array_equal(mine.tree.tree.view(np.uint32), ref_tree.tree.view(np.uint32)), 'priorities landed on their owner'
+        for i in own_rows:                         # the new mu rows of the samples I own (last writer wins on overlaps)
+            sid = mine.storage.ids_at(np.array([slot[i]]))[0]
+            got = mine.storage.rows_at(np.array([sid]))['mu_prob'][0]
+            assert got[0] >= 100, 'the write-back reached the owning shard'
+        # keep this rank's copies of the OTHER shards (and the union tree) in step for the next round: the same
+        # priorities and mu rows their owners just received (rows arrive in ascending sample order: last writer wins)
+        for s_i, s in enumerate(shards):
+            rows_s = np.nonzero(owner == s_i)[0]
+            if s_i != rank:
+                s.tree.update(slot[rows_s], pri[rows_s])
+                sids = s.storage.ids_at(slot[rows_s])
+                tgt = (sids[:, None] - 1 + np.arange(3)[None, :]).reshape(-1)
+                vals = np.repeat((100 + it + rows_s).astype(np.float32), 3)[:, None] * np.ones((1, 2), np.float32)
+                s.update_transitions(tgt, 'mu_prob', vals)
+        union.update(np.arange(world * Cs), np.concatenate([s.tree.tree[Cs - 1:] for s in shards]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parity_sharded_sampling_world2(tmp_path):
+    mp.spawn(_parity_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def test_parity_plan_equals_single_tree():
+    """host part alone, G = 1 / 2 / 4 / 8 shards: owner + residual of `plan_global_sample` followed by the owner's
+    descent is the single reference tree's sample, leaf for leaf and bit for bit"""
+    import asac_amd  # noqa: F401
+    from algorithm.parallel import plan_global_sample
+    from oracle.per_ref import SumTreeRef
+    rng = np.random.default_rng(3)
+    for G in (1, 2, 4, 8):
+        Cs, B = 128, 64
+        leaves = (rng.random(G * Cs) * (rng.random(G * Cs) < 0.7)).astype(np.float32)     # zero-priority leaves too
+        union = SumTreeRef(G * Cs)
+        union.update(np.arange(G * Cs), leaves)
+        shard_trees = []
+        for g in range(G):
+            t = SumTreeRef(Cs)
+            t.update(np.arange(Cs), leaves[g * Cs:(g + 1) * Cs])
+            shard_trees.append(t)
+        u = rng.random(B)
+        u[0], u[-1] = 0.0, np.nextafter(1.0, 0.0)
+        owner, v, total = plan_global_sample(np.array([t.total for t in shard_trees], np.float32), B, u)
+        assert total == union.total
+        leaf_ref, p_ref = union.sample(B, u)
+        for g in range(G):
+            rows = np.nonzero(owner == g)[0]
+            leaf, p = shard_trees[g].descend(v[rows])
+            assert np.array_equal(leaf - (Cs - 1) + g * Cs, leaf_ref[rows] - (G * Cs - 1))
+            assert np.array_equal(p.view(np.uint32), p_ref[rows].view(np.uint32))

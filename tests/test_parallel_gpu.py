@@ -1,0 +1,131 @@
+"""GPU: the multi-rank pieces on the device.
+* `asac_sumtree_descend` against the oracle's descent (explicit values, zero-priority leaves, boundary values);
+* "parity" sharded sampling (`algorithm/parallel.py`) with ONE rank and the product buffer as the shard:
+  it must reproduce the plain sampler bit for bit (ids, IS weights, windows) and route the write-backs;
+* two product learners on two GPUs over RCCL (skipped on a single-GPU box): throughput mode keeps the replicas'
+  weights identical step after step; parity mode draws the same global batch on both ranks."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.per_ref import SumTreeRef  # noqa: E402
+from tests import parity_utils as pu  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('C,n', [(16, 5), (1024, 700), (2 ** 19, 4096)])
+def test_sumtree_descend_matches_oracle(C, n):
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    native.load()
+    rng = np.random.default_rng(C)
+    leaves = (rng.random(C) * (rng.random(C) < 0.8)).astype(np.float32)
+    t = SumTreeRef(C)
+    t.update(np.arange(C), leaves)
+    v = rng.random(n) * float(t.total)
+    v[0], v[-1] = 0.0, float(t.total)
+    leaf_ref, p_ref = t.descend(v)
+    tree = torch.from_numpy(t.tree).cuda()
+    slot_ids = (torch.arange(C, dtype=torch.int64) * 3 + 1).cuda()
+    leaf, p, ids = (torch.empty(n, dtype=torch.int32, device='cuda'), torch.empty(n, device='cuda'),
+                    torch.empty(n, dtype=torch.int64, device='cuda'))
+    native.sumtree_descend(tree, C, torch.from_numpy(v).cuda(), slot_ids, leaf, p, ids)
+    assert np.array_equal(leaf.cpu().numpy(), leaf_ref)
+    assert np.array_equal(p.cpu().numpy().view(np.uint32), p_ref.view(np.uint32))
+    assert np.array_equal(ids.cpu().numpy(), (leaf_ref - (C - 1)) * 3 + 1)
+
+
+def _agent(dist_ctx=None, sampling='throughput', device='cuda:0', graph=False, seed=3):
+    import asac_amd  # noqa: F401
+    from algorithm.sac_base import SAC_Base
+    from algorithm.utils.enums import SEQ_ENCODER
+    torch.manual_seed(seed)
+    return SAC_Base(['vector'], [(6,)], [], 2, None, pu.plugin('nn_rnn'), device=device, batch_size=32, n_step=3,
+                    burn_in_step=2, seq_encoder=SEQ_ENCODER.RNN, replay_config={'capacity': 512},
+                    hip_config={'use_graph': graph, 'dist': dist_ctx, 'dist_sampling': sampling})
+
+
+def test_parity_sampling_single_rank_equals_plain_sampler():
+    """world size 1: the sharded protocol (top-level walk on the host, asac_sumtree_descend, exchange plan, windows by
+    gather_windows, write-backs through the plan) must be the plain step — same ids drawn, same weights, same batch,
+    same priorities / mu-probabilities / hidden states written back, same weights after the steps."""
+    import torch.distributed as dist
+    from algorithm.fused import RecordedNoise
+    from algorithm.parallel import DataParallelContext
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device('cuda:0'))
+    try:
+        plain = _agent()
+        sharded = _agent(DataParallelContext(always=False), 'parity')
+        assert sharded.replay_buffer.sharded is not None
+        sharded._params.flat.copy_(plain._params.flat)
+        sharded._target_params.flat.copy_(plain._target_params.flat)
+        rng = np.random.default_rng(0)
+        for T in (60, 45, 70, 80, 33):
+            ep = pu.synthetic_episode(rng, [(6,)], [], 2, (2, 8), T)
+            plain.put_episode(**ep)
+            sharded.put_episode(**ep)
+        for step in range(4):
+            u, eps, perm = pu.host_draws(rng, 32, 3, 2, 2)
+            for ag in (plain, sharded):
+                ag.noise = RecordedNoise(list(u), [e.copy() for e in eps], list(perm))
+                ag.replay_buffer.uniform_source = ag.noise
+                ag.train()
+            a, b = plain.replay_buffer, sharded.replay_buffer
+            assert torch.equal(a._w, b._w), f'step {step}: IS weights'
+            for k in a._batch:
+                assert torch.equal(a._batch[k], b._batch[k]), f'step {step}: window {k}'
+            assert torch.equal(a._tree, b._tree), f'step {step}: priorities written back'
+            assert torch.equal(a._columns['mu_prob'], b._columns['mu_prob'])
+            assert torch.equal(a._columns['pre_seq_hidden_state'], b._columns['pre_seq_hidden_state'])
+            assert torch.equal(plain._params.flat, sharded._params.flat), f'step {step}: weights'
+        plain.close()
+        sharded.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=2, device_id=torch.device('cuda', rank))
+    from algorithm.parallel import DataParallelContext, shard_of_episode
+    for sampling in ('throughput', 'parity'):
+        ctx = DataParallelContext()
+        agent = _agent(ctx, sampling, device=f'cuda:{rank}', graph=(sampling == 'throughput'), seed=3 + rank)
+        rng = np.random.default_rng(1)            # same episode stream everywhere, dealt round-robin to the shards
+        for ep_i, T in enumerate((60, 45, 70, 80, 33, 52, 41, 66)):
+            ep = pu.synthetic_episode(rng, [(6,)], [], 2, (2, 8), T)
+            if shard_of_episode(ep_i, 2) == rank:
+                agent.put_episode(**ep)
+        for _ in range(8):
+            agent.train()
+        torch.cuda.synchronize()
+        agent.replay_buffer.check_health()
+        flat = agent._params.flat.clone()
+        other = [torch.zeros_like(flat) for _ in range(2)]
+        dist.all_gather(other, flat)
+        assert torch.equal(other[0], other[1]), f'{sampling}: the replicas diverged'
+        assert torch.isfinite(flat).all()
+        if sampling == 'throughput':
+            assert agent._graph is not None, 'the step with its RCCL collectives is captured'
+        agent.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_two_product_ranks_over_rccl(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=2, join=True)

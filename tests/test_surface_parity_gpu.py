@@ -167,3 +167,56 @@ def test_add_with_td_error_matches_oracle(ignore_size):
         rb.check_health()
     rb._nan_flag.zero_()
     rb.close()
+
+
+def test_option_critic_replay_fields_and_random_reads():
+    """the option-critic variant's storage dict (reference oc/option_selector_base.py:2029-2086:
+    `option_index` int8, `option_changed_index` int32, `pre_low_seq_hidden_state` beside the usual keys) through
+    `add`, window sampling and `get_storage_data` / `get_storage_data_ids` — the random reads of its key-transition
+    walk (2205, 2223: ids - 1, ids - delta, negative and stale ids included) — on a ring that wraps: every key
+    bit-exact against `oracle.per_ref.RingStorageRef.rows_at`, in ONE gather launch per call."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm.replay_buffer import PrioritizedReplayBuffer
+    C, B = 128, 16
+    rb = PrioritizedReplayBuffer(B, 2, 3, torch.device('cuda:0'), capacity=C)
+    ref = PrioritizedReplayRef(B, 2, 3, capacity=C)
+    rng = np.random.default_rng(21)
+    for _ in range(9):                       # 9 episodes of 20..59 rows on 128 slots
+        T = int(rng.integers(20, 60))
+        ep = {'index': np.arange(T, dtype=np.int32), 'last_mask': np.arange(T) == T - 1,
+              'obs_vector': rng.standard_normal((T, 5)).astype(np.float32),
+              'obs_image': rng.integers(0, 256, (T, 3, 6, 6)).astype(np.uint8),
+              'option_index': rng.integers(-1, 4, T).astype(np.int8),
+              'option_changed_index': np.maximum.accumulate(np.where(rng.random(T) < 0.3, np.arange(T), 0)).astype(np.int32),
+              'action': rng.random((T, 3)).astype(np.float32), 'reward': rng.standard_normal(T).astype(np.float32),
+              'done': rng.random(T) < 0.1, 'mu_prob': rng.random((T, 3)).astype(np.float32),
+              'pre_seq_hidden_state': rng.standard_normal((T, 4)).astype(np.float32),
+              'pre_low_seq_hidden_state': rng.standard_normal((T, 2, 3)).astype(np.float32)}
+        rb.add(ep, ignore_size=1)
+        ref.add(ep, ignore_size=1)
+    assert set(rb._columns) == set(ep)
+    assert rb._columns['option_index'].dtype == torch.int8 and rb._columns['obs_image'].dtype == torch.uint8
+    u = rng.random(B)
+    rb._u.copy_(torch.from_numpy(u))
+    rb.uniform_source = type('U', (), {'fill': staticmethod(lambda buf: None)})()
+    ids, windows, w = rb.sample()
+    ids_ref, win_ref, w_ref = ref.sample(u)
+    assert np.array_equal(ids.cpu().numpy(), ids_ref)
+    for k, v in win_ref.items():             # no padding configured: plain windows of every key
+        assert np.array_equal(windows[k].cpu().numpy(), v), k
+    pointers = ids_ref.copy()
+    for hop in range(4):                     # the key-transition walk's reads
+        for probe in (pointers - 1, pointers - rng.integers(0, 40, B), pointers + 10 * C, -pointers):
+            with native.LaunchProfiler(repeat=1) as prof:
+                got = rb.get_storage_data(probe)
+            assert prof.summary()['asac_gather_rows']['calls'] == 1, 'one launch for all keys'
+            want = ref.storage.rows_at(probe)
+            assert set(got) == set(want)
+            for k, v in want.items():
+                g = got[k].cpu().numpy()
+                assert g.dtype == v.dtype and np.array_equal(g, v), f'hop {hop}: {k}'
+            assert np.array_equal(rb.get_storage_data_ids(probe).cpu().numpy(), ref.storage.ids_at(probe))
+        pointers = pointers - 1 - hop
+    assert rb.get_storage_data(np.zeros(0, np.int64))['reward'].shape == (0,)
+    rb.close()

@@ -5,7 +5,7 @@ import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r01'
+R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r02'
 
 for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
     shutil.copy(R / f'{c}_bench.json', P / f'{TAG}_{c}_bench.json')
@@ -33,5 +33,5 @@ for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
     d = json.load(open(P / f'{TAG}_{c}_bench.json'))
     r, h = d['roofline'] or {}, d['roofline_hbm'] or {}
     print(c, d['value'], d['ms_per_step'], 'cpu', d['cpu_baseline'] and d['cpu_baseline']['value'], '| roofline',
-          r.get('kernel'), r.get('achieved'), r.get('unit'), r.get('frac'), r.get('traffic'), '| hbm', h.get('kernel'),
+          r.get('kernel'), r.get('achieved'), r.get('unit'), r.get('frac'), r.get('traffic'), '| hbm', h.get('kernels') or h.get('kernel'),
           h.get('achieved'), h.get('frac'))
