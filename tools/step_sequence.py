@@ -17,9 +17,14 @@ def short(name):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
-    anchor = sys.argv[2] if len(sys.argv) > 2 else 'k_sumtree_sample'
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
+    # a step begins with its sampler: the fused prologue + sample launch, or the stand-alone sampler
+    anchors = [sys.argv[2]] if len(sys.argv) > 2 else ['k_prologue_sample', 'k_sumtree_sample']
+    idx = []
+    for anchor in anchors:
+        idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
+        if len(idx) >= 3:
+            break
     if len(idx) < 3:
         print('anchor not found often enough')
         return
