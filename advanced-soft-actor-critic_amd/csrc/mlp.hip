@@ -1070,8 +1070,18 @@ __global__ __launch_bounds__(256) void k_mlp_reduce_partials(const float* __rest
         loss_out[e] = l * inv_n;
     }
     if (i >= used) return;
+    // tile order, loads issued eight at a time (see optim.hip sum_tiles: the plain loop waits per tile)
     float s = 0.f;
-    for (int t = 0; t < tiles; ++t) s += partial[((int64_t)t * E + e) * member_stride + i];
+    for (int t0 = 0; t0 < tiles; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int t = t0 + w < tiles ? t0 + w : tiles - 1;
+            v[w] = partial[((int64_t)t * E + e) * member_stride + i];
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += t0 + w < tiles ? v[w] : 0.f;
+    }
     grad[e * member_stride + i] = accumulate ? grad[e * member_stride + i] + s : s;
 }
 

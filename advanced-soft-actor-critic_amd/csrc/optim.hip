@@ -55,6 +55,24 @@ __global__ __launch_bounds__(256) void k_alpha_adam(const AlphaAdamArgs a) {
 // Adam over the E member segments of a stock network whose parameter gradients are still per-tile
 // partial sums (asac_mlp_backward* with ASAC_MLP_REDUCE_DEFER): the fixed-order tile sum (the same
 // order k_mlp_reduce_partials uses), the optional accumulation into grad, and the update in one pass.
+// sum over the tiles of one parameter's partial gradients in tile order (the order k_mlp_reduce_partials uses), the
+// loads issued eight at a time: a plain `for (t) s += partial[t]` compiles to load -> wait -> add per tile, i.e. one
+// dependent L2 round trip per tile (sixteen of them at batch 256: most of this launch)
+__device__ __forceinline__ float sum_tiles(const float* __restrict__ partial, int64_t tile_stride, int tiles) {
+    float s = 0.f;
+    for (int t0 = 0; t0 < tiles; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int t = t0 + w < tiles ? t0 + w : tiles - 1;         // clamped: every load is issued, none branches
+            v[w] = partial[(int64_t)t * tile_stride];
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += t0 + w < tiles ? v[w] : 0.f;
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256) void k_adam_partials(float* __restrict__ param, float* __restrict__ grad,
                                                        float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                        int64_t n, AdamScalars c, const int64_t* __restrict__ steps_done,
@@ -62,25 +80,42 @@ __global__ __launch_bounds__(256) void k_adam_partials(float* __restrict__ param
                                                        int64_t member_stride, int64_t used, int accumulate,
                                                        const float* __restrict__ loss_partial,
                                                        float* __restrict__ loss_out, float inv_n) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tile_stride = (int64_t)E * member_stride;
+    // this thread's first parameter: its loads are in flight while the (double precision) bias corrections are
+    // formed; launches of this kernel have one parameter per thread
+    float g = 0.f, p = 0.f, m = 0.f, v = 0.f, s = 0.f;
+    bool summed = false;
+    if (tid < n) {
+        const int64_t e = tid / member_stride, local = tid - e * member_stride;
+        g = grad[tid], p = param[tid], m = exp_avg[tid], v = exp_avg_sq[tid];
+        summed = local < used;
+        if (summed) s = sum_tiles(partial + e * member_stride + local, tile_stride, tiles);
+    }
+    float l = 0.f;
+    if (loss_partial && tid < E) l = sum_tiles(loss_partial + tid, E, tiles);
     const double t = (double)(*steps_done + 1);
     const float step_size = (float)(c.lr / (1.0 - pow(c.b1, t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(c.b2d, t));
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (loss_partial && tid < E) {
-        float l = 0.f;
-        for (int tt = 0; tt < tiles; ++tt) l += loss_partial[(int64_t)tt * E + tid];
-        loss_out[tid] = l * inv_n;
-    }
-    for (int64_t i = tid; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = i / member_stride, local = i - e * member_stride;
-        float g = grad[i];
-        if (local < used) {
-            float s = 0.f;
-            for (int tt = 0; tt < tiles; ++tt) s += partial[((int64_t)tt * E + e) * member_stride + local];
+    if (loss_partial && tid < E) loss_out[tid] = l * inv_n;
+    if (tid < n) {
+        if (summed) {
             g = accumulate ? g + s : s;
-            grad[i] = g;
+            grad[tid] = g;
         }
-        adam1(param[i], g, exp_avg[i], exp_avg_sq[i], c, step_size, bc2_sqrt);
+        adam1(p, g, m, v, c, step_size, bc2_sqrt);
+        param[tid] = p, exp_avg[tid] = m, exp_avg_sq[tid] = v;
+    }
+    for (int64_t i = tid + stride; i < n; i += stride) {
+        const int64_t e = i / member_stride, local = i - e * member_stride;
+        float gi = grad[i];
+        if (local < used) {
+            const float si = sum_tiles(partial + e * member_stride + local, tile_stride, tiles);
+            gi = accumulate ? gi + si : si;
+            grad[i] = gi;
+        }
+        adam1(param[i], gi, exp_avg[i], exp_avg_sq[i], c, step_size, bc2_sqrt);
     }
 }
 
