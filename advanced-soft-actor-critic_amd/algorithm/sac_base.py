@@ -703,17 +703,43 @@ class SAC_Base(AuxHeadsMixin):
         return torch.cat([d_action, c_action], dim=-1), prob
 
     @torch.no_grad()
-    def choose_action(self, obs_list, pre_action, pre_seq_hidden_state, offline_action=None,
-                      disable_sample=False, force_rnd_if_available=False):
-        obs_list = [torch.from_numpy(o).to(self.device) for o in obs_list]
+    def choose_action_device(self, obs_list, pre_action, pre_seq_hidden_state, offline_action=None,
+                             disable_sample=False, force_rnd_if_available=False):
+        """`choose_action` on tensors that already live in HBM (the device-resident `AgentManager`,
+        algorithm/agent.py): same computation, no host round trip; returns device tensors."""
+        obs_list = list(obs_list)
         self._process_torch_obs_list(obs_list)
-        pre_action = torch.from_numpy(pre_action).to(self.device).unsqueeze(1)
-        hidden = torch.from_numpy(pre_seq_hidden_state).to(self.device).unsqueeze(1)
-        state, next_hidden = self.model_rep([o.unsqueeze(1) for o in obs_list], pre_action, hidden)
-        offline_action = torch.from_numpy(offline_action).to(self.device) if offline_action is not None else None
+        state, next_hidden = self.model_rep([o.unsqueeze(1) for o in obs_list], pre_action.unsqueeze(1),
+                                            pre_seq_hidden_state.unsqueeze(1))
         action, prob = self._choose_action(obs_list, state.squeeze(1), offline_action, disable_sample,
                                            force_rnd_if_available)
-        return action.cpu().numpy(), prob.cpu().numpy(), next_hidden.squeeze(1).cpu().numpy()
+        return action, prob, next_hidden.squeeze(1)
+
+    @torch.no_grad()
+    def choose_action(self, obs_list, pre_action, pre_seq_hidden_state, offline_action=None,
+                      disable_sample=False, force_rnd_if_available=False):
+        dev = lambda x: torch.from_numpy(x).to(self.device)  # noqa: E731
+        action, prob, next_hidden = self.choose_action_device(
+            [dev(o) for o in obs_list], dev(pre_action), dev(pre_seq_hidden_state),
+            dev(offline_action) if offline_action is not None else None, disable_sample, force_rnd_if_available)
+        return action.cpu().numpy(), prob.cpu().numpy(), next_hidden.cpu().numpy()
+
+    @torch.no_grad()
+    def choose_attn_action_device(self, ep_indexes, ep_padding_masks, ep_obses_list, ep_pre_actions,
+                                  ep_pre_attn_states, offline_action=None, disable_sample=False,
+                                  force_rnd_if_available=False):
+        """`choose_attn_action` on device tensors (windows of at most `burn_in_step` positions, which is all the
+        reference keeps of what it is handed, sac_base.py:1049-1053); returns device tensors."""
+        w = self.burn_in_step
+        cut = lambda x: x[:, -w:]  # noqa: E731
+        obs = [cut(o) for o in ep_obses_list]
+        self._process_torch_obs_list(obs)
+        state, attn_state, _ = self.model_rep(1, cut(ep_indexes), obs, cut(ep_pre_actions),
+                                              pre_seq_hidden_state=cut(ep_pre_attn_states),
+                                              is_prev_hidden_state=False, padding_mask=cut(ep_padding_masks))
+        action, prob = self._choose_action([o[:, -1] for o in obs], state.squeeze(1), offline_action,
+                                           disable_sample, force_rnd_if_available)
+        return action, prob, attn_state.squeeze(1)
 
     @torch.no_grad()
     def choose_attn_action(self, ep_indexes, ep_padding_masks, ep_obses_list, ep_pre_actions,
@@ -721,15 +747,12 @@ class SAC_Base(AuxHeadsMixin):
                            force_rnd_if_available=False):
         w = self.burn_in_step
         to = lambda x: torch.from_numpy(x[:, -w:]).to(self.device)  # noqa: E731
-        obs = [to(o) for o in ep_obses_list]
-        self._process_torch_obs_list(obs)
-        state, attn_state, _ = self.model_rep(1, to(ep_indexes), obs, to(ep_pre_actions),
-                                              pre_seq_hidden_state=to(ep_pre_attn_states),
-                                              is_prev_hidden_state=False, padding_mask=to(ep_padding_masks))
-        offline_action = torch.from_numpy(offline_action).to(self.device) if offline_action is not None else None
-        action, prob = self._choose_action([o[:, -1] for o in obs], state.squeeze(1), offline_action,
-                                           disable_sample, force_rnd_if_available)
-        return action.cpu().numpy(), prob.cpu().numpy(), attn_state.squeeze(1).cpu().numpy()
+        action, prob, attn_state = self.choose_attn_action_device(
+            to(ep_indexes), to(ep_padding_masks), [to(o) for o in ep_obses_list], to(ep_pre_actions),
+            to(ep_pre_attn_states),
+            torch.from_numpy(offline_action).to(self.device) if offline_action is not None else None,
+            disable_sample, force_rnd_if_available)
+        return action.cpu().numpy(), prob.cpu().numpy(), attn_state.cpu().numpy()
 
     # ==========================================================================================
     # states (reference sac_base.py:1090-1189)
@@ -1385,18 +1408,28 @@ class SAC_Base(AuxHeadsMixin):
     # ==========================================================================================
     def put_episode(self, ep_indexes, ep_obses_list, ep_actions, ep_rewards, ep_dones, ep_probs,
                     ep_pre_seq_hidden_states) -> None:
+        """Reference sac_base.py:2303-2396.  NumPy arrays (the reference's callers) or tensors already in HBM
+        (the device-resident `AgentManager`): the latter go slab -> ring without touching the host."""
         if ep_indexes.shape[1] < self.n_step:
             return
-        assert ep_indexes.dtype == np.int32
-        last = np.zeros_like(ep_indexes, dtype=bool)
-        last[:, -1] = True
-        last[ep_indexes == -1] = True
+        if isinstance(ep_indexes, torch.Tensor):
+            assert ep_indexes.dtype == torch.int32
+            last = ep_indexes == -1
+            last[:, -1] = True
+            obs_dev = [o[0] for o in ep_obses_list]
+        else:
+            assert ep_indexes.dtype == np.int32
+            last = np.zeros_like(ep_indexes, dtype=bool)
+            last[:, -1] = True
+            last[ep_indexes == -1] = True
+            obs_dev = None
         rows = {'index': ep_indexes[0], 'last_mask': last[0],
                 **{f'obs_{name}': o[0] for name, o in zip(self.obs_names, ep_obses_list)},
                 'action': ep_actions[0], 'reward': ep_rewards[0], 'done': ep_dones[0],
                 'mu_prob': ep_probs[0], 'pre_seq_hidden_state': ep_pre_seq_hidden_states[0]}
         if self.use_normalization:
-            self._update_normalizer([torch.from_numpy(o[0]).to(self.device) for o in ep_obses_list])
+            self._update_normalizer(obs_dev if obs_dev is not None
+                                    else [torch.from_numpy(o[0]).to(self.device) for o in ep_obses_list])
         self.replay_buffer.add(rows, ignore_size=1)
 
     # ==========================================================================================

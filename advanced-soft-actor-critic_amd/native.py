@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -29,6 +29,17 @@ class GatherKey(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('pad_row', C.c_void_p),
                 ('row_bytes', C.c_int32), ('pad_mode', C.c_int32), ('pad_word', C.c_uint32),
                 ('convert', C.c_int32)]
+
+
+ROW_ITEM, ROW_SLOT, ROW_SLOT_ROW, ROW_BROADCAST = 0, 1, 2, 3
+
+
+class RowMove(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p),
+                ('src_stride0', C.c_int64), ('src_stride1', C.c_int64),
+                ('dst_stride0', C.c_int64), ('dst_stride1', C.c_int64),
+                ('row_bytes', C.c_int32), ('src_mode', C.c_int32), ('dst_mode', C.c_int32),
+                ('src_row_offset', C.c_int32), ('pad_word', C.c_uint32), ('reserved_', C.c_int32)]
 
 
 class VtraceArgs(C.Structure):
@@ -127,6 +138,8 @@ _SIGNATURES = {
     'asac_sumtree_descend': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'asac_gather_rows': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'asac_rows_move': (C.c_int, [C.POINTER(RowMove), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p]),
     'asac_window_aux': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_scatter_rows_if_id_match': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -411,6 +424,29 @@ def window_gather_pad(keys, ids, batch, prev_n, post_n, capacity, index_ring):
 def gather_rows(keys, ids, capacity):
     """dst_key[r] = ring_key[ids[r] % capacity] for every key of `keys` (all PAD_KEEP) in one launch"""
     _check(load().asac_gather_rows(keys, len(keys), _p(ids), ids.numel(), capacity, _stream()), 'asac_gather_rows')
+
+
+def make_row_moves(specs):
+    """specs: list of dicts(src, dst, row_bytes, src_mode, dst_mode, src_stride0/1, dst_stride0/1 (bytes),
+    src_row_offset=0, pad_word=0); src / dst are tensors (their data_ptr is taken; keep them alive)."""
+    assert 0 < len(specs) <= MAX_GATHER_KEYS
+    arr = (RowMove * len(specs))()
+    for k, s in zip(arr, specs):
+        k.src, k.dst = s['src'].data_ptr(), s['dst'].data_ptr()
+        k.row_bytes = int(s['row_bytes'])
+        k.src_mode, k.dst_mode = int(s['src_mode']), int(s['dst_mode'])
+        k.src_stride0, k.src_stride1 = int(s.get('src_stride0', 0)), int(s.get('src_stride1', 0))
+        k.dst_stride0, k.dst_stride1 = int(s.get('dst_stride0', 0)), int(s.get('dst_stride1', 0))
+        k.src_row_offset = int(s.get('src_row_offset', 0))
+        k.pad_word = int(s.get('pad_word', 0)) & 0xffffffff
+    return arr
+
+
+@_profiled
+def rows_move(keys, slot, src_row, dst_row, n_items):
+    """one launch: every key of `keys` (ctypes array from `make_row_moves`) moves `n_items` rows"""
+    _check(load().asac_rows_move(keys, len(keys), _p(slot), _p(src_row), _p(dst_row), int(n_items), _stream()),
+           'asac_rows_move')
 
 
 def make_gather_keys(specs):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 37
+#define ASAC_ABI_VERSION 38
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -150,6 +150,39 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
  * the option-critic variant calls per key-transition hop (oc/option_selector_base.py:2205, 2223). */
 int asac_gather_rows(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int n_rows, int capacity,
                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Episode slabs: the agent-side episode assembly (reference algorithm/agent.py) in HBM.
+ * One row mover serves every movement of an environment step, over all agents and all keys in ONE launch:
+ *   commit   pending rows + this step's scalars -> slab[slot, cursor]   (Agent._add_transition, agent.py:191-235)
+ *   collect  pending action / hidden state of the listed agents -> dense batch
+ *                                                 (AgentManager._get_merged_action/_seq_hidden_state, 481-485)
+ *   stage    policy outputs + new observations -> pending rows          (Agent.set_tmp_obs_action, 87-97)
+ *   window   the last rows of the agents' running episodes, left-padded (Agent.get_episode_trans(force_length)
+ *            258-316 + the concatenations of AgentManager.get_action 536-552)
+ * Item i of a key copies row_bytes from  src + a*src_stride0 + b*src_stride1  to  dst + c*dst_stride0 +
+ * d*dst_stride1  with (a, b) resp. (c, d) given by the side's addressing mode:
+ *   ASAC_ROW_ITEM (i, 0)   ASAC_ROW_SLOT (slot[i], 0)   ASAC_ROW_SLOT_ROW (slot[i], row[i] (+ src_row_offset))
+ *   ASAC_ROW_BROADCAST (0, 0; sources only)
+ * A SLOT_ROW source whose row index is negative yields padding: every 4-byte word := pad_word (byte-wide keys:
+ * its low byte); a SLOT_ROW destination with a negative row is skipped.  Strides in bytes. */
+enum { ASAC_ROW_ITEM = 0, ASAC_ROW_SLOT = 1, ASAC_ROW_SLOT_ROW = 2, ASAC_ROW_BROADCAST = 3 };
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t src_stride0, src_stride1;
+    int64_t dst_stride0, dst_stride1;
+    int32_t row_bytes;
+    int32_t src_mode, dst_mode;
+    int32_t src_row_offset;
+    uint32_t pad_word;
+    int32_t reserved_;
+} asac_row_move_t;
+
+/*   keys_host  HOST array of n_keys (<= ASAC_MAX_GATHER_KEYS) descriptors (copied into the kernel arguments)
+ *   slot, src_row, dst_row   i32[n_items] device arrays (each may be NULL when no key's mode reads it) */
+int asac_rows_move(const asac_row_move_t* keys_host, int n_keys, const int32_t* slot, const int32_t* src_row,
+                   const int32_t* dst_row, int n_items, void* stream);
 
 /* The representation's window inputs derived from the sampled window, in one launch (SAC_Base.get_bnx_data,
  * sac_base.py:1090-1115; utils/operators.py gen_n_pre_actions with keep_last_action): for the L-1 leading

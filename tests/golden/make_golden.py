@@ -32,6 +32,7 @@ ref_shims.install()
 from algorithm.replay_buffer import PrioritizedReplayBuffer, SumTree  # noqa: E402
 from algorithm.sac_base import SAC_Base  # noqa: E402
 from algorithm.utils.enums import SEQ_ENCODER  # noqa: E402
+from agent_script import AGENT_CASES, agent_script  # noqa: E402
 
 
 def load_ref_nn(rel):
@@ -687,6 +688,63 @@ def f9_acting():
     np.savez_compressed(HERE / 'f9_acting.npz', **out)
 
 
+def f10_agent():
+    """Agent-side episode assembly (agent.py:21-690): the reference's `AgentManager` driven by `agent_script`
+    through get_action / end_episode, the Gaussian draw of every step recorded -> actions per step, every episode
+    it hands to `put_episode` (all seven arrays), the agents' statistics at the end."""
+    from algorithm.agent import AgentManager
+    out = {}
+    for tag, (nn_rel, _, kw, max_len) in AGENT_CASES.items():
+        kw = dict(kw)
+        if 'seq_encoder' in kw:
+            kw['seq_encoder'] = SEQ_ENCODER[kw['seq_encoder']]
+        seed_all(100)
+        sac = _tiny_sac(load_ref_nn(nn_rel), n_step=3, **kw)
+        for name, m in sac.ckpt_dict.items():
+            if isinstance(m, torch.nn.Module):
+                for k, v in m.state_dict().items():
+                    out[f'{tag}/w0/{name}/{k}'] = v.numpy().copy()
+        out[f'{tag}/w0/log_c_alpha'] = sac.log_c_alpha.detach().numpy().copy()
+        out[f'{tag}/w0/log_d_alpha'] = sac.log_d_alpha.detach().numpy().copy()
+        mgr = AgentManager('test', ['vector'], [(6,)], [np.float32], [], 2, max_episode_length=max_len, hit_reward=1)
+        mgr.set_rl(sac)
+        n_ep = 0
+
+        def drain(t):
+            nonlocal n_ep
+            for ep in mgr.get_tmp_episode_trans_list():
+                out[f'{tag}/ep{n_ep}/step'] = np.int64(t)
+                for k, v in ep.items():
+                    out[f'{tag}/ep{n_ep}/{k}'] = (v[0] if isinstance(v, list) else v).copy()
+                n_ep += 1
+            mgr.clear_tmp_episode_trans_list()
+
+        script = agent_script(tag)
+        for t, st in enumerate(script):
+            with ref_shims.DrawRecorder() as rec:
+                d_action, c_action = mgr.get_action(st['agent_ids'], [st['obs'].copy()], st['last_reward'].copy())
+            assert len(rec.eps) == 1
+            out[f'{tag}/t{t}/eps'] = rec.eps[0].numpy()
+            out[f'{tag}/t{t}/c_action'] = c_action.copy()
+            m = st['term']
+            mgr.end_episode(st['agent_ids'][m], [st['term_obs'][m]], st['term_reward'][m], st['term_max'][m])
+            drain(t)
+        last = script[-1]
+        n = len(last['agent_ids'])
+        mgr.end_episode(last['agent_ids'], [last['term_obs']], last['term_reward'], np.ones(n, dtype=bool),
+                        force_terminated=True)
+        mgr.force_end_all_episodes()
+        drain(len(script))
+        out[f'{tag}/n_episodes'] = np.int64(n_ep)
+        ids = sorted(mgr.agents_dict)
+        out[f'{tag}/final/agent_ids'] = np.asarray(ids)
+        for f in ('steps', 'reward', 'done', 'max_reached', 'force_terminated', 'hit', 'current_step'):
+            out[f'{tag}/final/{f}'] = np.asarray([getattr(mgr.agents_dict[i], f) for i in ids], dtype=np.float64)
+        out[f'{tag}/final/liveness'] = np.asarray([mgr.agents_liveness[i] for i in ids])
+        sac.close()
+    np.savez_compressed(HERE / 'f10_agent.npz', **out)
+
+
 def main():
     torch.set_num_threads(1)
     f1_sumtree()
@@ -713,6 +771,7 @@ def main():
     conv_cases()
     f8_interop()
     f9_acting()
+    f10_agent()
     print('golden fixtures written to', HERE)
 
 
