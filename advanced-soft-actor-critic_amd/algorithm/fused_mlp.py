@@ -368,6 +368,21 @@ class StockMLP:
                                           self.grad_params, self._workspace_for(N), self._reduce_mode(defer))
         self._deferred_rows = N if defer else None
 
+    def policy_step_fused_ok(self, critics: 'StockMLP', N: int) -> bool:
+        """may `policy_step_fused` replace the critics' forward + `backward_policy_q` + `backward_policy_sample`?"""
+        return (self.E == 1 and critics.E == 2 and self.grad_params is not None and
+                native.policy_step_fused_ok(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
+                                            self.member_stride, N))
+
+    def policy_step_fused(self, critics: 'StockMLP', x0, action, eps, log_alpha, q_out=None, defer=False):
+        """Gaussian-head policy (E = 1) against two stock critics: the whole policy step in one launch
+        (`asac_policy_step_fused`); `q_out` [2, N, 1] receives the critics' values of (x0, action)."""
+        N = x0.shape[-2]
+        native.policy_step_fused(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
+                                 self.member_stride, x0, N, action, eps, log_alpha, q_out, self.grad_params,
+                                 self._workspace_for(N), self._reduce_mode(defer))
+        self._deferred_rows = N if defer else None
+
     def adam_partials(self, opt, loss_out=None):
         """The deferred tile reduction + Adam over this network's segment(s) in one launch (`opt`: the
         FlatAdam whose moment buffers cover the same flat layout)."""

@@ -211,6 +211,7 @@ class SAC_Base(AuxHeadsMixin):
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
+        self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
         assert self._dist_sampling in ('throughput', 'parity')
 
@@ -1164,18 +1165,24 @@ class SAC_Base(AuxHeadsMixin):
             a_tanh = torch.empty((B, A), dtype=torch.float32, device=self.device)
             logp = torch.empty(B, dtype=torch.float32, device=self.device)
             native.squash_sample_fwd(loc, scale, self._eps_pi, a_tanh, logp)
-        c_qs = self._fq._launch_forward(x, a_tanh, out=self._pi_q)                   # [E, B, 1]
         sub = self._subsets['pi_c']
         self.noise.subset_(sub, E)
-        # objective gradients formed on chip: dL/dq inside the Q backward (from the value table), dL/dlogp =
-        # alpha / B inside the sampling backward; the logged statistics are computed on demand
-        g_a = self._fq.backward_policy_q(x, a_tanh, c_qs.view(E, B), sub if self.ensemble_q_sample != E else None,
-                                         self.ensemble_q_sample)                    # [E, B, A]
         self._pi_stats_src = (logp, scale)
         opt = self.optimizer_policy
         fold = self._dist is None and (opt.start, opt.stop) == (self._fpi._start, self._fpi._start + self._fpi.member_stride)
-        # sampling backward (sums the members' action gradients) + policy backward in one launch
-        self._fpi.backward_policy_sample(x, self._eps_pi, g_a, self.log_c_alpha, defer=fold)
+        if (self._fused_policy_step and self.ensemble_q_sample == E and a_tanh.is_contiguous()
+                and self._fpi.policy_step_fused_ok(self._fq, B)):
+            # two critics, both sampled: critics forward, objective gradient, critics backward to the action, sampling
+            # backward and policy backward in ONE launch (bit-identical to the chain below)
+            self._fpi.policy_step_fused(self._fq, x, a_tanh, self._eps_pi, self.log_c_alpha, q_out=self._pi_q, defer=fold)
+        else:
+            c_qs = self._fq._launch_forward(x, a_tanh, out=self._pi_q)                   # [E, B, 1]
+            # objective gradients formed on chip: dL/dq inside the Q backward (from the value table), dL/dlogp =
+            # alpha / B inside the sampling backward; the logged statistics are computed on demand
+            g_a = self._fq.backward_policy_q(x, a_tanh, c_qs.view(E, B), sub if self.ensemble_q_sample != E else None,
+                                             self.ensemble_q_sample)                    # [E, B, A]
+            # sampling backward (sums the members' action gradients) + policy backward in one launch
+            self._fpi.backward_policy_sample(x, self._eps_pi, g_a, self.log_c_alpha, defer=fold)
         if fold:
             self._fpi.adam_partials(opt)
             return

@@ -1056,6 +1056,306 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
     MLP_STAMP(10);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The whole policy step of the stock networks in ONE launch (reference sac_base.py:1883-1906), two critics:
+//   Q_0, Q_1 forward on (s, a~pi)  ->  d(mean_b -min_e q_e)/dq  ->  both critics' backward to the ACTION only
+//   ->  rsample / tanh / log-prob backward  ->  policy backward with parameter gradients
+// i.e. asac_mlp_forward + asac_mlp_backward_policy_q + asac_mlp_backward_policy_sample, whose three launches
+// each stage 36-72 KB of weights and hand 16 KB of intermediate gradients to the next through L2.  Every step is
+// row-local, so a workgroup owns a 16-row tile from the critics' inputs to the policy's parameter-gradient
+// partials.  8 waves: in the critic phase waves 0-3 run member 0 and waves 4-7 member 1 side by side; the policy's
+// weights travel in registers meanwhile and take over the critics' LDS once they are done with it; in the policy
+// phase the 16 (heads: 8) independent weight-gradient tiles of a layer are dealt over all 8 waves.  Every MFMA
+// chain has the operand order of the three separate kernels: results are bit-identical to theirs.
+constexpr int kPsThreads = 512;
+constexpr int kPsRows = 16;
+
+struct PsQLds {       // one critic: weights, scalar head, bias, two activation tiles (forward ping-pong; then delta)
+    float w[3][kMaxW * kP];
+    float head[kHeadPad * kP];
+    float bias[3][kMaxW];
+    float head_bias[kHeadPad];
+    float xs[2][kPsRows * kP];
+};
+struct PsPiLds {      // the policy's backward: weights, heads, block inputs x_0..x_3, one delta tile
+    float w[3][kMaxW * kP];
+    float head[kHeadPad * kP];
+    float bias[3][kMaxW];
+    float head_bias[kHeadPad];
+    float x[4][kPsRows * kP];
+    float delta[kPsRows * kP];
+};
+struct PsLds {
+    PsQLds q[2];                           // the policy phase's PsPiLds overlays this
+    float ga[2][kPsRows * kHeadPad];       // the members' action gradients of the tile
+    float qv[2][kPsRows];                  // the members' values of the tile's rows
+};
+static_assert(sizeof(PsPiLds) <= 2 * sizeof(PsQLds), "the policy phase reuses the critics' LDS");
+
+struct PolicyStepArgs {
+    MlpArgs q, pi;          // q: E = 2 members, x0 = states, x1 = sampled actions; pi: x0 = states, eps, log_alpha, partial
+    float* q_out;           // [2][N] the value table (statistics) or NULL
+};
+
+// a 16-row input tile with 512 threads: 2 of the 16 x 64 slots per thread
+__device__ __forceinline__ void ps_fetch_tile(const StageScalars& q, int64_t row0, float (&v)[2]) {
+    const int in0 = q.in0, in1 = q.in1;
+    const rsrc_t r0 = make_rsrc(q.x0);
+    const rsrc_t r1 = make_rsrc(q.x1, in1 > 0 ? 0x7fffffffu : 0u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + u * kPsThreads;
+        const int r = i >> 6, c = i & 63;
+        const uint32_t row = (uint32_t)row0 + (uint32_t)r;
+        const bool live = (int64_t)row0 + r < q.N;
+        const unsigned o0 = (live && c < in0) ? (row * (uint32_t)q.x0_rs + (uint32_t)c) * 4u : kOob;
+        const unsigned o1 = (live && c >= in0 && c < in0 + in1) ? (row * (uint32_t)q.x1_rs + (uint32_t)(c - in0)) * 4u : kOob;
+        v[u] = __builtin_bit_cast(float, buf_ld(r0, o0) | buf_ld(r1, o1));
+    }
+}
+__device__ __forceinline__ void ps_put_tile(const float (&v)[2], float* xs) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + u * kPsThreads;
+        xs[(i >> 6) * kP + (i & 63)] = v[u];
+    }
+}
+
+// grad_weight<16> with the output's (J/16) x (K/16) MFMA tiles dealt over 8 waves (same chain per tile)
+__device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
+                                               int J, int K, float* __restrict__ out, int first_wave = 0) {
+    const int wave = ((threadIdx.x >> 6) + 8 - first_wave) & 7, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int njt = (J + 15) >> 4, nkt = (K + 15) >> 4;
+    const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int t = wave; t < njt * nkt; t += 8) {
+        const int jt = t / nkt, kt = t - jt * nkt;
+        float dv[4], xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[i] = delta[(4 * i + lk) * kP + jbase + jt * 16 + lr];
+            xv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], dv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], dv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], dv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], dv[3], acc1, 0, 0, 0);
+        const f32x4 acc = acc0 + acc1;
+        const int j = jt * 16 + lr, k0 = kt * 16 + 4 * lk;
+        if (j >= J) continue;
+        float* o = out + j * K + k0;
+        if (vec && k0 + 3 < K) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + r < K) o[r] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PsLds& L = *reinterpret_cast<PsLds*>(smem_raw);
+    PsPiLds& P = *reinterpret_cast<PsPiLds*>(smem_raw);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = wave >> 2, ct = wave & 3;           // critic phase: member, column tile
+    const int col = ct * 16 + (lane & 15);
+    const int64_t row0 = (int64_t)blockIdx.x * kPsRows;
+    const int64_t N = a.pi.N;
+    const int A = a.pi.d.head_cols[0];
+    const int S = a.q.d.in0, K0q = a.q.d.in0 + a.q.d.in1, K0p = a.pi.d.in0;
+
+    // ---- staging: both critics -> LDS, the policy's parameters and this tile's noise -> registers ---------------
+    const StageScalars s0 = stage_scalars<3>(a.q, 0), s1 = stage_scalars<3>(a.q, 1), sp = stage_scalars<3>(a.pi, 0);
+    float in_q[2], in_pi[2];
+    ps_fetch_tile(s0, row0, in_q);
+    ps_fetch_tile(sp, row0, in_pi);
+    StagedNet<kPsThreads> r0, r1, rp;
+    net_fetch_fixed<kPsThreads, 3>(s0, r0);
+    net_fetch_fixed<kPsThreads, 3>(s1, r1);
+    net_fetch_fixed<kPsThreads, 3>(sp, rp);
+    float ev = 0.f, gl = 0.f;       // the sampling backward's per-(row, action dim) inputs
+    {
+        const int lrow = threadIdx.x / (A > 0 ? A : 1), d = threadIdx.x - lrow * A;
+        if ((int)threadIdx.x < kPsRows * A && row0 + lrow < N) ev = a.pi.eps[(row0 + lrow) * A + d];
+        gl = expf(*a.pi.log_alpha) * (1.f / (float)N);
+    }
+    ps_put_tile(in_q, L.q[0].xs[0]);
+    ps_put_tile(in_q, L.q[1].xs[0]);
+    net_put_fixed<kPsThreads, 3>(r0, L.q[0]);
+    net_put_fixed<kPsThreads, 3>(r1, L.q[1]);
+    __syncthreads();
+
+    // ---- critics forward (derivatives of the activations stay in registers) ------------------------------------
+    PsQLds& Q = L.q[m];
+    f32x4 z[3];
+    int cur = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float* xin = Q.xs[cur];
+        float* xout = Q.xs[cur ^ 1];
+        const f32x4 acc = l > 0 ? gemm_tile(xin, Q.w[l], kMaxW, 0, ct) : gemm_tile(xin, Q.w[l], round4(K0q), 0, ct);
+        const float bias = Q.bias[l][col];
+        const bool res = a.q.d.residual[l] != 0;
+        f32x2_g ya, yb, da, db;
+        gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, da);
+        gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, db);
+        const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+        z[l] = f32x4{da.x, da.y, db.x, db.y};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (lane >> 4) + r;
+            float y = yv[r];
+            if (res) y += xin[row * kP + col];
+            xout[row * kP + col] = y;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (ct == 0) {          // the scalar head: one wave per member
+        const f32x4 raw = gemm_tile(Q.xs[cur], Q.head, kMaxW, 0, 0);
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = 4 * (lane >> 4) + r;
+                const float qv = raw[r] + Q.head_bias[0];
+                L.qv[m][lrow] = qv;
+                if (a.q_out && row0 + lrow < N) a.q_out[(int64_t)m * N + row0 + lrow] = qv;
+            }
+        }
+    }
+    __syncthreads();
+    // d(mean_b -min_e q_e)/dq_m: -1/N on the rows where member m is the (first) arg-min (sac_base.py:1896-1903)
+    float* qdelta = Q.xs[cur ^ 1];           // (the forward is done with both tiles; x_3 itself is not needed again)
+    {
+        const int t = threadIdx.x & 255;     // the member's 256 threads clear its 16 x 16 delta tile
+        const int r = t >> 4, c = t & 15;
+        float g = 0.f;
+        if (c == 0 && row0 + r < N) {
+            const int best = L.qv[1][r] < L.qv[0][r] ? 1 : 0;
+            if (best == m) g = -1.f / (float)N;
+        }
+        qdelta[r * kP + c] = g;
+    }
+    __syncthreads();
+    // ---- critics backward to the action ---------------------------------------------------------------------------
+    f32x4 g = gemm_tile_nt(qdelta, Q.head, kHeadPad, 0, ct);
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qdelta[(4 * (lane >> 4) + r) * kP + col] = g[r] * z[l][r];
+        __syncthreads();
+        f32x4 gin = gemm_tile_nt(qdelta, Q.w[l], kMaxW, 0, ct);
+        if (a.q.d.residual[l]) gin += g;
+        g = gin;
+    }
+    if (col >= S && col < K0q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L.ga[m][(4 * (lane >> 4) + r) * kHeadPad + (col - S)] = g[r];
+    }
+    __syncthreads();        // the critics are done with their LDS
+
+    // ---- the policy takes over: parameters registers -> LDS, forward recompute ------------------------------------
+    net_put_fixed<kPsThreads, 3>(rp, P);
+    ps_put_tile(in_pi, P.x[0]);
+    if (threadIdx.x < kPsRows * kHeadPad) P.delta[(threadIdx.x >> 4) * kP + (threadIdx.x & 15)] = 0.f;
+    __syncthreads();
+    f32x4 zp[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        if (wave < 4) {
+            const float* xin = P.x[l];
+            float* xout = P.x[l + 1];
+            const f32x4 acc = l > 0 ? gemm_tile(xin, P.w[l], kMaxW, 0, wave) : gemm_tile(xin, P.w[l], round4(K0p), 0, wave);
+            const int pc = wave * 16 + (lane & 15);
+            const float bias = P.bias[l][pc];
+            const bool res = a.pi.d.residual[l] != 0;
+            f32x2_g ya, yb, da, db;
+            gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, da);
+            gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, db);
+            const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+            zp[l] = f32x4{da.x, da.y, db.x, db.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                float y = yv[r];
+                if (res) y += xin[row * kP + pc];
+                xout[row * kP + pc] = y;
+            }
+        }
+        __syncthreads();
+    }
+    // raw head values -> (loc, scale) -> gradient of the rsample / tanh / log-prob chain (k_mlp_bwd's policy-sample mode)
+    if (wave == 0) {
+        const f32x4 raw = gemm_tile(P.x[3], P.head, kMaxW, 0, 0);
+        const int hc = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P.delta[(4 * (lane >> 4) + r) * kP + hc] = raw[r] + P.head_bias[hc];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < kPsRows * A) {
+        const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
+        const int64_t row = row0 + lrow;
+        float g_loc = 0.f, g_scale = 0.f;
+        const float raw_l = P.delta[lrow * kP + d], raw_s = P.delta[lrow * kP + A + d];
+        if (row < N) {
+            const float loc = head_value(a.pi.d, d, raw_l), sc = head_value(a.pi.d, A + d, raw_s);
+            const float t = tanhf(loc + ev * sc);
+            const float one_m = 1.f - t * t;
+            float ga = 0.f;
+            ga += L.ga[0][lrow * kHeadPad + d];
+            ga += L.ga[1][lrow * kHeadPad + d];
+            float gx = ga * one_m;
+            if (one_m > 1e-2f) gx += gl * ((float)A * 2.f * t);
+            g_loc = gx * head_deriv(a.pi.d, d, raw_l);
+            g_scale = (gx * ev - gl / sc) * head_deriv(a.pi.d, A + d, raw_s);
+        }
+        P.delta[lrow * kP + d] = g_loc;
+        P.delta[lrow * kP + A + d] = g_scale;
+    }
+    __syncthreads();
+    // ---- policy backward: parameter-gradient partials of this tile ------------------------------------------------
+    float* part = a.pi.partial + (int64_t)blockIdx.x * a.pi.member_stride;
+    ps_grad_weight(P.delta, 0, P.x[3], A, kMaxW, part + a.pi.d.head_w_off[0]);
+    ps_grad_weight(P.delta, A, P.x[3], A, kMaxW, part + a.pi.d.head_w_off[1], 4);
+    if (wave == 7) {        // the two head biases: 16 columns x 16 rows
+        const int c = lane & 15, rq = (lane >> 4) * 4;
+        float sb = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sb += P.delta[(rq + r) * kP + c];
+        sb += __shfl_xor(sb, 16, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        if (lane < 16) {
+            if (c < A) part[a.pi.d.head_b_off[0] + c] = sb;
+            else if (c < 2 * A) part[a.pi.d.head_b_off[1] + c - A] = sb;
+        }
+    }
+    f32x4 gp = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 4) gp = gemm_tile_nt(P.delta, P.head, kHeadPad, 0, wave);
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        const int Kin = l == 0 ? K0p : kMaxW;
+        __syncthreads();
+        if (wave < 4) {
+            const int pc = wave * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P.delta[(4 * (lane >> 4) + r) * kP + pc] = gp[r] * zp[l][r];
+        }
+        __syncthreads();
+        ps_grad_weight(P.delta, 0, P.x[l], kMaxW, Kin, part + a.pi.d.w_off[l]);
+        grad_bias<kPsRows>(P.delta, 0, kMaxW, part + a.pi.d.b_off[l]);
+        if (l > 0 && wave < 4) {
+            f32x4 gin = gemm_tile_nt(P.delta, P.w[l], kMaxW, 0, wave);
+            if (a.pi.d.residual[l]) gin += gp;
+            gp = gin;
+        }
+    }
+}
+
 // grad[e*stride + i] (+)= sum_tiles partial[tile][e][i]   (fixed order: deterministic)
 __global__ __launch_bounds__(256) void k_mlp_reduce_partials(const float* __restrict__ partial, int tiles, int E,
                                                              int64_t member_stride, int64_t used,
@@ -1413,6 +1713,54 @@ int asac_mlp_backward_policy_sample(const asac_mlp_desc_t* desc, const float* pa
     a.log_alpha = log_alpha;
     return mlp_backward_common("asac_mlp_backward_policy_sample", desc, a, 1, N, member_stride, grad_params,
                                workspace, reduce_mode, nullptr, as_stream(stream));
+}
+
+int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
+                              const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride, int64_t N) {
+    if (!q_desc || !pi_desc || !desc_ok(*q_desc) || !desc_ok(*pi_desc) || N <= 0) return 0;
+    if (!stock3(*q_desc, q_params, q_member_stride) || !stock3(*pi_desc, pi_params, pi_member_stride)) return 0;
+    if (q_desc->head_cols[0] != 1 || q_desc->head_cols[1] != 0 || q_desc->head_transform != 0) return 0;
+    if (pi_desc->head_transform != 1 || pi_desc->head_cols[0] != pi_desc->head_cols[1] || pi_desc->in1 != 0) return 0;
+    if (q_desc->in0 != pi_desc->in0 || q_desc->in1 != pi_desc->head_cols[0] || 2 * pi_desc->head_cols[0] > kHeadPad) return 0;
+    return mlp_tile_rows(N, 1) == kPsRows ? 1 : 0;        // the partials' tile count is asac_mlp_backward_tiles(N, 1)
+}
+
+int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
+                           const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
+                           const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
+                           const float* log_alpha, float* q_out, float* pi_grad_params, float* workspace,
+                           int reduce_mode, void* stream) {
+    if (!asac_policy_step_fused_ok(q_desc, q_params, q_member_stride, pi_desc, pi_params, pi_member_stride, N) ||
+        !x || !action || !eps || !log_alpha || !pi_grad_params || !workspace)
+        return bad_arg("asac_policy_step_fused");
+    PolicyStepArgs a{};
+    const int A = pi_desc->head_cols[0];
+    a.q = make_args(q_desc, q_params, q_member_stride, x, x_row_stride, 0, action, A, 0, N);
+    a.pi = make_args(pi_desc, pi_params, pi_member_stride, x, x_row_stride, 0, nullptr, 0, 0, N);
+    if (!offsets32(a.q) || !offsets32(a.pi)) return bad_arg("asac_policy_step_fused: offsets");
+    a.pi.eps = eps;
+    a.pi.log_alpha = log_alpha;
+    a.pi.partial = workspace;
+    a.q_out = q_out;
+    static bool attr_done = false;
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_policy_step), sizeof(PsLds), attr_done,
+                               "asac_policy_step_fused: hipFuncSetAttribute"))
+        return rc;
+    const int tiles = (int)((N + kPsRows - 1) / kPsRows);
+    hipStream_t s = as_stream(stream);
+    ASAC_LAUNCH(k_policy_step, dim3((unsigned)tiles), dim3(kPsThreads), sizeof(PsLds), s, a);
+    if (reduce_mode != ASAC_MLP_REDUCE_DEFER) {
+        const int64_t used = asac_mlp_param_extent(pi_desc);
+        if (tiles >= kSlicedFrom)
+            hipLaunchKernelGGL(k_mlp_reduce_partials_sliced, dim3((unsigned)((used + 63) / 64), 1u), dim3(64 * kReduceSlices),
+                               0, s, workspace, tiles, 1, pi_member_stride, used, pi_grad_params,
+                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, nullptr, nullptr, 0.f);
+        else
+            hipLaunchKernelGGL(k_mlp_reduce_partials, dim3((unsigned)((used + 255) / 256), 1u), dim3(256), 0, s, workspace,
+                               tiles, 1, pi_member_stride, used, pi_grad_params,
+                               reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, nullptr, nullptr, 0.f);
+    }
+    return finish_launch("asac_policy_step_fused");
 }
 
 int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 38
+#define ASAC_ABI_VERSION 39
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -487,6 +487,24 @@ int asac_mlp_backward_policy_q(const asac_mlp_desc_t* desc_host, const float* pa
                                const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
                                const float* q_table, const int32_t* subset, int E_sample, float* grad_x1,
                                void* stream);
+
+/* The WHOLE policy step of the stock networks with two critics in one launch (sac_base.py:1883-1906): the critics'
+ * forward on (x, action), d(mean_b -min_e q_e)/dq, both critics' backward to the action, the rsample / tanh /
+ * log-prob backward (dL/dlogp = exp(*log_alpha) / N) and the policy's backward — what asac_mlp_forward +
+ * asac_mlp_backward_policy_q (E = E_sample = 2) + asac_mlp_backward_policy_sample compute in three launches,
+ * bit for bit (same MFMA chains).  A workgroup of 8 waves owns a 16-row tile end to end; nothing but the policy's
+ * per-tile parameter-gradient partials (workspace, tiles = asac_mlp_backward_tiles(N, 1); reduce_mode as above)
+ * and the value table q_out [2][N] (optional) leaves the chip.
+ *   x [N] rows of in0 floats (row stride x_row_stride), action [N][A] = tanh(loc + eps * scale), eps [N][A].
+ * asac_policy_step_fused_ok: 1 when the shapes qualify (both networks three 64-wide blocks on <= 64 inputs with
+ * 16-byte aligned weights, scalar-head critics on (in0 | A), Gaussian-head policy on in0, N <= 4096). */
+int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
+                              const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride, int64_t N);
+int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
+                           const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
+                           const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
+                           const float* log_alpha, float* q_out, float* pi_grad_params, float* workspace,
+                           int reduce_mode, void* stream);
 
 /* The policy step's policy backward (sac_base.py:1883-1906, stock Gaussian-head ModelPolicy): the
  * gradient of the objective w.r.t. (loc | scale) — asac_squash_sample_bwd's math with dL/dlogp =

@@ -149,6 +149,50 @@ def test_policy_step_fused_backwards_match_the_kernel_chain(N):
         np.testing.assert_allclose(pgroup.grad.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('N,S,A', [(256, 6, 2), (45, 6, 2), (1024, 8, 4), (4096, 8, 4), (16, 64 - 3, 3)])
+def test_policy_step_in_one_launch_is_the_chain_bit_for_bit(N, S, A):
+    """`asac_policy_step_fused` (two critics) against critics forward + `asac_mlp_backward_policy_q` +
+    `asac_mlp_backward_policy_sample`: the value table, the reduced policy gradient and the per-tile partials the
+    Adam launch sums must be IDENTICAL (same MFMA chains, same summation orders)."""
+    from asac_amd import native
+    E = 2
+    _, qgroup, fq = _setup(E, S, A)
+    _, pgroup, fpi = _setup(1, S, A, policy=True)
+    win = torch.randn(N, 3, S, device='cuda')
+    x = win[:, 1]                                    # strided rows, like states[:, b]
+    eps = torch.randn(N, A, device='cuda')
+    log_alpha = torch.tensor(-0.7, device='cuda')
+    ls = fpi._launch_forward(x, None)[0]
+    a, logp = torch.empty(N, A, device='cuda'), torch.empty(N, device='cuda')
+    native.squash_sample_fwd(ls[:, :A], ls[:, A:], eps, a, logp)
+    assert fpi.policy_step_fused_ok(fq, N)
+    # chain
+    q = fq._launch_forward(x, a)
+    ga = fq.backward_policy_q(x, a, q.view(E, N), None, E)
+    pgroup.grad.zero_()
+    fpi.backward_policy_sample(x, eps, ga, log_alpha)
+    want = pgroup.grad.clone()
+    fpi.backward_policy_sample(x, eps, ga, log_alpha, defer=True)
+    tiles = native.mlp_backward_tiles(N, 1)
+    used = native.mlp_param_extent(fpi.desc)
+    want_partials = fpi._workspace[:tiles * fpi.member_stride].view(tiles, -1)[:, :used].clone()
+    # one launch
+    q_out = torch.zeros(E, N, 1, device='cuda')
+    pgroup.grad.zero_()
+    fpi._workspace.fill_(float('nan'))
+    fpi.policy_step_fused(fq, x, a, eps, log_alpha, q_out=q_out)
+    assert torch.equal(q_out, q), 'value table'
+    assert torch.equal(pgroup.grad, want), 'reduced policy gradient'
+    fpi._workspace.fill_(float('nan'))
+    fpi.policy_step_fused(fq, x, a, eps, log_alpha, q_out=None, defer=True)
+    got_partials = fpi._workspace[:tiles * fpi.member_stride].view(tiles, -1)[:, :used]
+    assert torch.equal(got_partials, want_partials), 'per-tile partials'
+    assert qgroup.grad.count_nonzero() == 0
+    # three critics, or too many rows for 16-row tiles: not eligible (the learner keeps the chain)
+    _, _, fq3 = _setup(3, S, A)
+    assert not fpi.policy_step_fused_ok(fq3, N) and not fpi.policy_step_fused_ok(fq, 4097)
+
+
 @pytest.mark.parametrize('N', [256, 1280, 7])
 def test_policy_forward_backward_and_gauss_head(N):
     from algorithm.fused_mlp import gauss_head
