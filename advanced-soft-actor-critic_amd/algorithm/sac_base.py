@@ -212,6 +212,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
+        self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
         assert self._dist_sampling in ('throughput', 'parity')
 
@@ -1025,15 +1026,44 @@ class SAC_Base(AuxHeadsMixin):
         E, B = self.ensemble_q_num, nx_states.shape[0]
         x0 = StockMLP._rows(nx_states[:, 0], self.state_size)
         a0 = StockMLP._rows(nx_actions[:, 0], self.c_action_size)
-        # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window
         xs = StockMLP._rows(nx_states, self.state_size)
         job_tq, _ = self._ftq.job(x0, a0, out=self._tq_buf)
         job_pi, ls = self._fpi.job(xs, None)
-        native.mlp_forward_multi([job_tq, job_pi])
-        ls = ls[0].view(*nx_states.shape[:2], 2 * self.c_action_size)
-        _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
-                             n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
-                             subset_prefix='y', y_out=self._y_buf, policy_sample=policy_sample, ls=ls)
+        T, A = nx_states.shape[1], self.c_action_size
+        fused = None
+        if self._fused_forward_chain and self.curiosity is None:
+            # policy over the window -> target sample (+ pi(stored actions), + the policy step's sample at t = 0) ->
+            # target critics on the sampled actions, with the target Q of the stored pair riding along: ONE launch
+            # (bit-identical to the three it replaces)
+            f32 = dict(dtype=torch.float32, device=self.device)
+            a_y, logp_y = torch.empty((B, T, A), **f32), torch.empty((B, T), **f32)
+            c_pi = torch.empty((B, T, A), **f32) if self.use_n_step_is else None
+            job_q, q_tab = self._ftq.job(xs, a_y.view(-1, A))
+            fused = native.pi_q_job(job_pi, job_q, self._eps_y, a_y, logp_y, T,
+                                    action=nx_actions if self.use_n_step_is else None,
+                                    action_offset=self.d_action_summed_size, prob_out=c_pi,
+                                    eps2=self._eps_pi if policy_sample else None, t2=0,
+                                    a2_out=self._pi_a, logp2_out=self._pi_logp)
+            if not native.policy_sample_q_forward_ok(fused):
+                fused = None
+        if fused is not None:
+            self.noise.normal_(self._eps_y)
+            if policy_sample:
+                self.noise.normal_(self._eps_pi)
+                self._pi_sampled = True
+            native.policy_sample_q_forward(fused, [job_tq])
+            ls = ls[0].view(B, T, 2 * A)
+            _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
+                                 n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
+                                 subset_prefix='y', y_out=self._y_buf, ls=ls, sample=(a_y, logp_y), stored_pi=c_pi,
+                                 q_table=q_tab.view(E, B, T))
+        else:
+            # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window
+            native.mlp_forward_multi([job_tq, job_pi])
+            ls = ls[0].view(*nx_states.shape[:2], 2 * self.c_action_size)
+            _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
+                                 n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
+                                 subset_prefix='y', y_out=self._y_buf, policy_sample=policy_sample, ls=ls)
         w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
         # loss + backward in one launch (the backward recomputes the forward on chip anyway); on a single
         # GPU the tile reduction of the parameter gradients is folded into the Adam launch

@@ -22,6 +22,7 @@
 #include "asac_common.h"
 #include "asac_gelu.h"
 #include "asac_sidecar.h"
+#include "asac_squash.h"
 
 #include <cmath>
 
@@ -1167,6 +1168,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     const int64_t N = a.pi.N;
     const int A = a.pi.d.head_cols[0];
     const int S = a.q.d.in0, K0q = a.q.d.in0 + a.q.d.in1, K0p = a.pi.d.in0;
+    MLP_STAMP(0);
 
     // ---- staging: both critics -> LDS, the policy's parameters and this tile's noise -> registers ---------------
     const StageScalars s0 = stage_scalars<3>(a.q, 0), s1 = stage_scalars<3>(a.q, 1), sp = stage_scalars<3>(a.pi, 0);
@@ -1188,6 +1190,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     net_put_fixed<kPsThreads, 3>(r0, L.q[0]);
     net_put_fixed<kPsThreads, 3>(r1, L.q[1]);
     __syncthreads();
+    MLP_STAMP(1);
 
     // ---- critics forward (derivatives of the activations stay in registers) ------------------------------------
     PsQLds& Q = L.q[m];
@@ -1215,6 +1218,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         __syncthreads();
         cur ^= 1;
     }
+    MLP_STAMP(2);
     if (ct == 0) {          // the scalar head: one wave per member
         const f32x4 raw = gemm_tile(Q.xs[cur], Q.head, kMaxW, 0, 0);
         if ((lane & 15) == 0) {
@@ -1228,6 +1232,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         }
     }
     __syncthreads();
+    MLP_STAMP(3);
     // d(mean_b -min_e q_e)/dq_m: -1/N on the rows where member m is the (first) arg-min (sac_base.py:1896-1903)
     float* qdelta = Q.xs[cur ^ 1];           // (the forward is done with both tiles; x_3 itself is not needed again)
     {
@@ -1241,6 +1246,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         qdelta[r * kP + c] = g;
     }
     __syncthreads();
+    MLP_STAMP(4);
     // ---- critics backward to the action ---------------------------------------------------------------------------
     f32x4 g = gemm_tile_nt(qdelta, Q.head, kHeadPad, 0, ct);
 #pragma unroll
@@ -1258,12 +1264,14 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         for (int r = 0; r < 4; ++r) L.ga[m][(4 * (lane >> 4) + r) * kHeadPad + (col - S)] = g[r];
     }
     __syncthreads();        // the critics are done with their LDS
+    MLP_STAMP(5);
 
     // ---- the policy takes over: parameters registers -> LDS, forward recompute ------------------------------------
     net_put_fixed<kPsThreads, 3>(rp, P);
     ps_put_tile(in_pi, P.x[0]);
     if (threadIdx.x < kPsRows * kHeadPad) P.delta[(threadIdx.x >> 4) * kP + (threadIdx.x & 15)] = 0.f;
     __syncthreads();
+    MLP_STAMP(6);
     f32x4 zp[3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
@@ -1289,6 +1297,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         }
         __syncthreads();
     }
+    MLP_STAMP(7);
     // raw head values -> (loc, scale) -> gradient of the rsample / tanh / log-prob chain (k_mlp_bwd's policy-sample mode)
     if (wave == 0) {
         const f32x4 raw = gemm_tile(P.x[3], P.head, kMaxW, 0, 0);
@@ -1297,6 +1306,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         for (int r = 0; r < 4; ++r) P.delta[(4 * (lane >> 4) + r) * kP + hc] = raw[r] + P.head_bias[hc];
     }
     __syncthreads();
+    MLP_STAMP(8);
     if ((int)threadIdx.x < kPsRows * A) {
         const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
         const int64_t row = row0 + lrow;
@@ -1318,6 +1328,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         P.delta[lrow * kP + A + d] = g_scale;
     }
     __syncthreads();
+    MLP_STAMP(9);
     // ---- policy backward: parameter-gradient partials of this tile ------------------------------------------------
     float* part = a.pi.partial + (int64_t)blockIdx.x * a.pi.member_stride;
     ps_grad_weight(P.delta, 0, P.x[3], A, kMaxW, part + a.pi.d.head_w_off[0]);
@@ -1336,6 +1347,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     }
     f32x4 gp = {0.f, 0.f, 0.f, 0.f};
     if (wave < 4) gp = gemm_tile_nt(P.delta, P.head, kHeadPad, 0, wave);
+    MLP_STAMP(10);
 #pragma unroll
     for (int l = 2; l >= 0; --l) {
         const int Kin = l == 0 ? K0p : kMaxW;
@@ -1353,7 +1365,284 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
             if (a.pi.d.residual[l]) gin += gp;
             gp = gin;
         }
+        MLP_STAMP(11 + (2 - l));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Policy forward -> sampling -> critic ensemble forward over the same rows in ONE launch: what the train step issues
+// as asac_mlp_forward(_multi)[policy] -> asac_squash_multi -> asac_mlp_forward(_multi)[critics] for the return target
+// (sac_base.py:1297-1466) and again for the TD error / new behaviour probabilities (2182-2245, 1159-1189).  The
+// chain is row-local: a workgroup (16-row tile, member e) evaluates the policy on its tile, samples on chip, runs
+// critic e on (state, sampled action).  Both networks' weights are staged together (one L2 round trip instead of
+// two launches' worth), (loc | scale) and the sampled actions never travel through L2 between launches.  The policy
+// part is repeated by the E workgroups of a tile (they run side by side on different CUs); member 0's workgroup
+// writes the shared outputs.  Same MFMA chains and the very device functions of the separate launches: bit-identical.
+struct PiQLds {
+    float head[kHeadPad * kP];            // --- the layout of MlpLds<16> up to `w`: the extra plain forward jobs of the
+    float bias[kMaxB][kMaxW];             //     launch run mlp_fwd_tiles<16> on the same memory
+    float head_bias[kHeadPad];
+    float xs[2][16 * kP];
+    float w[3][kMaxW * kP];               // the policy
+    float qw[3][kMaxW * kP];              // critic e
+    float qhead[kHeadPad * kP];
+    float qbias[3][kMaxW];
+    float qhead_bias[kHeadPad];
+    float ls[16 * 2 * kHeadPad];          // (loc | scale) of the tile, row pitch 32
+    float act[16 * kHeadPad];             // sampled actions of the tile
+};
+static_assert(offsetof(PiQLds, w) == offsetof(MlpLds<16>, w), "PiQLds starts like MlpLds<16>");
+
+struct PiQCritic {       // a view with the member names net_put_fixed expects
+    float (&w)[3][kMaxW * kP];
+    float (&head)[kHeadPad * kP];
+    float (&bias)[3][kMaxW];
+    float (&head_bias)[kHeadPad];
+};
+
+struct PiQArgs {
+    MlpArgs pi, q;            // pi.out: [N][2A] (loc | scale) or NULL; q.out: [E][N]
+    int32_t E, tile_groups;   // critics; workgroups along the tile axis (they loop over the tiles)
+    int32_t blocks;           // workgroups of the fused job = tile_groups * E
+    // sampling (asac_squash_job_t): main sample over every row, optional stored-action probabilities, optional second
+    // sample at window position t2
+    const float* eps;
+    float *a_out, *logp_out;
+    StoredProb sp;
+    const float* eps2;
+    int32_t T, t2;
+    float *a2_out, *logp2_out;
+};
+
+template <bool WINDOW>
+__device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
+    constexpr int THREADS = 256;
+    const int e = (int)blockIdx.x % a.E, group = (int)blockIdx.x / a.E;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = wave * 16 + (lane & 15);
+    const int A = a.pi.d.head_cols[0], S = a.q.d.in0;
+    const int K0p = a.pi.d.in0, K0q = a.q.d.in0 + a.q.d.in1;
+    const int64_t N = a.pi.N;
+    const int n_tiles = (int)((N + 15) / 16);
+    const bool writer = e == 0;
+    MLP_STAMP(0);
+
+    // ---- staging: the policy and critic e, one round trip ----------------------------------------------------------
+    const StageScalars sp = stage_scalars<3>(a.pi, 0), sq = stage_scalars<3>(a.q, e);
+    float in_lo[4];
+    fetch_input_tile_fixed<THREADS, WINDOW>(sp, 0, (int64_t)group * 16, in_lo);
+    StagedNet<THREADS> rp, rq;
+    net_fetch_fixed<THREADS, 3>(sp, rp);
+    net_fetch_fixed<THREADS, 3>(sq, rq);
+    put_input_tile<THREADS>(in_lo, L.xs[0]);
+    net_put_fixed<THREADS, 3>(rp, L);
+    PiQCritic C{L.qw, L.qhead, L.qbias, L.qhead_bias};
+    net_put_fixed<THREADS, 3>(rq, C);
+    __syncthreads();
+    MLP_STAMP(1);
+
+    for (int tile = group; tile < n_tiles; tile += a.tile_groups) {
+        const int64_t row0 = (int64_t)tile * 16;
+        if (tile != group) {       // (later tiles of a looping workgroup: the first one arrived with the weights)
+            fetch_input_tile_fixed<THREADS, WINDOW>(sp, 0, row0, in_lo);
+            __syncthreads();
+            put_input_tile<THREADS>(in_lo, L.xs[0]);
+            __syncthreads();
+        }
+        // ---- policy forward ----------------------------------------------------------------------------------------
+        int cur = 0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float* xin = L.xs[cur];
+            float* xout = L.xs[cur ^ 1];
+            const f32x4 acc = l > 0 ? gemm_tile(xin, L.w[l], kMaxW, 0, wave) : gemm_tile(xin, L.w[l], round4(K0p), 0, wave);
+            const float bias = L.bias[l][col];
+            const bool res = a.pi.d.residual[l] != 0;
+            f32x2_g ya, yb, unused;
+            gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
+            gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
+            const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                float y = yv[r];
+                if (res) y += xin[row * kP + col];
+                xout[row * kP + col] = y;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        MLP_STAMP(2);
+        if (wave == 0) {
+            const f32x4 acc = gemm_tile(L.xs[cur], L.head, kMaxW, 0, 0);
+            const int hc = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = 4 * (lane >> 4) + r;
+                const float v = head_value(a.pi.d, hc, acc[r] + L.head_bias[hc]);
+                L.ls[lrow * 2 * kHeadPad + hc] = v;
+                if (writer && a.pi.out && row0 + lrow < N && hc < 2 * A) a.pi.out[(row0 + lrow) * (2 * A) + hc] = v;
+            }
+        }
+        __syncthreads();
+        MLP_STAMP(3);
+        // ---- sampling: the elementwise launches' arithmetic (asac_squash.h), spread over lanes ---------------------------
+        // Their one-lane-per-row loops cost ~4 us of dependent tanh / log / atanh / exp chains here (16 rows = 16 lanes).
+        // Same values, same summation order: the per-(row, d) transcendentals run on 16 A lanes — main sample on wave
+        // 0, stored-action probabilities on wave 1, the second sample on wave 2 — and land in LDS; one lane per row
+        // then forms the sums / products over d in d order.
+        {
+            float* scr = L.xs[1];                  // (the policy's last activations are dead; xs[0] is being refilled)
+            const int job = wave;                  // 0 main, 1 stored-action probabilities, 2 second sample
+            const bool job_on = job == 0 || (writer && ((job == 1 && a.sp.action) || (job == 2 && a.eps2)));
+            float* s0 = scr + job * 256;           // [16][8] per-element term 0 | [16][8] term 1
+            float* s1 = s0 + 128;
+            if (job < 3 && job_on) {
+                for (int it = lane; it < 16 * A; it += 64) {
+                    const int lrow = it / A, d = it - lrow * A;
+                    const int64_t r = row0 + lrow;
+                    if (r >= N) continue;
+                    const float l = L.ls[lrow * 2 * kHeadPad + d], sc = L.ls[lrow * 2 * kHeadPad + A + d];
+                    if (job == 1) {
+                        const int64_t sb = r / a.sp.T, st = r - sb * a.sp.T;
+                        const float av = a.sp.action[sb * a.sp.a_sb + st * a.sp.a_st + a.sp.a_off + d];
+                        const float x = atanhf(fminf(fmaxf(av, -0.999f), 0.999f));
+                        s0[lrow * 8 + d] = squash_jac(x);
+                        s1[lrow * 8 + d] = expf(normal_log_prob(x, l, sc));
+                    } else {
+                        float ev;
+                        const int64_t smp = r / a.T;
+                        if (job == 0) {
+                            ev = a.eps[r * A + d];
+                        } else {
+                            if (r - smp * a.T != a.t2) continue;
+                            ev = a.eps2[smp * A + d];
+                        }
+                        const float x = l + ev * sc;
+                        const float t = tanhf(x);
+                        s0[lrow * 8 + d] = logf(fmaxf(1.f - t * t, kSquashFloor));
+                        s1[lrow * 8 + d] = normal_log_prob(x, l, sc);
+                        if (job == 0) {
+                            L.act[lrow * kHeadPad + d] = t;
+                            if (writer) a.a_out[r * A + d] = t;
+                        } else {
+                            a.a2_out[smp * A + d] = t;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < 16) {
+                    const int lrow = lane;
+                    const int64_t r = row0 + lrow;
+                    if (r < N) {
+                        if (job == 1) {
+                            float jac = 1.f;
+                            for (int d = 0; d < A; ++d) jac *= s0[lrow * 8 + d];
+                            const int64_t sb = r / a.sp.T, st = r - sb * a.sp.T;
+                            float* out = a.sp.out + sb * a.sp.p_sb + st * a.sp.p_st + a.sp.p_off;
+                            for (int d = 0; d < A; ++d) out[d] = s1[lrow * 8 + d] / jac;
+                        } else {
+                            const int64_t smp = r / a.T;
+                            if (job == 0 || r - smp * a.T == a.t2) {
+                                float corr = 0.f;
+                                for (int d = 0; d < A; ++d) corr += s0[lrow * 8 + d];
+                                float lp = 0.f;
+                                for (int d = 0; d < A; ++d) {
+                                    float v = s1[lrow * 8 + d] - corr;
+                                    if (v == INFINITY) v = 0.f;
+                                    lp += v;
+                                }
+                                if (job == 2) a.logp2_out[smp] = lp;
+                                else if (writer) a.logp_out[r] = lp;
+                            }
+                        }
+                    }
+                }
+            }
+            if (job == 0 && lane < 16 && row0 + lane >= N)
+                for (int d = 0; d < A; ++d) L.act[lane * kHeadPad + d] = 0.f;
+        }
+        // ---- critic e on (state, sampled action) ---------------------------------------------------------------------
+        put_input_tile<THREADS>(in_lo, L.xs[0]);         // the states again (columns >= S are zero)
+        __syncthreads();
+        MLP_STAMP(4);
+        if ((int)threadIdx.x < 16 * A) {
+            const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
+            L.xs[0][lrow * kP + S + d] = L.act[lrow * kHeadPad + d];
+        }
+        __syncthreads();
+        MLP_STAMP(5);
+        cur = 0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float* xin = L.xs[cur];
+            float* xout = L.xs[cur ^ 1];
+            const f32x4 acc = l > 0 ? gemm_tile(xin, L.qw[l], kMaxW, 0, wave) : gemm_tile(xin, L.qw[l], round4(K0q), 0, wave);
+            const float bias = L.qbias[l][col];
+            const bool res = a.q.d.residual[l] != 0;
+            f32x2_g ya, yb, unused;
+            gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
+            gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
+            const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (lane >> 4) + r;
+                float y = yv[r];
+                if (res) y += xin[row * kP + col];
+                xout[row * kP + col] = y;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        MLP_STAMP(6);
+        if (wave == 0) {
+            const f32x4 acc = gemm_tile(L.xs[cur], L.qhead, kMaxW, 0, 0);
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + 4 * (lane >> 4) + r;
+                    if (row < N) a.q.out[(int64_t)e * N + row] = acc[r] + L.qhead_bias[0];
+                }
+            }
+        }
+        MLP_STAMP(7);
+    }
+}
+
+struct PiQLaunch {
+    PiQArgs f;
+    MlpMultiArgs extra;       // plain forward jobs riding in the same launch (their workgroups follow the fused job's)
+};
+
+static_assert(sizeof(PiQLaunch) + sizeof(SidecarsDev) <= 4096, "kernel arguments of k_pi_sample_q");
+
+__global__ __launch_bounds__(256) void k_pi_sample_q(const PiQLaunch m, const SidecarsDev sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int blk = (int)blockIdx.x;
+    if (blk < m.f.blocks) {
+        PiQLds& L = *reinterpret_cast<PiQLds*>(smem_raw);
+        if (m.f.pi.x0_T > 0) pi_q_tiles<true>(m.f, L);
+        else pi_q_tiles<false>(m.f, L);
+        return;
+    }
+    const int xb = blk - m.f.blocks;
+    if (xb >= m.extra.blocks) {
+        sidecar_run(sc, xb - m.extra.blocks, reinterpret_cast<float*>(smem_raw));
+        return;
+    }
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < ASAC_MLP_MAX_JOBS; ++q)
+        if (q < m.extra.n && xb >= m.extra.first_block[q]) k = q;
+    const int local = xb - m.extra.first_block[k];
+    const int E = m.extra.E[k];
+    MlpLds<16>& L = *reinterpret_cast<MlpLds<16>*>(smem_raw);
+    if (m.extra.job[k].x0_T > 0)
+        mlp_fwd_tiles<16, true, false, 3>(m.extra.job[k], local % E, local / E, m.extra.tile_stride[k], L);
+    else
+        mlp_fwd_tiles<16, false, false, 3>(m.extra.job[k], local % E, local / E, m.extra.tile_stride[k], L);
 }
 
 // grad[e*stride + i] (+)= sum_tiles partial[tile][e][i]   (fixed order: deterministic)
@@ -1761,6 +2050,94 @@ int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params,
                                reduce_mode == ASAC_MLP_REDUCE_ACCUMULATE ? 1 : 0, nullptr, nullptr, 0.f);
     }
     return finish_launch("asac_policy_step_fused");
+}
+
+static bool pi_q_job_ok(const asac_pi_q_job_t& j) {
+    const asac_mlp_job_t &p = j.pi, &q = j.q;
+    if (!p.desc || !q.desc || !desc_ok(*p.desc) || !desc_ok(*q.desc) || p.N <= 0 || q.N != p.N || p.E != 1 || q.E < 1) return false;
+    if (!stock3(*p.desc, p.params, p.member_stride) || !stock3(*q.desc, q.params, q.member_stride)) return false;
+    if (q.desc->head_cols[0] != 1 || q.desc->head_cols[1] != 0 || q.desc->head_transform != 0) return false;
+    if (p.desc->head_transform != 1 || p.desc->head_cols[0] != p.desc->head_cols[1] || p.desc->in1 != 0) return false;
+    const int A = p.desc->head_cols[0];
+    if (q.desc->in0 != p.desc->in0 || q.desc->in1 != A || 2 * A > kHeadPad || A > 8) return false;
+    if (!p.x0 || q.x0 != p.x0 || q.x0_row_stride != p.x0_row_stride || q.x0_window_T != p.x0_window_T ||
+        q.x0_sample_stride != p.x0_sample_stride || p.x0_member_stride != 0 || q.x0_member_stride != 0 || !q.out)
+        return false;        // the critics read the policy's rows
+    const asac_squash_job_t& s = j.sample;
+    if (!s.eps || !s.a_tanh_out || !s.logp_out || s.A != A || s.rows != p.N) return false;
+    if (s.action && (!s.prob_out || s.T <= 0)) return false;
+    if (j.eps2 && (!j.a2_out || !j.logp2_out || s.T <= 0 || j.t2 < 0 || j.t2 >= s.T)) return false;
+    return p.N * (p.x0_row_stride + 1) < 0x1fffffffLL &&
+           (p.x0_window_T == 0 || (p.N / p.x0_window_T + 1) * p.x0_sample_stride < 0x1fffffffLL);
+}
+
+int asac_policy_sample_q_forward_ok(const asac_pi_q_job_t* job) { return job && pi_q_job_ok(*job) ? 1 : 0; }
+
+int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_t* extra_jobs, int n_extra,
+                                 const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream) {
+    if (!job || !pi_q_job_ok(*job) || n_extra < 0 || n_extra > ASAC_MLP_MAX_JOBS || (n_extra > 0 && !extra_jobs))
+        return bad_arg("asac_policy_sample_q_forward");
+    SidecarsDev sc{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_policy_sample_q_forward: sidecar");
+    PiQLaunch m{};
+    const asac_mlp_job_t &p = job->pi, &q = job->q;
+    PiQArgs& f = m.f;
+    f.pi = make_args(p.desc, p.params, p.member_stride, p.x0, p.x0_row_stride, 0, nullptr, 0, 0, p.N);
+    f.pi.x0_T = p.x0_window_T;
+    f.pi.x0_sb = p.x0_sample_stride;
+    f.pi.out = p.out;
+    f.q = make_args(q.desc, q.params, q.member_stride, p.x0, p.x0_row_stride, 0, p.x0, 0, 0, p.N);   // (x1: the sampled actions, on chip)
+    f.q.x0_T = p.x0_window_T;
+    f.q.x0_sb = p.x0_sample_stride;
+    f.q.out = q.out;
+    f.E = q.E;
+    const int tiles = (int)((p.N + 15) / 16);
+    const int cap = 256 / q.E > 0 ? 256 / q.E : 1;
+    f.tile_groups = tiles <= cap ? tiles : cap;
+    f.blocks = f.tile_groups * q.E;
+    const asac_squash_job_t& sj = job->sample;
+    f.eps = sj.eps;
+    f.a_out = sj.a_tanh_out;
+    f.logp_out = sj.logp_out;
+    f.sp = StoredProb{sj.action, sj.T, sj.action_stride_b, sj.action_stride_t, sj.action_offset,
+                      sj.prob_out, sj.prob_stride_b, sj.prob_stride_t, sj.prob_offset};
+    f.eps2 = job->eps2;
+    f.T = sj.T > 0 ? sj.T : 1;
+    f.t2 = job->t2;
+    f.a2_out = job->a2_out;
+    f.logp2_out = job->logp2_out;
+    MlpMultiArgs& x = m.extra;
+    x.n = n_extra;
+    int blocks = 0;
+    for (int k = 0; k < n_extra; ++k) {
+        const asac_mlp_job_t& j = extra_jobs[k];
+        if (!j.desc || !desc_ok(*j.desc) || !stock3(*j.desc, j.params, j.member_stride) || j.E <= 0 || j.N <= 0 || !j.x0 ||
+            (j.desc->in1 > 0 && !j.x1) || !j.out || j.x0_window_T < 0 ||
+            j.N * (j.x0_row_stride + j.x1_row_stride + 1) >= 0x1fffffffLL ||
+            (j.x0_window_T > 0 && (j.N / j.x0_window_T + 1) * j.x0_sample_stride >= 0x1fffffffLL))
+            return bad_arg("asac_policy_sample_q_forward: extra job");
+        x.job[k] = make_args(j.desc, j.params, j.member_stride, j.x0, j.x0_row_stride, j.x0_member_stride, j.x1,
+                             j.x1_row_stride, j.x1_member_stride, j.N);
+        x.job[k].x0_T = j.x0_window_T;
+        x.job[k].x0_sb = j.x0_sample_stride;
+        x.job[k].out = j.out;
+        x.E[k] = j.E;
+        x.first_block[k] = blocks;
+        x.tile_stride[k] = mlp_tile_groups(j.N, j.E, 1, 16);
+        blocks += x.tile_stride[k] * j.E;
+    }
+    x.blocks = blocks;
+    static bool attr_done = false;
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_pi_sample_q), sizeof(PiQLds), attr_done,
+                               "asac_policy_sample_q_forward: hipFuncSetAttribute"))
+        return rc;
+    const SidecarsDev none{};
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
+        const bool last = rep == g_launch_repeat - 1;
+        hipLaunchKernelGGL(k_pi_sample_q, dim3((unsigned)(f.blocks + blocks + (last ? sc.blocks : 0))), dim3(256),
+                           sizeof(PiQLds), as_stream(stream), m, last ? sc : none);
+    }
+    return finish_launch("asac_policy_sample_q_forward");
 }
 
 int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,

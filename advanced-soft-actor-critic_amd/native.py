@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 39
+ABI_VERSION = 40
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -105,6 +105,12 @@ class SquashJob(C.Structure):
 SQUASH_MAX_JOBS = 4
 
 
+class PiQJob(C.Structure):
+    """asac_pi_q_job_t: policy forward -> sampling -> critics forward over the same rows"""
+    _fields_ = [('pi', MlpJob), ('sample', SquashJob), ('eps2', C.c_void_p), ('t2', C.c_int32), ('reserved_', C.c_int32),
+                ('a2_out', C.c_void_p), ('logp2_out', C.c_void_p), ('q', MlpJob)]
+
+
 class GruDesc(C.Structure):
     _fields_ = [('input', C.c_int32), ('hidden', C.c_int32), ('hidden_pow2', C.c_int32), ('layers', C.c_int32)]
 
@@ -179,6 +185,9 @@ _SIGNATURES = {
     'asac_mlp_backward_policy_sample': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'asac_policy_sample_q_forward_ok': (C.c_int, [C.POINTER(PiQJob)]),
+    'asac_policy_sample_q_forward': (C.c_int, [C.POINTER(PiQJob), C.POINTER(MlpJob), C.c_int, C.POINTER(Sidecar), C.c_int,
+                                               C.c_void_p]),
     'asac_policy_step_fused_ok': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(MlpDesc), C.c_void_p,
                                             C.c_int64, C.c_int64]),
     'asac_policy_step_fused': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(MlpDesc), C.c_void_p,
@@ -695,6 +704,48 @@ def mlp_forward_multi(jobs, sidecars=None):
     arr = (MlpJob * len(jobs))(*jobs)
     sc, n_sc = _sidecar_array(sidecars)
     _check(load().asac_mlp_forward_multi(arr, len(jobs), sc, n_sc, _stream()), 'asac_mlp_forward_multi')
+
+
+def pi_q_job(pi_job: MlpJob, q_job: MlpJob, eps, a_out, logp_out, T, action=None, action_offset=0, prob_out=None,
+             prob_offset=0, eps2=None, t2=0, a2_out=None, logp2_out=None) -> PiQJob:
+    """The fused policy -> sample -> critics forward (`policy_sample_q_forward`): `pi_job` / `q_job` from `mlp_job`
+    on the same rows ([samples, T] flattened); the main sample (eps -> a_out, logp_out), optionally the stored
+    actions' probabilities and a second sample at window position `t2`.  Raw pointers: keep the tensors alive."""
+    j = PiQJob()
+    j.pi, j.q = pi_job, q_job
+    A = pi_job.desc.contents.head_cols[0]
+    N = pi_job.N
+    assert eps.is_contiguous() and a_out.is_contiguous() and eps.numel() == N * A and logp_out.numel() == N
+    s = j.sample
+    s.eps, s.a_tanh_out, s.logp_out, s.rows, s.A, s.T = eps.data_ptr(), a_out.data_ptr(), logp_out.data_ptr(), N, A, T
+    if action is not None:
+        assert action.dim() == 3 and prob_out.dim() == 3 and action.stride(-1) == 1 and prob_out.stride(-1) == 1
+        assert action.shape[0] * action.shape[1] == N and action.shape[1] == T and prob_out.shape[:2] == action.shape[:2]
+        s.action, s.action_stride_b, s.action_stride_t, s.action_offset = \
+            action.data_ptr(), action.stride(0), action.stride(1), action_offset
+        s.prob_out, s.prob_stride_b, s.prob_stride_t, s.prob_offset = \
+            prob_out.data_ptr(), prob_out.stride(0), prob_out.stride(1), prob_offset
+    if eps2 is not None:
+        assert eps2.is_contiguous() and a2_out.is_contiguous() and eps2.numel() == (N // T) * A
+        j.eps2, j.t2, j.a2_out, j.logp2_out = eps2.data_ptr(), t2, a2_out.data_ptr(), logp2_out.data_ptr()
+    return j
+
+
+def policy_sample_q_forward_ok(job: PiQJob) -> bool:
+    return bool(load().asac_policy_sample_q_forward_ok(C.byref(job)))
+
+
+@_profiled
+def policy_sample_q_forward(job: PiQJob, extra_jobs=(), sidecars=None):
+    global _last_work
+    _last_work = (mlp_flops(job.pi.desc.contents, job.q.E, job.pi.N) + mlp_flops(job.q.desc.contents, job.q.E, job.q.N)
+                  + sum(mlp_flops(j.desc.contents, j.E, j.N) for j in extra_jobs))
+    extra_jobs = list(extra_jobs)
+    assert len(extra_jobs) <= MLP_MAX_JOBS
+    arr = (MlpJob * len(extra_jobs))(*extra_jobs) if extra_jobs else None
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_policy_sample_q_forward(C.byref(job), arr, len(extra_jobs), sc, n_sc, _stream()),
+           'asac_policy_sample_q_forward')
 
 
 def mlp_backward_workspace(member_stride, E, N) -> int:

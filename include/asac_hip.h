@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 39
+#define ASAC_ABI_VERSION 40
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -439,6 +439,35 @@ typedef struct {
 } asac_mlp_job_t;
 int asac_mlp_forward_multi(const asac_mlp_job_t* jobs_host, int n_jobs, const asac_sidecar_t* sidecars_host,
                            int n_sidecars, void* stream);
+
+/* Policy forward -> sampling -> critic ensemble forward over the same rows in ONE launch: the chain
+ * asac_mlp_forward(_multi)[policy] -> asac_squash_multi -> asac_mlp_forward(_multi)[critics] of the return target
+ * (sac_base.py:1297-1466: a' ~ pi(s_t), Q'_e(s_t, a')) and of the TD error / new behaviour probabilities (2182-2245,
+ * 1159-1189), bit for bit.  A workgroup owns (16-row tile, critic e) end to end; the policy's output and the sampled
+ * actions stay on chip between the three stages.
+ *   pi      the policy (E = 1) over N rows (flat or window addressing); out: [N][2A] (loc | scale) or NULL
+ *   sample  the main sample over every row: eps [N][A] -> a_tanh_out [N][A], logp_out [N]; with `action` also the
+ *           stored actions' probabilities (fields as asac_squash_job_t; loc / scale / ls_row_stride / x_out unused)
+ *   eps2    optional second sample from the same (loc | scale) at window position t2 of every sample (rows are
+ *           [samples][sample.T]): eps2 [samples][A] -> a2_out [samples][A], logp2_out [samples]
+ *   q       the critics (E members) on (the policy's rows, the main sample): x0 fields equal pi's, x1 ignored,
+ *           out [E][N]
+ * extra_jobs: up to ASAC_MLP_MAX_JOBS plain forward passes (three 64-wide blocks) riding as further workgroups;
+ * sidecars as asac_mlp_forward_multi.  asac_policy_sample_q_forward_ok: 1 when `job` qualifies (both networks three
+ * 64-wide blocks on <= 64 inputs, 16-byte aligned weights, scalar-head critics on (in0 | A), Gaussian-head policy). */
+typedef struct {
+    asac_mlp_job_t pi;
+    asac_squash_job_t sample;
+    const float* eps2;
+    int32_t t2;
+    int32_t reserved_;
+    float* a2_out;
+    float* logp2_out;
+    asac_mlp_job_t q;
+} asac_pi_q_job_t;
+int asac_policy_sample_q_forward_ok(const asac_pi_q_job_t* job);
+int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_t* extra_jobs, int n_extra,
+                                 const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream);
 
 #define ASAC_MLP_REDUCE_OVERWRITE 0
 #define ASAC_MLP_REDUCE_ACCUMULATE 1

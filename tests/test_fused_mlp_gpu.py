@@ -193,6 +193,57 @@ def test_policy_step_in_one_launch_is_the_chain_bit_for_bit(N, S, A):
     assert not fpi.policy_step_fused_ok(fq3, N) and not fpi.policy_step_fused_ok(fq, 4097)
 
 
+@pytest.mark.parametrize('B,T,S,A,E,window', [(256, 5, 6, 2, 2, False), (256, 5, 6, 2, 2, True), (37, 3, 8, 4, 3, True),
+                                               (1024, 9, 8, 4, 2, False), (6000, 2, 6, 2, 2, False)])
+def test_policy_sample_critics_forward_in_one_launch_is_the_chain_bit_for_bit(B, T, S, A, E, window):
+    """`asac_policy_sample_q_forward` against policy forward -> `asac_squash_multi` -> critics forward (+ the extra
+    plain forward job riding along): every output identical."""
+    from asac_amd import native
+    _, _, fq = _setup(E, S, A)
+    _, _, fpi = _setup(1, S, A, policy=True)
+    N = B * T
+    if window:      # [B, T, S] view of a longer window (states[:, b:]), read in place
+        base = torch.randn(B, T + 2, S, device='cuda')
+        xs = native.WindowRows(base[:, 2:])
+        x_flat = base[:, 2:].reshape(N, S)
+    else:
+        x_flat = torch.randn(N, S, device='cuda')
+        xs = x_flat
+    eps, eps2 = torch.randn(N, A, device='cuda'), torch.randn(B, A, device='cuda')
+    stored = torch.rand(B, T, A + 1, device='cuda') * 1.9 - 0.95       # stored actions behind one discrete column
+    x0, a0 = torch.randn(B, S, device='cuda'), torch.randn(B, A, device='cuda').tanh()
+    t2 = T - 1
+    # the chain
+    ls = fpi._launch_forward(xs, None)[0].view(B, T, 2 * A)
+    a_w, lp_w, pr_w = torch.empty(B, T, A, device='cuda'), torch.empty(B, T, device='cuda'), torch.zeros(B, T, A, device='cuda')
+    a2_w, lp2_w = torch.empty(B, A, device='cuda'), torch.empty(B, device='cuda')
+    native.squash_multi([native.squash_job(ls[..., :A], ls[..., A:], eps, a_w, lp_w, stored, 1, pr_w, 0),
+                         native.squash_job(ls[:, t2, :A], ls[:, t2, A:], eps2, a2_w, lp2_w)])
+    q_w = fq._launch_forward(xs, a_w.view(N, A))
+    x_w = fq._launch_forward(x0, a0)
+    # one launch
+    job_pi, ls_g = fpi.job(xs, None)
+    a_g, lp_g, pr_g = torch.empty(B, T, A, device='cuda'), torch.empty(B, T, device='cuda'), torch.zeros(B, T, A, device='cuda')
+    a2_g, lp2_g = torch.empty(B, A, device='cuda'), torch.empty(B, device='cuda')
+    job_q, q_g = fq.job(xs, a_g.view(N, A))
+    job_x, x_g = fq.job(x0, a0)
+    job = native.pi_q_job(job_pi, job_q, eps, a_g, lp_g, T, action=stored, action_offset=1, prob_out=pr_g,
+                          eps2=eps2, t2=t2, a2_out=a2_g, logp2_out=lp2_g)
+    assert native.policy_sample_q_forward_ok(job)
+    native.policy_sample_q_forward(job, [job_x])
+    for name, got, want in (('loc|scale', ls_g[0].view(B, T, 2 * A), ls), ('action', a_g, a_w), ('logp', lp_g, lp_w),
+                            ('stored-action probabilities', pr_g, pr_w), ('second sample', a2_g, a2_w),
+                            ('second logp', lp2_g, lp2_w), ('critics', q_g, q_w), ('extra job', x_g, x_w)):
+        assert torch.equal(got, want), name
+    # no stored actions / second sample; and a job that does not qualify
+    job = native.pi_q_job(job_pi, job_q, eps, a_g.zero_(), lp_g.zero_(), T)
+    q_g.zero_()
+    native.policy_sample_q_forward(job)
+    assert torch.equal(a_g, a_w) and torch.equal(lp_g, lp_w) and torch.equal(q_g, q_w)
+    other = fq.job(torch.randn(N, S, device='cuda'), a_g.view(N, A))[0]
+    assert not native.policy_sample_q_forward_ok(native.pi_q_job(job_pi, other, eps, a_g, lp_g, T))
+
+
 @pytest.mark.parametrize('N', [256, 1280, 7])
 def test_policy_forward_backward_and_gauss_head(N):
     from algorithm.fused_mlp import gauss_head

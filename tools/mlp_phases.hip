@@ -79,5 +79,51 @@ int main() {
             printf("   reverse L3 in detail: delta tile + barriers %.2f, grad_weight %.2f, grad_bias %.2f, dX gemm %.2f\n",
                    acc[10] / reps, acc[11] / reps, acc[12] / reps, acc[13] / reps);
     }
+    // ---- the one-launch policy step and the one-launch policy -> sample -> critics forward ----------------------------
+    {
+        float *act, *qout, *lsout, *aout, *lpout, *prob, *a2, *lp2, *eps5, *x5, *q5;
+        const int T = 5, N5 = N * T;
+        hipMalloc(&act, N * A * 4); hipMemset(act, 0, N * A * 4); hipMalloc(&qout, E * N * 4);
+        hipMalloc(&x5, N5 * 8 * 4); hipMemset(x5, 0, N5 * 8 * 4); hipMalloc(&eps5, N5 * A * 4); hipMemset(eps5, 0, N5 * A * 4);
+        hipMalloc(&lsout, N5 * 2 * A * 4); hipMalloc(&aout, N5 * A * 4); hipMalloc(&lpout, N5 * 4); hipMalloc(&prob, N5 * A * 4);
+        hipMalloc(&a2, N * A * 4); hipMalloc(&lp2, N * 4); hipMalloc(&q5, E * N5 * 4);
+        const int reps = 200;
+        double acc[16] = {0};
+        for (int r = 0; r < reps; ++r) {
+            asac_policy_step_fused(&dq, params, stride, &dp, params, stride, x0, S, N, act, eps, la, qout, grad, ws,
+                                   ASAC_MLP_REDUCE_DEFER, nullptr);
+            hipDeviceSynchronize();
+            unsigned long long st[32];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(asac::g_mlp_stamps), sizeof st);
+            for (int i = 1; i <= 13; ++i) acc[i] += (double)(st[i] - st[i - 1]) / 100.0;
+            acc[0] += (double)(st[13] - st[0]) / 100.0;
+        }
+        static const char* names[] = {"", "staging", "critics forward", "critic heads", "dq", "critics backward", "policy -> LDS",
+                                      "policy forward", "policy head", "sampling backward", "head grads + g", "reverse L3",
+                                      "reverse L2", "reverse L1"};
+        printf("policy_step_fused: workgroup 0 total %.2f us\n", acc[0] / reps);
+        for (int i = 1; i <= 13; ++i) printf("   %-18s %6.2f us\n", names[i], acc[i] / reps);
+        asac_pi_q_job_t job{};
+        job.pi.desc = &dp; job.pi.params = params; job.pi.member_stride = stride; job.pi.x0 = x5; job.pi.x0_row_stride = S;
+        job.pi.N = N5; job.pi.out = lsout; job.pi.E = 1;
+        job.q = job.pi; job.q.desc = &dq; job.q.E = E; job.q.out = q5;
+        job.sample.eps = eps5; job.sample.a_tanh_out = aout; job.sample.logp_out = lpout; job.sample.rows = N5; job.sample.A = A;
+        job.sample.T = T; job.sample.action = aout; job.sample.action_stride_b = T * A; job.sample.action_stride_t = A;
+        job.sample.prob_out = prob; job.sample.prob_stride_b = T * A; job.sample.prob_stride_t = A;
+        job.eps2 = eps; job.t2 = 0; job.a2_out = a2; job.logp2_out = lp2;
+        double acc2[10] = {0};
+        for (int r = 0; r < reps; ++r) {
+            asac_policy_sample_q_forward(&job, nullptr, 0, nullptr, 0, nullptr);
+            hipDeviceSynchronize();
+            unsigned long long st[32];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(asac::g_mlp_stamps), sizeof st);
+            for (int i = 1; i <= 7; ++i) acc2[i] += (double)(st[i] - st[i - 1]) / 100.0;
+            acc2[0] += (double)(st[7] - st[0]) / 100.0;
+        }
+        static const char* names2[] = {"", "staging", "policy forward", "policy head", "sampling", "actions -> tile",
+                                       "critic forward", "critic head"};
+        printf("policy_sample_q_forward: workgroup 0 total %.2f us\n", acc2[0] / reps);
+        for (int i = 1; i <= 7; ++i) printf("   %-18s %6.2f us\n", names2[i], acc2[i] / reps);
+    }
     return 0;
 }
