@@ -293,7 +293,7 @@ class PrioritizedReplayBuffer:
     # ------------------------------------------------------------------------------------------
     # priority / transition write-backs
     # ------------------------------------------------------------------------------------------
-    def _update_ids(self, ids: torch.Tensor, td: torch.Tensor, stale_check=True, mode=0) -> None:
+    def _update_ids(self, ids: torch.Tensor, td: torch.Tensor, stale_check=True, mode=0, sidecars=None) -> None:
         k = ids.numel()
         if k == 0:
             return
@@ -303,17 +303,19 @@ class PrioritizedReplayBuffer:
         for s in range(0, k, piece):
             native.sumtree_update(self._tree, self.capacity, ids[s:s + piece], self._slot_ids if stale_check else None,
                                   td[s:s + piece], self.alpha, self.td_error_min, self.td_error_max, mode,
-                                  self._winner, self._nan_flag)
+                                  self._winner, self._nan_flag, sidecars=sidecars if s == 0 else None)
 
-    def update(self, data_ids, td_error) -> None:
-        """priority <- clip(td, min, max)^alpha for ids still resident (replay_buffer.py:412-427)."""
+    def update(self, data_ids, td_error, sidecars=None) -> None:
+        """priority <- clip(td, min, max)^alpha for ids still resident (replay_buffer.py:412-427).  `sidecars`: small
+        jobs of the caller's step that ride as extra workgroups of the update launch (`native.Sidecar`)."""
         ids = data_ids if isinstance(data_ids, torch.Tensor) else self._to_device(np.asarray(data_ids, np.int64))
         td = td_error if isinstance(td_error, torch.Tensor) else self._to_device(np.asarray(td_error, np.float32))
         if self.sharded is not None and ids is self._ids:      # the step's batch: priorities go to the owning shards
+            assert not sidecars
             self.sharded.update(td.reshape(-1))
             return
         with torch.cuda.device(self.device):
-            self._update_ids(ids.reshape(-1), td.reshape(-1).contiguous(), stale_check=True)
+            self._update_ids(ids.reshape(-1), td.reshape(-1).contiguous(), stale_check=True, sidecars=sidecars)
 
     def update_transitions(self, data_ids, key: str, data) -> None:
         """Overwrite `key` rows for ids still resident (replay_buffer.py:429-434); later duplicates

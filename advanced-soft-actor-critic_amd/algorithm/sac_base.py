@@ -213,6 +213,8 @@ class SAC_Base(AuxHeadsMixin):
         self._use_sidecars = bool(hip_config.get('sidecars', True))
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
+        self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
+        self._vtrace_sidecars = self._pending_alpha = None
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
         assert self._dist_sampling in ('throughput', 'parity')
 
@@ -994,7 +996,11 @@ class SAC_Base(AuxHeadsMixin):
             if q_online is not None and not self.d_action_sizes:
                 self._join()     # q_online may come from the side stream
                 args.q_online, args.E_online, args.td_error_out = q_online.data_ptr(), q_online.shape[0], td_out.data_ptr()
-            native.vtrace_return_min(args)
+            sidecars = None
+            if q_online is not None and self._vtrace_sidecars:     # the TD error's launch hosts the pending write-backs
+                sidecars, self._vtrace_sidecars = self._vtrace_sidecars, None
+            native.vtrace_return_min(args, sidecars=sidecars,
+                                     pending_alpha=self._pending_alpha if q_online is not None else None)
             c_y = y_out.unsqueeze(-1)
         return d_y, c_y
 
@@ -1554,35 +1560,79 @@ class SAC_Base(AuxHeadsMixin):
         # asac_sidecar.h): the mu-probability write-back elects in the sampling launch and writes in the TD error's
         # forward launch, which also carries the temperature step
         sc_elect = sc_write = sc_alpha = None
+        side_cq = td_q_table = None
+        fused_b = False
+        self._vtrace_sidecars = self._pending_alpha = None
         if stock and self.use_n_step_is:
             with torch.no_grad():
                 B_, L_, A = *bnx_states.shape[:2], self.c_action_size
-                ls_win = self._fpi._launch_forward(StockMLP._rows(bnx_states, self.state_size), None)[0] \
-                    .view(B_, L_, 2 * A)
-                # ... and ONE elementwise launch on it: the temperature step's sample, pi(stored actions)
-                # over the window, the TD target's sample
                 f32 = dict(dtype=torch.float32, device=self.device)
-                probs_win = torch.empty((B_, L_, A), **f32)
-                jobs = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=bnx_actions, prob_out=probs_win)]
-                if auto_alpha:
-                    self.noise.normal_(self._eps_alpha)
-                    alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
-                    jobs.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, alpha_logp))
                 same_states = (b == 0 and bnx_target_states.data_ptr() == bnx_states.data_ptr()
                                and bnx_target_states.stride() == bnx_states.stride())
-                if self.use_priority and same_states:
-                    self.noise.normal_(self._eps_td)
+                rows_win = StockMLP._rows(bnx_states, self.state_size)
+                job_b = None
+                if (self._fused_td_chain and self.use_priority and same_states and self._use_sidecars
+                        and not self._parallel_branches and rb.sharded is None
+                        and self.curiosity is None and not self.use_rnd):
+                    # the UPDATED policy over the window -> [pi(stored actions) = the new mu, the TD target's sample,
+                    # the temperature step's sample at row b] -> target critics on the TD sample, with the TD error's
+                    # online Q of (s_b, a_b) riding along and the mu-probability write-back electing beside it: ONE launch
+                    # (bit-identical to the three it replaces).  The write-back's second pass rides in the TD error's
+                    # return launch; the temperature step (it needs every tile's sample) rides in the priority update,
+                    # the step's last launch, and the TD error's return, which must already see the new temperature,
+                    # evaluates the value that step will write (`pending_alpha`)
+                    job_pi, ls_out = self._fpi.job(rows_win, None)
+                    probs_win = torch.empty((B_, L_, A), **f32)
                     td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
-                    jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
-                if td_sample is not None and self._use_sidecars and not self._parallel_branches:
+                    job_tq, td_q_table = self._ftq.job(rows_win, td_sample[0].view(-1, A))
+                    if auto_alpha:
+                        alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
+                    job_b = native.pi_q_job(job_pi, job_tq, self._eps_td, td_sample[0], td_sample[1], L_,
+                                            action=bnx_actions, prob_out=probs_win,
+                                            eps2=self._eps_alpha if auto_alpha else None, t2=b,
+                                            a2_out=scratch if auto_alpha else None,
+                                            logp2_out=alpha_logp if auto_alpha else None)
+                    if not native.policy_sample_q_forward_ok(job_b):
+                        job_b = probs_win = td_sample = td_q_table = alpha_logp = None
+                if job_b is not None:
+                    if auto_alpha:
+                        self.noise.normal_(self._eps_alpha)
+                    self.noise.normal_(self._eps_td)
+                    xb = StockMLP._rows(bnx_states[:, b], self.state_size)
+                    ab = StockMLP._rows(bnx_actions[:, b], self.c_action_size)
+                    job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
                     sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
                     if auto_alpha:
                         sc_alpha = self._alpha_sidecar(alpha_logp)
-                native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
+                    native.policy_sample_q_forward(job_b, [job_q], sidecars=[sc_elect])
+                    self._pending_alpha = sc_alpha      # (None: data parallel / a wider optimizer -> `_train_alpha` below)
+                    ls_win = ls_out[0].view(B_, L_, 2 * A)
+                    td_q_table = td_q_table.view(self.ensemble_q_num, B_, L_)
+                    side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
+                    self._vtrace_sidecars = [sc_write]
+                    fused_b = True
+                else:
+                    ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
+                    # ... and ONE elementwise launch on it: the temperature step's sample, pi(stored actions)
+                    # over the window, the TD target's sample
+                    probs_win = torch.empty((B_, L_, A), **f32)
+                    jobs = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=bnx_actions, prob_out=probs_win)]
+                    if auto_alpha:
+                        self.noise.normal_(self._eps_alpha)
+                        alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
+                        jobs.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, alpha_logp))
+                    if self.use_priority and same_states:
+                        self.noise.normal_(self._eps_td)
+                        td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
+                        jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
+                    if td_sample is not None and self._use_sidecars and not self._parallel_branches:
+                        sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
+                        if auto_alpha:
+                            sc_alpha = self._alpha_sidecar(alpha_logp)
+                    native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
         # side stream from here to the end of the step: the TD error's online Q and the mu-probability
         # write-back (its own election scratch) beside the temperature step / TD target / tree update
-        side_cq = td_q_table = None
-        if probs_win is not None:
+        if probs_win is not None and not fused_b:
             with torch.no_grad(), self._fork():
                 if self.use_priority:
                     xb = StockMLP._rows(bnx_states[:, b], self.state_size)
@@ -1626,7 +1676,8 @@ class SAC_Base(AuxHeadsMixin):
                                     ls=ls_win if td_sample is not None else None, sample=td_sample,
                                     stored_pi=probs_win if td_sample is not None else None, c_q=side_cq,
                                     q_table=td_q_table)
-            rb.update(ids, td)
+            rb.update(ids, td, sidecars=[self._pending_alpha] if self._pending_alpha is not None else None)
+            self._pending_alpha = None
         if self.seq_hidden_state_shape[-1] != 0:
             rb.update_window_transitions(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
                                          next_hidden.detach().contiguous())

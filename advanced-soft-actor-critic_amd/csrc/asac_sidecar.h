@@ -82,6 +82,32 @@ __device__ __forceinline__ void alpha_adam_block(const AlphaAdamArgs& a, float* 
             adam1(a.param[i], i == a.slot ? g_slot : a.grad[i], a.exp_avg[i], a.exp_avg_sq[i], a.c, step_size, bc2_sqrt);
 }
 
+// The value the temperature parameter `slot` WILL have after alpha_adam_block(a), computed without writing anything:
+// a launch that must already see the updated temperature (the TD error's return, sac_base.py:2182-2245 after 1913-1949)
+// evaluates this per workgroup while the step itself rides as a sidecar of a LATER launch — nothing waits for a
+// one-workgroup kernel.  Same reduction order and arithmetic as alpha_adam_block: bit-identical.  Called by every thread
+// of a 256-thread workgroup.
+__device__ __forceinline__ float alpha_adam_preview(const AlphaAdamArgs& a, float* red /* LDS, 256 floats */) {
+    const int tid = threadIdx.x;
+    float part = 0.f;
+    for (int b = tid; b < a.B; b += 256) part += -a.logp[b] - a.target;
+    const int64_t done = *a.steps_done;
+    float p = a.param[a.slot], m = a.exp_avg[a.slot], v = a.exp_avg_sq[a.slot];
+    const double t = (double)(done + 1);
+    const float step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));      // (overlaps the loads above)
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
+    red[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float g_slot = red[0] / (float)a.B;
+    __syncthreads();                                    // (the caller reuses `red`)
+    adam1(p, g_slot, m, v, a.c, step_size, bc2_sqrt);
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K7: two passes over the [batch, count] targets.  Pass 1 elects, per ring slot, the LAST row (in
 // row-major order) that is unpadded and whose id still lives in the slot; pass 2 lets only the

@@ -100,18 +100,25 @@ __global__ __launch_bounds__(256) void k_squash_prob(const float* __restrict__ l
 // ------------------------------------------------------------------------------------------------
 struct VtraceDev {
     asac_vtrace_args_t a;
-    int32_t R, pitch, seg;
+    int32_t R, pitch, seg, blocks;
+    int32_t has_pending, pad_;       // the temperature step is still pending: use the value it will produce
+    AlphaAdamArgs pending;
 };
 
-__global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v) {
+__global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v, const SidecarsDev sc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= v.blocks) {           // sidecar workgroups (asac_sidecar.h)
+        sidecar_run(sc, (int)blockIdx.x - v.blocks, lds);
+        return;
+    }
     const asac_vtrace_args_t& a = v.a;
     const int n = a.n, R = v.R, pitch = v.pitch, SEG = v.seg;
     float* s_d = lds;                        // [R][pitch]  per-step term d_t
     float* s_c = s_d + R * pitch;            // [R][pitch]  trace-cutting factor c_t = min(pi/mu, c_bar)
     float* s_v0 = s_c + R * pitch;           // [R]         V(s_0)
     const int row0 = blockIdx.x * R;
-    const float alpha = a.q ? expf(*a.log_alpha) : 0.f;
+    float alpha = a.q ? expf(*a.log_alpha) : 0.f;
+    if (v.has_pending) alpha = expf(alpha_adam_preview(v.pending, lds));
 
     // phase 1 (all lanes, coalesced over (row, t), ONE round of global loads): everything of step t that
     // does not depend on the running product
@@ -382,11 +389,23 @@ int asac_squash_prob(const float* loc, const float* scale, int64_t ls_row_stride
 }
 
 int asac_vtrace_return_min(const asac_vtrace_args_t* args_host, void* stream) {
+    return asac_vtrace_return_min_sc(args_host, nullptr, 0, nullptr, stream);
+}
+
+int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_sidecar_t* sidecars_host, int n_sidecars,
+                              const asac_sidecar_t* pending_alpha, void* stream) {
     const asac_vtrace_args_t& h = *args_host;
+    SidecarsDev sc{}, none{}, pend{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_vtrace_return_min: sidecar");
+    if (pending_alpha) {
+        if (pending_alpha->kind != ASAC_SIDECAR_ALPHA_ADAM || sidecars_prepare(pending_alpha, 1, pend) ||
+            h.log_alpha != pending_alpha->param + pending_alpha->slot)
+            return bad_arg("asac_vtrace_return_min: pending temperature step");
+    }
     if (h.B <= 0 || h.n <= 0 || !h.y_out || !h.q || h.E_sample <= 0 || h.E_sample > ASAC_MAX_ENSEMBLE)
         return bad_arg("asac_vtrace_return_min");
     if (h.use_n_step_is && (!h.mu_prob || !h.pi_prob || h.A <= 0)) return bad_arg("asac_vtrace_return_min: is");
-    VtraceDev v;
+    VtraceDev v{};
     v.a = h;
     v.pitch = (h.n + 1) | 1;                      // odd pitch: conflict-free row-per-lane reads
     // Rows per workgroup.  A lane's items in phase 1 are sequential global round trips, so small batches
@@ -401,10 +420,18 @@ int asac_vtrace_return_min(const asac_vtrace_args_t* args_host, void* stream) {
     while (R > 1 && (size_t)(2 * R * v.pitch + R) * sizeof(float) > 64 * 1024) R >>= 1;
     v.R = R;
     v.seg = huge ? 1 : 4;
-    const size_t lds = (size_t)(2 * R * v.pitch + R) * sizeof(float);
+    size_t lds = (size_t)(2 * R * v.pitch + R) * sizeof(float);
     if (lds > 64 * 1024) return bad_arg("asac_vtrace_return_min: n too large");
+    if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);        // (a sidecar workgroup's reduction scratch)
     const int blocks = (h.B + R - 1) / R;
-    ASAC_LAUNCH(k_vtrace_return_min, dim3(blocks), dim3(256), lds, as_stream(stream), v);
+    v.blocks = blocks;
+    v.has_pending = pending_alpha ? 1 : 0;
+    if (pending_alpha) v.pending = pend.j[0].alpha;
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
+        const bool last = rep == g_launch_repeat - 1;
+        hipLaunchKernelGGL(k_vtrace_return_min, dim3((unsigned)(blocks + (last ? sc.blocks : 0))), dim3(256), lds,
+                           as_stream(stream), v, last ? sc : none);
+    }
     return finish_launch("asac_vtrace_return_min");
 }
 
@@ -414,7 +441,7 @@ int asac_vtrace_return_direct(const asac_vtrace_args_t* args_host, const float* 
     const asac_vtrace_args_t& h = *args_host;
     if (h.B <= 0 || h.n <= 0 || !h.y_out || !v_n || !v_next) return bad_arg("asac_vtrace_return_direct");
     if (h.use_n_step_is && (!pi_prod || !mu_prod)) return bad_arg("asac_vtrace_return_direct: is");
-    VtraceDev v;
+    VtraceDev v{};
     v.a = h;
     v.R = v.pitch = v.seg = 0;
     ASAC_LAUNCH(k_vtrace_direct, dim3((h.B + 255) / 256), dim3(256), 0, as_stream(stream), v,

@@ -7,6 +7,7 @@
 // workgroup for the descent.
 #include "asac_common.h"
 #include "asac_noise.h"
+#include "asac_sidecar.h"
 
 #include <cmath>
 #include <cstdio>
@@ -270,7 +271,12 @@ __device__ __forceinline__ void propagate_chunks(float* tree, int levels, int k,
 __global__ __launch_bounds__(kUpdateBlock) void k_sumtree_update(
     float* tree, int capacity, int levels, int k, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_ids, const float* __restrict__ td, float alpha, float td_min,
-    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch) {
+    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch, const SidecarsDev sc) {
+    if (blockIdx.x > 0) {                        // sidecar workgroups (asac_sidecar.h)
+        __shared__ float sc_red[256];
+        sidecar_run(sc, (int)blockIdx.x - 1, sc_red);
+        return;
+    }
     // pass 0: NaN screen (the reference raises before touching the tree)
     int bad = 0;
     for (int i = threadIdx.x; i < k; i += blockDim.x) bad |= (td[i] != td[i]);
@@ -493,16 +499,29 @@ int asac_per_is_weights(const float* p, int batch, const float* total, const flo
 int asac_sumtree_update(float* tree, int capacity, int k, const int64_t* ids,
                         const int64_t* slot_ids, const float* td_error, float alpha, float td_min,
                         float td_max, int mode, int32_t* winner, int32_t* nan_flag, void* stream) {
+    return asac_sumtree_update_sc(tree, capacity, k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner, nan_flag,
+                                  nullptr, 0, stream);
+}
+
+int asac_sumtree_update_sc(float* tree, int capacity, int k, const int64_t* ids,
+                           const int64_t* slot_ids, const float* td_error, float alpha, float td_min,
+                           float td_max, int mode, int32_t* winner, int32_t* nan_flag,
+                           const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream) {
     if (capacity <= 0 || (capacity & (capacity - 1)) || k <= 0 || !winner || !nan_flag)
         return bad_arg("asac_sumtree_update");
+    SidecarsDev sc{}, none{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_sumtree_update: sidecar");
     // items beyond the first kUpdateBlock keep their (leaf, p) in the tail of the winner scratch?
     // No: winner is [C] and must stay -1.  They are spilled behind it by contract: callers with
     // k > 1024 must provide winner of size C + 2k.
     const int threads = k <= 256 ? 256 : kUpdateBlock;
     int32_t* item_scratch = winner + capacity;
-    ASAC_LAUNCH(k_sumtree_update, dim3(1), dim3(threads), 0, as_stream(stream), tree, capacity,
-                       ilog2(capacity), k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner,
-                       nan_flag, item_scratch);
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
+        const bool last = rep == g_launch_repeat - 1;
+        hipLaunchKernelGGL(k_sumtree_update, dim3(1u + (unsigned)(last ? sc.blocks : 0)), dim3(threads), 0, as_stream(stream),
+                           tree, capacity, ilog2(capacity), k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner,
+                           nan_flag, item_scratch, last ? sc : none);
+    }
     return finish_launch("asac_sumtree_update");
 }
 

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 40
+ABI_VERSION = 42
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -163,6 +163,11 @@ _SIGNATURES = {
                                    C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                    C.c_void_p]),
     'asac_vtrace_return_min': (C.c_int, [C.POINTER(VtraceArgs), C.c_void_p]),
+    'asac_vtrace_return_min_sc': (C.c_int, [C.POINTER(VtraceArgs), C.POINTER(Sidecar), C.c_int, C.POINTER(Sidecar),
+                                            C.c_void_p]),
+    'asac_sumtree_update_sc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                         C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Sidecar), C.c_int,
+                                         C.c_void_p]),
     'asac_vtrace_return_direct': (C.c_int, [C.POINTER(VtraceArgs), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
     'asac_q_loss_fwd_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -403,12 +408,13 @@ def per_is_weights(p, batch, total, min_ratio, beta_state, beta_increment, w_out
 
 
 @_profiled
-def sumtree_update(tree, capacity, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner, nan_flag):
+def sumtree_update(tree, capacity, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner, nan_flag, sidecars=None):
     k = ids.numel()
     assert ids.dtype == torch.int64 and td_error.dtype == torch.float32 and td_error.numel() == k
     assert winner.dtype == torch.int32 and winner.numel() >= capacity + (2 * k if k > 1024 else 0)
-    _check(load().asac_sumtree_update(_p(tree), capacity, k, _p(ids), _p(slot_ids), _p(td_error),
-                                      alpha, td_min, td_max, mode, _p(winner), _p(nan_flag), _stream()),
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_sumtree_update_sc(_p(tree), capacity, k, _p(ids), _p(slot_ids), _p(td_error),
+                                         alpha, td_min, td_max, mode, _p(winner), _p(nan_flag), sc, n_sc, _stream()),
            'asac_sumtree_update')
 
 
@@ -618,8 +624,13 @@ def squash_prob(loc, scale, action, action_offset, prob_out, prob_offset):
 
 
 @_profiled
-def vtrace_return_min(args: VtraceArgs):
-    _check(load().asac_vtrace_return_min(C.byref(args), _stream()), 'asac_vtrace_return_min')
+def vtrace_return_min(args: VtraceArgs, sidecars=None, pending_alpha: 'Sidecar | None' = None):
+    """`pending_alpha`: the temperature step's sidecar job when it has not run yet (it rides in a LATER launch): the
+    return is evaluated with the temperature that job will write"""
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_vtrace_return_min_sc(C.byref(args), sc, n_sc,
+                                            C.byref(pending_alpha) if pending_alpha is not None else None, _stream()),
+           'asac_vtrace_return_min')
 
 
 @_profiled

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 40
+#define ASAC_ABI_VERSION 42
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -349,6 +349,17 @@ typedef struct {
  * through LDS with coalesced loads.  Replaces sac_base.py:1434-1445 + 1450-1464 + _v_trace
  * (1244-1295). */
 int asac_vtrace_return_min(const asac_vtrace_args_t* args_host, void* stream);
+/* ... with sidecar jobs riding as extra workgroups of the launch (e.g. the write pass of the behaviour-probability
+ * write-back beside the TD error's return) */
+/* pending_alpha (optional): an ASAC_SIDECAR_ALPHA_ADAM job that has NOT run yet but precedes this return in the
+ * reference's order (the TD error sees the updated temperature): the launch uses the value that job will write
+ * (args.log_alpha must be its parameter slot); the job itself rides in a later launch (asac_sumtree_update_sc). */
+int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_sidecar_t* sidecars_host,
+                              int n_sidecars, const asac_sidecar_t* pending_alpha, void* stream);
+/* asac_sumtree_update (declared above) with sidecar jobs riding as extra workgroups */
+int asac_sumtree_update_sc(float* tree, int capacity, int k, const int64_t* ids, const int64_t* slot_ids,
+                           const float* td_error, float alpha, float td_min, float td_max, int mode, int32_t* winner,
+                           int32_t* nan_flag, const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream);
 
 /* Same scan with V(s_t), V(s_t+1) [B, n] and the pi / mu products [B, n] handed in directly (the
  * discrete-action branch computes its V from categorical probabilities, sac_base.py:1387-1421;

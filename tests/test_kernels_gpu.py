@@ -341,6 +341,61 @@ def test_get_y_pipeline_vs_golden(nat, golden_dir, tag):
     np.testing.assert_allclose(y.cpu().numpy()[:, None], g[f'{tag}_y'], rtol=2e-5, atol=2e-5)
 
 
+def test_return_with_the_pending_temperature_step(nat, golden_dir):
+    """The TD error's return must see the temperature AFTER the step's temperature update.  One-launch steps defer
+    that update to the priority update's launch (a sidecar) and give the return launch the pending job instead:
+    return(pending) + tree update(sidecar) == temperature step, then return, then tree update — bit for bit."""
+    g = np.load(golden_dir / 'f4_get_y.npz')
+    tag = 'n4_e2'
+    n, E, Es, A, use_is = (int(x) for x in g[f'{tag}_cfg'])
+    loc, scale, eps = dev(g[f'{tag}_loc']), dev(g[f'{tag}_scale']), dev(g[f'{tag}_eps'])
+    B = loc.shape[0]
+    a_tanh, logp, pi = torch.zeros_like(loc), torch.zeros(B, n + 1, device='cuda'), torch.zeros(B, n + 1, A, device='cuda')
+    actions = torch.zeros(B, n + 1, A, device='cuda')
+    actions[:, :n] = dev(g[f'{tag}_n_actions'])
+    nat.squash_sample_fwd(loc, scale, eps, a_tanh, logp, None, actions, 0, pi, 0)
+    q = dev(g[f'{tag}_q']).squeeze(-1).contiguous()
+    perm = g[f'{tag}_perm']
+    sub_n, sub_next = dev(perm[0][:Es], torch.int32), dev(perm[1][:Es], torch.int32)
+    gr, lr = torch.logspace(0, n - 1, n, 0.99).cuda(), torch.logspace(0, n - 1, n, 1.0).cuda()
+    q_on = torch.randn(E, B, device='cuda')
+    C = 1024
+    rng = np.random.default_rng(1)
+    assert B <= C
+    ids = dev(rng.permutation(C)[:B].astype(np.int64))
+    la0 = float(np.asarray(g[f'{tag}_log_alpha']).reshape(-1)[0])
+    alpha_logp = dev(rng.standard_normal(B).astype(np.float32) * 2)
+
+    def run(deferred):
+        seg = torch.tensor([0.3, la0], device='cuda')      # [log_d_alpha, log_c_alpha]
+        state = [torch.zeros(2, device='cuda'), torch.full((2,), 0.01, device='cuda'), torch.full((2,), 1e-3, device='cuda')]
+        steps = torch.tensor(7, dtype=torch.int64, device='cuda')
+        tree, slot_ids = torch.zeros(2 * C - 1, device='cuda'), torch.arange(C, dtype=torch.int64, device='cuda')
+        winner, nan_flag = torch.full((C + 2 * 4096,), -1, dtype=torch.int32, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+        y, td = torch.zeros(B, device='cuda'), torch.zeros(B, device='cuda')
+        a = _vtrace_args(nat, q=q, logp=logp, log_alpha=seg[1:], reward=dev(g[f'{tag}_n_rewards']),
+                         done=dev(g[f'{tag}_n_dones']), last=dev(g[f'{tag}_n_last_masks']),
+                         pad=dev(g[f'{tag}_n_padding_masks']), mu=dev(g[f'{tag}_n_mu_probs']), pi=pi, A=A,
+                         gamma_ratio=gr, lambda_ratio=lr, gamma=0.99, rho=1.0, c=1.0, use_is=bool(use_is), y=y,
+                         subset_n=sub_n, subset_next=sub_next, E_sample=Es)
+        a.q_online, a.E_online, a.td_error_out = q_on.data_ptr(), E, td.data_ptr()
+        job = nat.sidecar_alpha_adam(alpha_logp, -float(A), 1, seg, *state, 3e-4, 0.9, 0.999, 1e-8, steps, advance_counter=True)
+        if deferred:
+            nat.vtrace_return_min(a, pending_alpha=job)
+            assert float(seg[1]) == float(np.float32(la0)), 'the return launch only previews the step'
+            nat.sumtree_update(tree, C, ids, slot_ids, td, 0.9, 0.01, 1.0, 0, winner, nan_flag, sidecars=[job])
+        else:
+            nat.alpha_adam_step(alpha_logp, -float(A), 1, seg, *state, 3e-4, 0.9, 0.999, 1e-8, steps, advance_counter=True)
+            nat.vtrace_return_min(a)
+            nat.sumtree_update(tree, C, ids, slot_ids, td, 0.9, 0.01, 1.0, 0, winner, nan_flag)
+        return [y, td, seg, *state, steps, tree]
+
+    want, got = run(False), run(True)
+    assert float(want[2][1]) != float(np.float32(la0))
+    for name, w_, g_ in zip(('y', 'td', 'temperatures', 'grad', 'exp_avg', 'exp_avg_sq', 'steps', 'tree'), want, got):
+        assert torch.equal(w_, g_), name
+
+
 def test_squash_sample_backward_vs_autograd(nat):
     torch.manual_seed(0)
     B, A = 257, 3
