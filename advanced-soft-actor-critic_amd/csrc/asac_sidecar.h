@@ -168,10 +168,23 @@ struct SidecarDev {
     AlphaAdamArgs alpha;
     ScatterArgs scatter;
 };
-struct SidecarsDev {
-    SidecarDev j[ASAC_MAX_SIDECARS];
+// (kernel arguments are copied per launch: hosts that usually carry no or one sidecar have variants taking a shorter
+// list — SidecarsT<1> is 250 bytes, the full list 1 KB)
+template <int NSC>
+struct SidecarsT {
+    SidecarDev j[NSC];
     int32_t n, blocks;                // jobs, sidecar workgroups in all
 };
+using SidecarsDev = SidecarsT<ASAC_MAX_SIDECARS>;
+
+template <int NSC>
+inline SidecarsT<NSC> sidecars_first(const SidecarsDev& full) {
+    SidecarsT<NSC> out{};
+    for (int k = 0; k < NSC && k < full.n; ++k) out.j[k] = full.j[k];
+    out.n = full.n < NSC ? full.n : NSC;
+    out.blocks = full.blocks;
+    return out;
+}
 
 constexpr int kSidecarRowsPerWg = 256;        // SCATTER_ELECT, and SCATTER_WRITE of short rows: one lane per row
 inline int scatter_write_rows_per_wg(int row_bytes) { return row_bytes <= 32 ? kSidecarRowsPerWg : 4; }
@@ -209,10 +222,11 @@ inline int sidecars_prepare(const asac_sidecar_t* jobs, int n, SidecarsDev& out)
 }
 
 // device: workgroup `block` (0-based among the sidecar workgroups) of a host kernel with >= 256 threads
-__device__ __forceinline__ void sidecar_run(const SidecarsDev& sc, int block, float* lds256) {
+template <int NSC>
+__device__ __forceinline__ void sidecar_run(const SidecarsT<NSC>& sc, int block, float* lds256) {
     int k = 0;
 #pragma unroll
-    for (int q = 1; q < ASAC_MAX_SIDECARS; ++q)
+    for (int q = 1; q < NSC; ++q)
         if (q < sc.n && block >= sc.j[q].first_block) k = q;
     const SidecarDev& job = sc.j[k];
     const int local = block - job.first_block;

@@ -1618,7 +1618,8 @@ struct PiQLaunch {
 
 static_assert(sizeof(PiQLaunch) + sizeof(SidecarsDev) <= 4096, "kernel arguments of k_pi_sample_q");
 
-__global__ __launch_bounds__(256) void k_pi_sample_q(const PiQLaunch m, const SidecarsDev sc) {
+template <int NSC>
+__global__ __launch_bounds__(256) void k_pi_sample_q(const PiQLaunch m, const SidecarsT<NSC> sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int blk = (int)blockIdx.x;
     if (blk < m.f.blocks) {
@@ -2128,14 +2129,23 @@ int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_
     }
     x.blocks = blocks;
     static bool attr_done = false;
-    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_pi_sample_q), sizeof(PiQLds), attr_done,
+    static bool attr_done1 = false;
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_pi_sample_q<ASAC_MAX_SIDECARS>), sizeof(PiQLds), attr_done,
+                               "asac_policy_sample_q_forward: hipFuncSetAttribute"))
+        return rc;
+    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_pi_sample_q<1>), sizeof(PiQLds), attr_done1,
                                "asac_policy_sample_q_forward: hipFuncSetAttribute"))
         return rc;
     const SidecarsDev none{};
     for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
         const bool last = rep == g_launch_repeat - 1;
-        hipLaunchKernelGGL(k_pi_sample_q, dim3((unsigned)(f.blocks + blocks + (last ? sc.blocks : 0))), dim3(256),
-                           sizeof(PiQLds), as_stream(stream), m, last ? sc : none);
+        const dim3 grid((unsigned)(f.blocks + blocks + (last ? sc.blocks : 0)));
+        if (sc.n <= 1)
+            hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(256), sizeof(PiQLds), as_stream(stream), m,
+                               sidecars_first<1>(last ? sc : none));
+        else
+            hipLaunchKernelGGL(k_pi_sample_q<ASAC_MAX_SIDECARS>, grid, dim3(256), sizeof(PiQLds), as_stream(stream), m,
+                               last ? sc : none);
     }
     return finish_launch("asac_policy_sample_q_forward");
 }

@@ -101,16 +101,15 @@ __global__ __launch_bounds__(256) void k_squash_prob(const float* __restrict__ l
 struct VtraceDev {
     asac_vtrace_args_t a;
     int32_t R, pitch, seg, blocks;
+};
+template <int NSC>
+struct VtraceExtra {                 // what the launches with sidecars / a pending temperature step carry on top
+    SidecarsT<NSC> sc;
     int32_t has_pending, pad_;       // the temperature step is still pending: use the value it will produce
     AlphaAdamArgs pending;
 };
 
-__global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v, const SidecarsDev sc) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x >= v.blocks) {           // sidecar workgroups (asac_sidecar.h)
-        sidecar_run(sc, (int)blockIdx.x - v.blocks, lds);
-        return;
-    }
+__device__ __forceinline__ void vtrace_return_min_wg(const VtraceDev& v, float* lds, const AlphaAdamArgs* pending) {
     const asac_vtrace_args_t& a = v.a;
     const int n = a.n, R = v.R, pitch = v.pitch, SEG = v.seg;
     float* s_d = lds;                        // [R][pitch]  per-step term d_t
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v, co
     float* s_v0 = s_c + R * pitch;           // [R]         V(s_0)
     const int row0 = blockIdx.x * R;
     float alpha = a.q ? expf(*a.log_alpha) : 0.f;
-    if (v.has_pending) alpha = expf(alpha_adam_preview(v.pending, lds));
+    if (pending) alpha = expf(alpha_adam_preview(*pending, lds));
 
     // phase 1 (all lanes, coalesced over (row, t), ONE round of global loads): everything of step t that
     // does not depend on the running product
@@ -166,6 +165,21 @@ __global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v, co
         for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * a.B + b] - y);
         a.td_error_out[b] = s / (float)a.E_online;
     }
+}
+
+__global__ __launch_bounds__(256) void k_vtrace_return_min(const VtraceDev v) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    vtrace_return_min_wg(v, lds, nullptr);
+}
+
+template <int NSC>
+__global__ __launch_bounds__(256) void k_vtrace_return_min_sc(const VtraceDev v, const VtraceExtra<NSC> x) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= v.blocks) {           // sidecar workgroups (asac_sidecar.h)
+        sidecar_run(x.sc, (int)blockIdx.x - v.blocks, lds);
+        return;
+    }
+    vtrace_return_min_wg(v, lds, x.has_pending ? &x.pending : nullptr);
 }
 
 // precomputed-V variant of phase 1a (discrete / hybrid branches hand V in directly)
@@ -425,12 +439,20 @@ int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_si
     if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);        // (a sidecar workgroup's reduction scratch)
     const int blocks = (h.B + R - 1) / R;
     v.blocks = blocks;
-    v.has_pending = pending_alpha ? 1 : 0;
-    if (pending_alpha) v.pending = pend.j[0].alpha;
+    if (sc.n == 0 && !pending_alpha) {
+        ASAC_LAUNCH(k_vtrace_return_min, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), v);
+        return finish_launch("asac_vtrace_return_min");
+    }
     for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
         const bool last = rep == g_launch_repeat - 1;
-        hipLaunchKernelGGL(k_vtrace_return_min, dim3((unsigned)(blocks + (last ? sc.blocks : 0))), dim3(256), lds,
-                           as_stream(stream), v, last ? sc : none);
+        const unsigned grid = (unsigned)(blocks + (last ? sc.blocks : 0));
+        if (sc.n <= 1) {
+            VtraceExtra<1> x{sidecars_first<1>(last ? sc : none), pending_alpha ? 1 : 0, 0, pend.j[0].alpha};
+            hipLaunchKernelGGL(k_vtrace_return_min_sc<1>, dim3(grid), dim3(256), lds, as_stream(stream), v, x);
+        } else {
+            VtraceExtra<ASAC_MAX_SIDECARS> x{last ? sc : none, pending_alpha ? 1 : 0, 0, pend.j[0].alpha};
+            hipLaunchKernelGGL(k_vtrace_return_min_sc<ASAC_MAX_SIDECARS>, dim3(grid), dim3(256), lds, as_stream(stream), v, x);
+        }
     }
     return finish_launch("asac_vtrace_return_min");
 }

@@ -250,6 +250,46 @@ __global__ __launch_bounds__(256) void k_ratio_partials(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 constexpr int kUpdateBlock = 1024;
 
+// Three levels per round trip: once the nodes `s` levels above the leaves are final, the item's ancestor A three
+// levels further up has its eight descendants of that level contiguous in the heap — one round of loads, seven adds
+// (each parent = left + right of the values just formed: the very sums the level-by-level walk stores), and the three
+// ancestors on the item's own path are written.  Nodes beside the path are recomputed in registers only: they equal
+// what the tree holds (untouched: tree[i] == tree[2i+1] + tree[2i+2] is the tree's invariant) or what the item that
+// owns them writes (same operands).  19 levels: 7 rounds of [loads -> barrier] instead of 19.
+__device__ __forceinline__ float pick4(const float (&v)[4], int i) {
+    return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3];
+}
+
+// every thread of the workgroup calls this (leaf1 = leaf index + 1, 0 = nothing to do); the leaves are final
+__device__ __forceinline__ void propagate_leaf(float* tree, int levels, int leaf1) {
+    {
+        int s = 0;
+        for (; s + 3 <= levels; s += 3) {
+            if (leaf1) {
+                const int top1 = leaf1 >> (s + 3);             // 1-based index of A
+                const float* d = tree + (top1 << 3) - 1;       // its descendants three levels down
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = d[j];
+                const int me = (leaf1 >> s) & 7;
+                const float p1[4] = {v[0] + v[1], v[2] + v[3], v[4] + v[5], v[6] + v[7]};
+                const float p2[2] = {p1[0] + p1[1], p1[2] + p1[3]};
+                tree[(top1 << 2) - 1 + (me >> 1)] = pick4(p1, me >> 1);
+                tree[(top1 << 1) - 1 + (me >> 2)] = (me >> 2) ? p2[1] : p2[0];
+                tree[top1 - 1] = p2[0] + p2[1];
+            }
+            __syncthreads();
+        }
+        for (; s < levels; ++s) {
+            if (leaf1) {
+                const int node = (leaf1 >> (s + 1)) - 1;
+                tree[node] = tree[2 * node + 1] + tree[2 * node + 2];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __device__ __forceinline__ void propagate_chunks(float* tree, int levels, int k,
                                                  const int* __restrict__ leaf1_of_item,
                                                  int own_leaf1_first) {
@@ -258,25 +298,14 @@ __device__ __forceinline__ void propagate_chunks(float* tree, int levels, int k,
         const int i = base + threadIdx.x;
         int leaf1 = 0;
         if (i < k) leaf1 = (base == 0) ? own_leaf1_first : leaf1_of_item[i];
-        for (int s = 1; s <= levels; ++s) {
-            if (leaf1) {
-                const int node = (leaf1 >> s) - 1;
-                tree[node] = tree[2 * node + 1] + tree[2 * node + 2];
-            }
-            __syncthreads();
-        }
+        propagate_leaf(tree, levels, leaf1);
     }
 }
 
-__global__ __launch_bounds__(kUpdateBlock) void k_sumtree_update(
+__device__ __forceinline__ void sumtree_update_wg(
     float* tree, int capacity, int levels, int k, const int64_t* __restrict__ ids,
     const int64_t* __restrict__ slot_ids, const float* __restrict__ td, float alpha, float td_min,
-    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch, const SidecarsDev sc) {
-    if (blockIdx.x > 0) {                        // sidecar workgroups (asac_sidecar.h)
-        __shared__ float sc_red[256];
-        sidecar_run(sc, (int)blockIdx.x - 1, sc_red);
-        return;
-    }
+    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch) {
     // pass 0: NaN screen (the reference raises before touching the tree)
     int bad = 0;
     for (int i = threadIdx.x; i < k; i += blockDim.x) bad |= (td[i] != td[i]);
@@ -321,6 +350,27 @@ __global__ __launch_bounds__(kUpdateBlock) void k_sumtree_update(
     propagate_chunks(tree, levels, k, item_scratch, own_leaf1);
 }
 
+__global__ __launch_bounds__(kUpdateBlock) void k_sumtree_update(
+    float* tree, int capacity, int levels, int k, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_ids, const float* __restrict__ td, float alpha, float td_min,
+    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch) {
+    sumtree_update_wg(tree, capacity, levels, k, ids, slot_ids, td, alpha, td_min, td_max, mode, winner, nan_flag, item_scratch);
+}
+
+// ... with sidecar jobs (asac_sidecar.h) as workgroups 1.. of the launch
+template <int NSC>
+__global__ __launch_bounds__(kUpdateBlock) void k_sumtree_update_sc(
+    float* tree, int capacity, int levels, int k, const int64_t* __restrict__ ids,
+    const int64_t* __restrict__ slot_ids, const float* __restrict__ td, float alpha, float td_min,
+    float td_max, int mode, int32_t* winner, int32_t* nan_flag, int32_t* item_scratch, const SidecarsT<NSC> sc) {
+    if (blockIdx.x > 0) {
+        __shared__ float sc_red[256];
+        sidecar_run(sc, (int)blockIdx.x - 1, sc_red);
+        return;
+    }
+    sumtree_update_wg(tree, capacity, levels, k, ids, slot_ids, td, alpha, td_min, td_max, mode, winner, nan_flag, item_scratch);
+}
+
 __global__ __launch_bounds__(kUpdateBlock) void k_per_add(
     float* tree, int capacity, int levels, int64_t first_id, int count, int ignore_size,
     const float* max_p_dev, float max_p_host, int64_t* slot_ids) {
@@ -341,13 +391,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_per_add(
         const int j = base + threadIdx.x;
         int leaf1 = 0;
         if (j < count) leaf1 = (int)(((first_id + j) % max_id) % capacity) + capacity;
-        for (int s = 1; s <= levels; ++s) {
-            if (leaf1) {
-                const int node = (leaf1 >> s) - 1;
-                tree[node] = tree[2 * node + 1] + tree[2 * node + 2];
-            }
-            __syncthreads();
-        }
+        propagate_leaf(tree, levels, leaf1);
     }
 }
 
@@ -516,11 +560,22 @@ int asac_sumtree_update_sc(float* tree, int capacity, int k, const int64_t* ids,
     // k > 1024 must provide winner of size C + 2k.
     const int threads = k <= 256 ? 256 : kUpdateBlock;
     int32_t* item_scratch = winner + capacity;
+    if (sc.n == 0) {
+        ASAC_LAUNCH(k_sumtree_update, dim3(1), dim3(threads), 0, as_stream(stream), tree, capacity, ilog2(capacity), k,
+                    ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner, nan_flag, item_scratch);
+        return finish_launch("asac_sumtree_update");
+    }
     for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
         const bool last = rep == g_launch_repeat - 1;
-        hipLaunchKernelGGL(k_sumtree_update, dim3(1u + (unsigned)(last ? sc.blocks : 0)), dim3(threads), 0, as_stream(stream),
-                           tree, capacity, ilog2(capacity), k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner,
-                           nan_flag, item_scratch, last ? sc : none);
+        const dim3 grid(1u + (unsigned)(last ? sc.blocks : 0));
+        if (sc.n == 1)
+            hipLaunchKernelGGL(k_sumtree_update_sc<1>, grid, dim3(threads), 0, as_stream(stream), tree, capacity,
+                               ilog2(capacity), k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner, nan_flag,
+                               item_scratch, sidecars_first<1>(last ? sc : none));
+        else
+            hipLaunchKernelGGL(k_sumtree_update_sc<ASAC_MAX_SIDECARS>, grid, dim3(threads), 0, as_stream(stream), tree,
+                               capacity, ilog2(capacity), k, ids, slot_ids, td_error, alpha, td_min, td_max, mode, winner,
+                               nan_flag, item_scratch, last ? sc : none);
     }
     return finish_launch("asac_sumtree_update");
 }
