@@ -749,7 +749,8 @@ def policy_sample_q_forward_ok(job: PiQJob) -> bool:
 @_profiled
 def policy_sample_q_forward(job: PiQJob, extra_jobs=(), sidecars=None):
     global _last_work
-    _last_work = (mlp_flops(job.pi.desc.contents, job.q.E, job.pi.N) + mlp_flops(job.q.desc.contents, job.q.E, job.q.N)
+    # algorithmic work: the policy once (the E workgroups of a tile repeat it side by side), every critic once
+    _last_work = (mlp_flops(job.pi.desc.contents, 1, job.pi.N) + mlp_flops(job.q.desc.contents, job.q.E, job.q.N)
                   + sum(mlp_flops(j.desc.contents, j.E, j.N) for j in extra_jobs))
     extra_jobs = list(extra_jobs)
     assert len(extra_jobs) <= MLP_MAX_JOBS

@@ -91,7 +91,8 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_attention_proj_forward': 'asac::k_attn_proj_fwd', 'asac_attention_proj_backward': 'asac::k_attn_proj_bwd',
               'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd',
               'asac_adam_step_partials': 'asac::k_adam_partials', 'asac_adam_step': 'asac::k_adam',
-              'asac_step_prologue': 'asac::k_noise_fill'}
+              'asac_step_prologue': 'asac::k_noise_fill', 'asac_policy_sample_q_forward': 'asac::k_pi_sample_q',
+              'asac_policy_step_fused': 'asac::k_policy_step', 'asac_rows_move': 'asac::k_rows_move'}
 SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min')
 ROUND = 'r02'
 
@@ -105,7 +106,8 @@ def pmc_traffic(config: str, kernel: str):
         if not path.exists():
             continue
         recs = [v for k, v in json.loads(path.read_text()).items()
-                if (k == kernel or k.startswith(kernel + '<')) and v.get('fetch_bytes_corrected') is not None]
+                if (k == kernel or k.startswith(kernel + '<') or k.startswith(kernel + '_sc<'))     # (_sc: with sidecars)
+                and v.get('fetch_bytes_corrected') is not None]
         if not recs:
             continue
         calls = sum(r.get('launches', 1) for r in recs) or 1
