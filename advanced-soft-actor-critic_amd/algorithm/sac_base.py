@@ -982,7 +982,8 @@ class SAC_Base(AuxHeadsMixin):
             args = self._vtrace_args(n_rewards, n_dones, n_last_masks, n_padding_masks, y_out)
             args.q = q_tab.data_ptr()
             args.q_stride_e, args.q_stride_b, args.q_stride_t = q_tab.stride(0), q_tab.stride(1), q_tab.stride(2)
-            args.subset_n, args.subset_next, args.E_sample = sub_n.data_ptr(), sub_next.data_ptr(), Es
+            # (the whole ensemble: the minimum does not depend on the order, no index loads in front of the values)
+            args.subset_n, args.subset_next, args.E_sample = (sub_n.data_ptr(), sub_next.data_ptr(), Es) if Es != E else (None, None, Es)
             logp = logp.contiguous()
             args.logp, args.log_alpha = logp.data_ptr(), self.log_c_alpha.data_ptr()
             if self.use_n_step_is:

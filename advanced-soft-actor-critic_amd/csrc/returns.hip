@@ -116,20 +116,25 @@ __device__ __forceinline__ void vtrace_return_min_wg(const VtraceDev& v, float* 
     float* s_c = s_d + R * pitch;            // [R][pitch]  trace-cutting factor c_t = min(pi/mu, c_bar)
     float* s_v0 = s_c + R * pitch;           // [R]         V(s_0)
     const int row0 = blockIdx.x * R;
-    float alpha = a.q ? expf(*a.log_alpha) : 0.f;
-    if (pending) alpha = expf(alpha_adam_preview(*pending, lds));
-
     // phase 1 (all lanes, coalesced over (row, t), ONE round of global loads): everything of step t that
     // does not depend on the running product
     //   V(s_t)   = min_{e in subset_n}    Q_e(s_t, a_t)     - alpha logpi_t
     //   V(s_t+1) = min_{e in subset_next} Q_e(s_t+1, a_t+1) - alpha logpi_t+1
     //   d_t = rho_t * lambda^t * gamma^t * (r_t + gamma (1 - done_t) V(s_t+1) - V(s_t)) * ~(last | pad)
+    // The first item's loads are issued before the temperature is worked out (a pending temperature step costs a
+    // reduction and two f64 powers: they run while the loads travel).
+    const int f0 = threadIdx.x;
+    const bool have0 = f0 < R * n && row0 + f0 / n < a.B;
+    VtraceStepRaw raw0{};
+    if (have0) raw0 = vtrace_step_load(a, row0 + f0 / n, f0 - (f0 / n) * n);
+    float alpha = a.q ? expf(*a.log_alpha) : 0.f;
+    if (pending) alpha = expf(alpha_adam_preview(*pending, lds));
     for (int f = threadIdx.x; f < R * n; f += blockDim.x) {
         const int r = f / n, t = f - r * n;
         const int b = row0 + r;
         if (b >= a.B) continue;
         float d, c;
-        const float v_t = vtrace_step_terms(a, b, t, alpha, &d, &c);
+        const float v_t = f == f0 ? vtrace_step_finish(a, raw0, alpha, &d, &c) : vtrace_step_terms(a, b, t, alpha, &d, &c);
         if (t == 0) s_v0[r] = v_t;
         s_d[r * pitch + t] = d;
         s_c[r * pitch + t] = c;
