@@ -85,13 +85,13 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
         const int sample = (int)(row / a.L);
         const int j = (int)(row - (int64_t)sample * a.L);
         const int64_t id = a.ids[sample];
+        // the row is read whether or not it turns out to belong to the centre row's episode (the slot is always a
+        // valid address): the validity test's own loads — random reads of the index ring — travel WITH the data
+        // instead of in front of it
+        const int slot = ring_slot(id + (j - a.prev_n), a.capacity);
+        const Unit data = reinterpret_cast<const Unit*>(k.src + (int64_t)slot * k.row_bytes)[w];
         const bool valid = (k.pad_mode == ASAC_PAD_KEEP) || row_valid(a, id, j);
-        if (valid) {
-            const int slot = ring_slot(id + (j - a.prev_n), a.capacity);
-            val[r] = reinterpret_cast<const Unit*>(k.src + (int64_t)slot * k.row_bytes)[w];
-        } else {
-            val[r] = pad_value<Unit>(k, w);
-        }
+        val[r] = valid ? data : pad_value<Unit>(k, w);
     }
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r)
