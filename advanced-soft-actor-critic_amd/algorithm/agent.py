@@ -88,6 +88,8 @@ class EpisodeSlab:
         # `_tmp_seq_hidden_state`)
         self._pending_spec = {k: self._spec[k] for k in self._spec if k not in self.SCALARS}
         self._pending_spec['seq_hidden_state'] = (self.hidden_shape, torch.float32)
+        self._row_bytes_of = {k: int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+                              for k, (shape, dtype) in (self._spec | self._pending_spec).items()}
         self.padding_action = torch.from_numpy(np.ascontiguousarray(padding_action, dtype=np.float32)).to(self.device)
         self.ones_prob = torch.ones(self.action_size, dtype=torch.float32, device=self.device)
         self.slots = 0
@@ -98,8 +100,7 @@ class EpisodeSlab:
 
     # -- storage ---------------------------------------------------------------------------------------------
     def _row_bytes(self, key) -> int:
-        shape, dtype = (self._spec | self._pending_spec)[key]
-        return int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+        return self._row_bytes_of[key]
 
     def _grow(self, slots: int) -> None:
         old, self.slots = self.slots, slots

@@ -649,8 +649,27 @@ class SAC_Base(AuxHeadsMixin):
     def _choose_action(self, obs_list, state, offline_action=None, disable_sample=False,
                        force_rnd_if_available=False):
         batch = state.shape[0]
-        d_policy, c_policy = self.model_policy(state, obs_list)
         use_rnd = self.use_rnd and (self.train_mode or force_rnd_if_available)
+        if (offline_action is None and not use_rnd and self.action_noise is None and self._stock_c_only()
+                and state.dim() == 2):
+            # stock Gaussian policy, continuous actions only: the policy's forward is ONE launch (`asac_mlp_forward`),
+            # the sample and the probability of the chosen action one elementwise launch each — instead of ~25 eager
+            # module / distribution launches (0.45 ms of host time per environment step)
+            A = self.c_action_size
+            ls = self._fpi._launch_forward(StockMLP._rows(state, self.state_size), None)[0]      # [batch, 2A] (loc | scale)
+            loc, scale = ls[:, :A], ls[:, A:]
+            if disable_sample:
+                c_action = torch.tanh(loc)
+            else:
+                eps = torch.empty((batch, A), dtype=torch.float32, device=self.device)
+                self.noise.normal_(eps)
+                c_action = torch.empty((batch, A), dtype=torch.float32, device=self.device)
+                native.squash_sample_fwd(loc, scale, eps, c_action, torch.empty(batch, dtype=torch.float32, device=self.device))
+            prob = torch.empty((batch, A), dtype=torch.float32, device=self.device)
+            win = lambda t: t.as_strided((batch, 1, A), (t.stride(0), t.stride(0), 1))  # noqa: E731
+            native.squash_prob(win(loc), win(scale), win(c_action), 0, win(prob), 0)
+            return c_action, prob
+        d_policy, c_policy = self.model_policy(state, obs_list)
         if offline_action is None:
             if self.d_action_sizes and self.discrete_dqn_like:
                 # greedy w.r.t. the first critic, epsilon / RND-novelty random (reference 904-930)

@@ -6,7 +6,7 @@ environment steps of five agents that join, pause, finish "empty" first episodes
 — for a vector, a recurrent and an attention learner: the continuous action it returned every step (with the
 recorded Gaussian draw) and EVERY episode it handed to `put_episode`.  The product replays the same script:
 indexes, observations, rewards and done flags of the episodes must be bit-identical, actions / probabilities /
-hidden states within the acting tolerances (`test_surface_parity_gpu.py`), the agents' statistics equal.
+hidden states within the acting tolerances (`test_surface_parity_gpu.py`; probabilities 1e-3), the agents' statistics equal.
 Also: the row mover against NumPy on every addressing mode, and slab -> replay ring without a host copy."""
 import sys
 from pathlib import Path
@@ -37,11 +37,13 @@ def _assert_probs(got, want, what):
     the attention fixture: see DESIGN.md §5) `(loc + eps * scale) - loc` cancels in f32 and the density is 0 or ~1e9
     depending on the last bit, in the reference as much as here: those entries (density > 1e6) are only required
     to be degenerate on both sides.  Below that the density's condition number still grows like the density itself
-    (one ulp of the pre-squash action is 6e-8 |u| / scale standard deviations): rtol 2e-4 + 1e-8 * density.
+    (one ulp of the pre-squash action is 6e-8 |u| / scale standard deviations), and the density is evaluated at
+    atanh(clamp(tanh(u))), which loses digits as tanh saturates: rtol 1e-3 (the tolerance of the written-back
+    probabilities in the step tests) + 1e-8 * density.
     -> number of degenerate entries"""
     sane = want < 1e6
     err = np.abs(got[sane] - want[sane])
-    bound = 1e-6 + (2e-4 + 1e-8 * want[sane]) * np.abs(want[sane])
+    bound = 1e-6 + (1e-3 + 1e-8 * want[sane]) * np.abs(want[sane])
     assert np.all(err <= bound), (what, got[sane][err > bound], want[sane][err > bound])
     assert np.all((got[~sane] > 1e6) | (got[~sane] == 0)), what
     return int((~sane).sum())
