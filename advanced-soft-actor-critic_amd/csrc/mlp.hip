@@ -1436,8 +1436,9 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
     net_fetch_fixed<THREADS, 3>(sq, rq);
     put_input_tile<THREADS>(in_lo, L.xs[0]);
     net_put_fixed<THREADS, 3>(rp, L);
+    // (critic e's weights stay in registers until the policy has run: its 36 KB are still travelling when the policy's
+    // have landed — memory returns in order — and nothing needs them before the first critic layer)
     PiQCritic C{L.qw, L.qhead, L.qbias, L.qhead_bias};
-    net_put_fixed<THREADS, 3>(rq, C);
     __syncthreads();
     MLP_STAMP(1);
 
@@ -1565,6 +1566,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
                 for (int d = 0; d < A; ++d) L.act[lane * kHeadPad + d] = 0.f;
         }
         // ---- critic e on (state, sampled action) ---------------------------------------------------------------------
+        if (tile == group) net_put_fixed<THREADS, 3>(rq, C);
         put_input_tile<THREADS>(in_lo, L.xs[0]);         // the states again (columns >= S are zero)
         __syncthreads();
         MLP_STAMP(4);

@@ -12,14 +12,6 @@
 
 namespace asac {
 
-__global__ __launch_bounds__(256) void k_squash_sample_fwd(
-    const float* __restrict__ loc, const float* __restrict__ scale, int64_t ls, const float* __restrict__ eps,
-    int64_t rows, int A, float* __restrict__ a_out, float* __restrict__ logp_out,
-    float* __restrict__ x_out, const StoredProb sp) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    squash_sample_row(loc, scale, ls, eps, r, A, a_out, logp_out, x_out, sp);
-}
 
 // Several independent sampling / probability jobs in ONE launch (a train step issues up to three
 // back-to-back on outputs of the same policy forward; at 256..1280 rows each a launch is pure latency).
@@ -35,10 +27,70 @@ struct SquashJobsDev {
     int32_t n, blocks;
 };
 
+// One workgroup (256 threads) of a sampling / probability job.  The rows' transcendental chains (tanh, log, atanh, exp:
+// ~4 us when one lane walks a row's A dimensions, whatever the batch) are spread over lanes: a workgroup owns
+// R = 256 / A rows, lane (row, d) evaluates the per-element terms of squash_sample_at / stored_action_prob
+// (asac_squash.h) and parks them in LDS, then the sums and products over the action dimension are formed in d order —
+// the same values in the same order as the one-lane-per-row form, bit for bit.
+inline int squash_rows_per_block(int A) { return 256 / A; }
+
+__device__ __forceinline__ void squash_rows_block(const SquashJobDev& job, int64_t local_block, float* lds /* 512 floats */) {
+    const int A = job.A, R = 256 / A;
+    const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
+    const int64_t r = local_block * R + lrow;
+    const bool live = lrow < R && r < job.rows;
+    float* s0 = lds;
+    float* s1 = lds + 256;
+    const float* lrow_p = job.loc + r * job.ls;
+    const float* srow_p = job.scale + r * job.ls;
+    float l = 0.f, sc = 1.f;
+    if (live) l = lrow_p[d], sc = srow_p[d];
+    if (job.eps) {
+        if (live) {
+            const float x = l + job.eps[r * A + d] * sc;
+            const float t = tanhf(x);
+            s0[threadIdx.x] = logf(fmaxf(1.f - t * t, kSquashFloor));
+            s1[threadIdx.x] = normal_log_prob(x, l, sc);
+            job.a_out[r * A + d] = t;
+            if (job.x_out) job.x_out[r * A + d] = x;
+        }
+        __syncthreads();
+        if (live && d == 0) {
+            float corr = 0.f;
+            for (int dd = 0; dd < A; ++dd) corr += s0[lrow * A + dd];
+            float lp = 0.f;
+            for (int dd = 0; dd < A; ++dd) {
+                float v = s1[lrow * A + dd] - corr;      // correction broadcast to every component
+                if (v == INFINITY) v = 0.f;              // sum_log_prob's inf mask
+                lp += v;
+            }
+            job.logp_out[r] = lp;
+        }
+        if (!job.sp.action) return;
+        __syncthreads();
+    }
+    // probabilities of the stored actions under the same Gaussian
+    const StoredProb& sp = job.sp;
+    int64_t sb = 0, st = 0;
+    if (live) {
+        sb = r / sp.T;
+        st = r - sb * sp.T;
+        const float x = atanhf(fminf(fmaxf(sp.action[sb * sp.a_sb + st * sp.a_st + sp.a_off + d], -0.999f), 0.999f));
+        s0[threadIdx.x] = squash_jac(x);
+        s1[threadIdx.x] = expf(normal_log_prob(x, l, sc));
+    }
+    __syncthreads();
+    if (live) {
+        float jac = 1.f;
+        for (int dd = 0; dd < A; ++dd) jac *= s0[lrow * A + dd];
+        sp.out[sb * sp.p_sb + st * sp.p_st + sp.p_off + d] = s1[threadIdx.x] / jac;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_squash_multi(const SquashJobsDev js, const SidecarsDev sc) {
+    __shared__ float lds[512];
     if ((int)blockIdx.x >= js.blocks) {         // sidecar workgroups (asac_sidecar.h)
-        __shared__ float red[256];
-        sidecar_run(sc, (int)blockIdx.x - js.blocks, red);
+        sidecar_run(sc, (int)blockIdx.x - js.blocks, lds);
         return;
     }
     int k = 0;
@@ -46,12 +98,7 @@ __global__ __launch_bounds__(256) void k_squash_multi(const SquashJobsDev js, co
     for (int q = 1; q < ASAC_SQUASH_MAX_JOBS; ++q)
         if (q < js.n && (int)blockIdx.x >= js.j[q].first_block) k = q;
     const SquashJobDev& job = js.j[k];
-    const int64_t r = (int64_t)((int)blockIdx.x - job.first_block) * blockDim.x + threadIdx.x;
-    if (r >= job.rows) return;
-    if (job.eps)
-        squash_sample_row(job.loc, job.scale, job.ls, job.eps, r, job.A, job.a_out, job.logp_out, job.x_out, job.sp);
-    else
-        stored_action_prob(job.loc + r * job.ls, job.scale + r * job.ls, job.sp, r, job.A);
+    squash_rows_block(job, (int)blockIdx.x - job.first_block, lds);
 }
 
 // d logp / d x_d  = A * 2 tanh(x_d) [1 - tanh^2 > floor]   (+ the Normal part cancels between the
@@ -81,12 +128,10 @@ __global__ __launch_bounds__(256) void k_squash_sample_bwd(
     }
 }
 
-// Per-dimension probability of stored (already squashed) actions only.
-__global__ __launch_bounds__(256) void k_squash_prob(const float* __restrict__ loc, const float* __restrict__ scale,
-                                                     int64_t ls, int64_t rows, int A, const StoredProb sp) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    stored_action_prob(loc + r * ls, scale + r * ls, sp, r, A);
+// a single job (asac_squash_sample_fwd, asac_squash_prob)
+__global__ __launch_bounds__(256) void k_squash_job(const SquashJobDev job) {
+    __shared__ float lds[512];
+    squash_rows_block(job, blockIdx.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,10 +387,15 @@ int asac_squash_sample_fwd(const float* loc, const float* scale, int64_t ls_row_
                            int prob_offset, void* stream) {
     if (rows <= 0 || A <= 0 || A > ASAC_MAX_ACTION || (action && (T <= 0 || !prob_out)))
         return bad_arg("asac_squash_sample_fwd");
-    const StoredProb sp{action, T, action_stride_b, action_stride_t, action_offset,
+    if (!eps || !a_tanh_out || !logp_out) return bad_arg("asac_squash_sample_fwd: outputs");
+    SquashJobDev job{};
+    job.loc = loc; job.scale = scale; job.eps = eps;
+    job.ls = ls_row_stride; job.rows = rows; job.A = A;
+    job.a_out = a_tanh_out; job.logp_out = logp_out; job.x_out = x_out;
+    job.sp = StoredProb{action, T, action_stride_b, action_stride_t, action_offset,
                         prob_out, prob_stride_b, prob_stride_t, prob_offset};
-    ASAC_LAUNCH(k_squash_sample_fwd, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                as_stream(stream), loc, scale, ls_row_stride, eps, rows, A, a_tanh_out, logp_out, x_out, sp);
+    const int R = squash_rows_per_block(A);
+    ASAC_LAUNCH(k_squash_job, dim3((unsigned)((rows + R - 1) / R)), dim3(256), 0, as_stream(stream), job);
     return finish_launch("asac_squash_sample_fwd");
 }
 
@@ -382,7 +432,8 @@ int asac_squash_multi(const asac_squash_job_t* jobs_host, int n_jobs, const asac
         d.a_out = h.a_tanh_out; d.logp_out = h.logp_out; d.x_out = h.x_out;
         d.sp = StoredProb{h.action, h.T, h.action_stride_b, h.action_stride_t, h.action_offset,
                           h.prob_out, h.prob_stride_b, h.prob_stride_t, h.prob_offset};
-        blocks += (int)((h.rows + 255) / 256);
+        const int R = squash_rows_per_block(h.A);
+        blocks += (int)((h.rows + R - 1) / R);
     }
     js.blocks = blocks;
     // (under the measurement repeat knob only the last repetition carries the sidecars)
@@ -400,10 +451,13 @@ int asac_squash_prob(const float* loc, const float* scale, int64_t ls_row_stride
                      int64_t prob_stride_t, int prob_offset, void* stream) {
     if (rows <= 0 || A <= 0 || A > ASAC_MAX_ACTION || T <= 0 || !action || !prob_out)
         return bad_arg("asac_squash_prob");
-    const StoredProb sp{action, T, action_stride_b, action_stride_t, action_offset,
+    SquashJobDev job{};
+    job.loc = loc; job.scale = scale;
+    job.ls = ls_row_stride; job.rows = rows; job.A = A;
+    job.sp = StoredProb{action, T, action_stride_b, action_stride_t, action_offset,
                         prob_out, prob_stride_b, prob_stride_t, prob_offset};
-    ASAC_LAUNCH(k_squash_prob, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                as_stream(stream), loc, scale, ls_row_stride, rows, A, sp);
+    const int R = squash_rows_per_block(A);
+    ASAC_LAUNCH(k_squash_job, dim3((unsigned)((rows + R - 1) / R)), dim3(256), 0, as_stream(stream), job);
     return finish_launch("asac_squash_prob");
 }
 
