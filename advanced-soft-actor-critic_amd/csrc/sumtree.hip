@@ -441,6 +441,23 @@ extern "C" {
 
 int asac_version(void) { return ASAC_ABI_VERSION; }
 
+// sizeof of the by-value structs of the ABI as this library was compiled (bindings check their mirrors against it)
+int64_t asac_struct_size(const char* name) {
+#define ASAC_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
+    ASAC_SZ(asac_gather_key_t);
+    ASAC_SZ(asac_row_move_t);
+    ASAC_SZ(asac_sidecar_t);
+    ASAC_SZ(asac_squash_job_t);
+    ASAC_SZ(asac_vtrace_args_t);
+    ASAC_SZ(asac_mlp_desc_t);
+    ASAC_SZ(asac_mlp_job_t);
+    ASAC_SZ(asac_pi_q_job_t);
+    ASAC_SZ(asac_gru_desc_t);
+    ASAC_SZ(asac_conv2_desc_t);
+#undef ASAC_SZ
+    return -1;
+}
+
 const char* asac_last_error(void) { return g_err; }
 
 int asac_set_launch_repeat(int repeat) {

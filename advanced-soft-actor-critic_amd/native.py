@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 42
+ABI_VERSION = 43
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -190,6 +190,7 @@ _SIGNATURES = {
     'asac_mlp_backward_policy_sample': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'asac_struct_size': (C.c_int64, [C.c_char_p]),
     'asac_policy_sample_q_forward_ok': (C.c_int, [C.POINTER(PiQJob)]),
     'asac_policy_sample_q_forward': (C.c_int, [C.POINTER(PiQJob), C.POINTER(MlpJob), C.c_int, C.POINTER(Sidecar), C.c_int,
                                                C.c_void_p]),

@@ -25,13 +25,16 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 42
+#define ASAC_ABI_VERSION 43
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
 #define ASAC_MLP_MAX_BLOCKS 4
 
 int asac_version(void);
+/* sizeof of a by-value struct of this header ("asac_mlp_job_t", ...) as the library was compiled, -1 for an unknown name:
+ * bindings in other languages check their mirrors of the structs against it */
+int64_t asac_struct_size(const char* name);
 const char* asac_last_error(void);
 
 /* Measurement knob: every kernel launch inside an entry point is issued `repeat` times

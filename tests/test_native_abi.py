@@ -43,11 +43,16 @@ def test_binding_covers_header_and_abi_version():
 
 
 def test_struct_layouts_match_header_sizes():
-    """ctypes mirrors of the by-value structs: field counts / sizes as the C compiler lays them out."""
+    """ctypes mirrors of the by-value structs against sizeof as the library's compiler laid them out"""
     from asac_amd import native
-    assert ctypes.sizeof(native.GatherKey) == 40
-    # 11 pointers/int64 blocks ... computed once with offsetof in csrc; keep in sync when editing
-    assert ctypes.sizeof(native.VtraceArgs) % 8 == 0 and ctypes.sizeof(native.VtraceArgs) >= 200
+    lib = native.load()
+    mirrors = {'asac_gather_key_t': native.GatherKey, 'asac_row_move_t': native.RowMove, 'asac_sidecar_t': native.Sidecar,
+               'asac_squash_job_t': native.SquashJob, 'asac_vtrace_args_t': native.VtraceArgs,
+               'asac_mlp_desc_t': native.MlpDesc, 'asac_mlp_job_t': native.MlpJob, 'asac_pi_q_job_t': native.PiQJob,
+               'asac_gru_desc_t': native.GruDesc, 'asac_conv2_desc_t': native.Conv2Desc}
+    for name, mirror in mirrors.items():
+        assert lib.asac_struct_size(name.encode()) == ctypes.sizeof(mirror), name
+    assert lib.asac_struct_size(b'no_such_struct') == -1
 
 
 def test_product_path_refuses_cpu_devices():
@@ -56,3 +61,7 @@ def test_product_path_refuses_cpu_devices():
     from algorithm.replay_buffer import PrioritizedReplayBuffer
     with pytest.raises(native.AsacNativeError):
         PrioritizedReplayBuffer(batch_size=4, device=torch.device('cpu'), capacity=16)
+    from algorithm.agent import EpisodeSlab
+    import numpy as np
+    with pytest.raises(native.AsacNativeError):     # the agent side's episode slabs live in HBM as well
+        EpisodeSlab([(6,)], [np.float32], 2, (0,), 16, torch.device('cpu'), np.zeros(2, np.float32))
