@@ -56,19 +56,20 @@ __global__ __launch_bounds__(256) void k_alpha_adam(const AlphaAdamArgs a) {
 // partial sums (asac_mlp_backward* with ASAC_MLP_REDUCE_DEFER): the fixed-order tile sum (the same
 // order k_mlp_reduce_partials uses), the optional accumulation into grad, and the update in one pass.
 // sum over the tiles of one parameter's partial gradients in tile order (the order k_mlp_reduce_partials uses), the
-// loads issued eight at a time: a plain `for (t) s += partial[t]` compiles to load -> wait -> add per tile, i.e. one
-// dependent L2 round trip per tile (sixteen of them at batch 256: most of this launch)
+// loads issued sixteen at a time: a plain `for (t) s += partial[t]` compiles to load -> wait -> add per tile, i.e. one
+// dependent L2 round trip per tile (sixteen of them at batch 256: most of this launch); sixteen = the tiles of a
+// batch-256 backward, so the step's Adam launches wait for ONE round trip (eight at a time made it two)
 __device__ __forceinline__ float sum_tiles(const float* __restrict__ partial, int64_t tile_stride, int tiles) {
     float s = 0.f;
-    for (int t0 = 0; t0 < tiles; t0 += 8) {
-        float v[8];
+    for (int t0 = 0; t0 < tiles; t0 += 16) {
+        float v[16];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < 16; ++w) {
             const int t = t0 + w < tiles ? t0 + w : tiles - 1;         // clamped: every load is issued, none branches
             v[w] = partial[(int64_t)t * tile_stride];
         }
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += t0 + w < tiles ? v[w] : 0.f;
+        for (int w = 0; w < 16; ++w) s += t0 + w < tiles ? v[w] : 0.f;
     }
     return s;
 }
