@@ -203,3 +203,38 @@ def test_test_actions_without_a_learner():
         assert ep['ep_obses_list'][1].dtype == torch.uint8 and ep['ep_obses_list'][1].shape == (1, 7, 2)
         assert ep['ep_dones'].cpu().numpy().tolist() == [[False] * 5 + [True, False]]
         assert np.array_equal(ep['ep_actions'][0, -1].cpu().numpy(), np.asarray([1, 0, 0, 1, 0, 0, 0], np.float32))
+
+
+def test_multi_agents_manager_runs_two_behaviours(tmp_path):
+    """`MultiAgentsManager` (agent.py:691-890) over two behaviour names with their own learners: the reference's
+    training-loop calls (`sac_main._run`, 388-532) in order — actions per behaviour, episodes ended, put, trained."""
+    from algorithm.agent import MultiAgentsManager
+    names = ['a?team=0', 'b?team=1']
+    mgr = MultiAgentsManager({n: ['vector'] for n in names}, {n: [(6,)] for n in names}, {n: [np.float32] for n in names},
+                             {n: [] for n in names}, {n: 2 for n in names}, inference_ma_names=set(), model_abs_dir=tmp_path,
+                             max_episode_length=32)
+    assert len(mgr) == 2 and all((tmp_path / d).is_dir() for d in ('a-team=0', 'b-team=1'))
+    for n, m in mgr:
+        m.set_rl(_learner('nn_vec'))
+    mgr.set_train_mode(True)
+    rng = np.random.default_rng(0)
+    ids = {n: np.arange(3) for n in names}
+    trained = 0
+    for t in range(40):
+        obs = {n: [rng.standard_normal((3, 6)).astype(np.float32)] for n in names}
+        rew = {n: rng.standard_normal(3).astype(np.float32) for n in names}
+        d_act, c_act = mgr.get_ma_action(ids, obs, rew)
+        assert all(c_act[n].shape == (3, 2) and d_act[n].shape == (3, 0) for n in names)
+        if t % 9 == 8:
+            mgr.end_episode(ids, obs, rew, {n: np.zeros(3, dtype=bool) for n in names})
+            assert all(len(m.get_tmp_episode_trans_list()) == 3 for _, m in mgr)
+            mgr.log_episode()
+            mgr.put_episode()
+            trained = mgr.train(trained)
+    assert (tmp_path / 'episodes_info.json').exists()
+    # 4 rounds x 3 agents x 10 rows (9 transitions + the closing row) through a ring of 64 slots
+    assert trained >= 1 and all(m.rl.replay_buffer.size == 64 and m.rl.replay_buffer._next_id == 120 for _, m in mgr)
+    assert mgr.done is False or mgr.done is True
+    mgr.reset_and_continue()
+    mgr.force_end_all_episode()
+    mgr.close()
