@@ -358,15 +358,21 @@ class PrioritizedReplayBuffer:
                                         rows.stride(1) * es, scratch)
 
     def window_scatter_sidecars(self, sample_ids: torch.Tensor, first_off: int, count: int,
-                                padding_mask: torch.Tensor, key: str, rows: torch.Tensor):
+                                padding_mask: torch.Tensor, key: str, rows: torch.Tensor, side: bool = False):
         """`update_window_transitions` as two sidecar jobs (`native.Sidecar`: elect, write) for launches that
-        already sit on the step's critical path; the write job must ride a LATER launch than the elect job."""
+        already sit on the step's critical path; the write job must ride a LATER launch than the elect job.
+        `side`: the second election scratch (two write-backs in flight at once must not share their map)."""
         col = self._columns[key]
         row_bytes = col[0].numel() * col.element_size()
         assert row_bytes > 0 and rows.dtype == col.dtype
         es = rows.element_size()
+        scratch = self._winner_rows
+        if side:
+            if self._winner_rows_side is None:
+                self._winner_rows_side = torch.full_like(self._winner_rows, -1)
+            scratch = self._winner_rows_side
         args = (col, row_bytes, self.capacity, sample_ids, sample_ids.numel(), first_off, count, self._slot_ids,
-                padding_mask, padding_mask.stride(0), rows, rows.stride(0) * es, rows.stride(1) * es, self._winner_rows)
+                padding_mask, padding_mask.stride(0), rows, rows.stride(0) * es, rows.stride(1) * es, scratch)
         return (native.sidecar_scatter(native.SIDECAR_SCATTER_ELECT, *args),
                 native.sidecar_scatter(native.SIDECAR_SCATTER_WRITE, *args))
 

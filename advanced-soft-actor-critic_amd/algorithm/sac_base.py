@@ -1645,7 +1645,8 @@ class SAC_Base(AuxHeadsMixin):
                         self.noise.normal_(self._eps_td)
                         td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
                         jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
-                    if td_sample is not None and self._use_sidecars and not self._parallel_branches:
+                    # (with priorities the TD error's online-Q launch follows and hosts the second pass + the temperature step)
+                    if self.use_priority and self._use_sidecars and not self._parallel_branches and rb.sharded is None:
                         sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
                         if auto_alpha:
                             sc_alpha = self._alpha_sidecar(alpha_logp)
@@ -1666,6 +1667,9 @@ class SAC_Base(AuxHeadsMixin):
                         native.mlp_forward_multi([job_q, job_tq],
                                                  sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None] or None)
                         td_q_table = td_q_table.view(self.ensemble_q_num, *bnx_states.shape[:2])
+                    elif sc_write is not None or sc_alpha is not None:
+                        job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
+                        native.mlp_forward_multi([job_q], sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
                     else:
                         self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
@@ -1689,6 +1693,17 @@ class SAC_Base(AuxHeadsMixin):
                 pi_probs = probs_win[:, :-1]          # the last row's probability is not stored (1159-1189)
             else:
                 pi_probs = self.get_l_probs([o[:, :-1] for o in bnx_obses_list], bn_states, bn_actions)
+        # the hidden-state write-back rides along too: its election beside the TD error's return, its write pass beside the
+        # priority update (the step's last two launches; its own election scratch: the mu-probability write pass may
+        # share the return launch)
+        hidden_rows = hidden_write = None
+        if (self.seq_hidden_state_shape[-1] != 0 and self.use_priority and self._use_sidecars and not self._parallel_branches
+                and rb.sharded is None and bool(self.c_action_size) and not self.d_action_sizes
+                and len(self._vtrace_sidecars or ()) < native.MAX_SIDECARS):
+            hidden_rows = next_hidden.detach().contiguous()
+            h_elect, hidden_write = rb.window_scatter_sidecars(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
+                                                               hidden_rows, side=True)
+            self._vtrace_sidecars = list(self._vtrace_sidecars or ()) + [h_elect]
         if self.use_priority:
             td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
                                     bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
@@ -1696,9 +1711,10 @@ class SAC_Base(AuxHeadsMixin):
                                     ls=ls_win if td_sample is not None else None, sample=td_sample,
                                     stored_pi=probs_win if td_sample is not None else None, c_q=side_cq,
                                     q_table=td_q_table)
-            rb.update(ids, td, sidecars=[self._pending_alpha] if self._pending_alpha is not None else None)
+            assert not self._vtrace_sidecars, 'the TD error\'s return launch did not take its sidecars'
+            rb.update(ids, td, sidecars=[sc for sc in (self._pending_alpha, hidden_write) if sc is not None] or None)
             self._pending_alpha = None
-        if self.seq_hidden_state_shape[-1] != 0:
+        if self.seq_hidden_state_shape[-1] != 0 and hidden_write is None:
             rb.update_window_transitions(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
                                          next_hidden.detach().contiguous())
         if self.use_n_step_is and probs_win is None:
