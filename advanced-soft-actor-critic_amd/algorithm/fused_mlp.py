@@ -343,13 +343,17 @@ class StockMLP:
             return native.MLP_REDUCE_DEFER
         return native.MLP_REDUCE_ACCUMULATE if self.accumulate else native.MLP_REDUCE_OVERWRITE
 
-    def backward_qloss(self, x0, x1, target_q, y, weights, clip_eps, loss_out, defer=False):
+    def backward_qloss(self, x0, x1, target_q, y, weights, clip_eps, loss_out, defer=False, state_grads=False):
         """Scalar-head ensemble: clipped double-Q loss + backward in one launch.  With `defer` the
-        parameter gradients stay per-tile partial sums for `adam_partials`."""
+        parameter gradients stay per-tile partial sums for `adam_partials`.  `state_grads`: -> [E, N, in0], the
+        members' gradients w.r.t. x0 (a trainable representation continues the backward from their sum)."""
         N = x0.shape[-2]
+        g0 = torch.empty((self.E, N, self.in0), dtype=torch.float32, device=self.device) if state_grads else None
         native.mlp_backward_qloss(self.desc, self.params, self.member_stride, self.E, x0, x1, N, target_q, y, weights,
-                                  clip_eps, loss_out, self.grad_params, self._workspace_for(N), self._reduce_mode(defer))
+                                  clip_eps, loss_out, self.grad_params, self._workspace_for(N), self._reduce_mode(defer),
+                                  grad_x0=g0)
         self._deferred_rows = N if defer else None
+        return g0
 
     def backward_policy_q(self, x0, x1, q_table, subset, E_sample):
         """-> [E, N, in1] action gradients of mean_b(-min_{e in subset} q_e) (`q_table` [E, N] from the

@@ -214,6 +214,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
+        self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
         self._vtrace_sidecars = self._pending_alpha = None
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
         assert self._dist_sampling in ('throughput', 'parity')
@@ -1116,6 +1117,30 @@ class SAC_Base(AuxHeadsMixin):
         state, action = nx_states[:, 0], nx_actions[:, 0]
         d_action, c_action = action[..., :dsum], action[..., dsum:]
 
+        if (self._fused_q_state_grads and self._fq is not None and self._ftq is not None and not self.d_action_sizes
+                and self.c_action_size and self.clip_epsilon > 0 and aux is None and state_base is not None
+                and state_base[0].dim() == 3 and state.requires_grad):
+            # stock critics behind a trainable representation: target Q of the stored pair -> return target -> ONE
+            # launch for [critics forward, clipped double-Q loss, backward] that also returns d loss / d state (the
+            # separate critic forward and loss launches of the autograd form disappear); the representation's backward
+            # continues from that gradient
+            base, t = state_base
+            with torch.no_grad():
+                x0 = StockMLP._rows(base.detach()[:, t], self.state_size)
+                a0 = StockMLP._rows(c_action, self.c_action_size)
+                t_q = self._ftq._launch_forward(x0, a0, out=self._tq_buf)
+                _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states.detach(), nx_actions,
+                                     n_rewards, n_dones, n_mu_probs if self.use_n_step_is else None,
+                                     eps_buf=self._eps_y, subset_prefix='y', y_out=self._y_buf,
+                                     policy_sample=policy_sample)
+                w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
+                g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
+                                             self.clip_epsilon, self._loss_q_e, state_grads=True)
+                g_base = torch.zeros_like(base)
+                torch.sum(g0, dim=0, out=g_base[:, t])
+            with direct_param_grads():
+                torch.autograd.backward([base], [g_base])
+            return self._finish_rep_q(None, None)
         q_list = None
         if self.d_action_sizes:
             q_list = [q(state, c_action, obs_list) for q in self.model_q_list]

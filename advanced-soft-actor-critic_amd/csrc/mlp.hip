@@ -2158,6 +2158,17 @@ int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc, const float* params, in
                             const float* target_q, const float* y, const float* weights, float clip_eps,
                             float* loss_out, float* grad_params, float* workspace, int reduce_mode,
                             void* stream) {
+    return asac_mlp_backward_qloss_gx(desc, params, member_stride, E, x0, x0_row_stride, x0_member_stride, x1, x1_row_stride,
+                                      x1_member_stride, N, target_q, y, weights, clip_eps, loss_out, nullptr, grad_params,
+                                      workspace, reduce_mode, stream);
+}
+
+int asac_mlp_backward_qloss_gx(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,
+                               const float* x0, int64_t x0_row_stride, int64_t x0_member_stride,
+                               const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
+                               const float* target_q, const float* y, const float* weights, float clip_eps,
+                               float* loss_out, float* grad_x0, float* grad_params, float* workspace, int reduce_mode,
+                               void* stream) {
     if (!desc || !desc_ok(*desc) || E <= 0 || N <= 0 || !x0 || (desc->in1 > 0 && !x1) || !target_q || !y ||
         !grad_params || !workspace || clip_eps <= 0.f)
         return bad_arg("asac_mlp_backward_qloss");
@@ -2170,6 +2181,7 @@ int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc, const float* params, in
     a.y = y;
     a.w = weights;
     a.clip_eps = clip_eps;
+    a.gx0 = grad_x0;
     return mlp_backward_common("asac_mlp_backward_qloss", desc, a, E, N, member_stride, grad_params, workspace,
                                reduce_mode, loss_out, as_stream(stream));
 }

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 43
+ABI_VERSION = 44
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -184,6 +184,10 @@ _SIGNATURES = {
                                           C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int, C.c_void_p]),
+    'asac_mlp_backward_qloss_gx': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                             C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_void_p]),
     'asac_mlp_backward_policy_q': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                              C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -781,16 +785,18 @@ def mlp_param_extent(desc) -> int:
 
 @_profiled
 def mlp_backward_qloss(desc, params, member_stride, E, x0, x1, N, target_q, y, weights, clip_eps, loss_out,
-                       grad_params, workspace, reduce_mode):
-    """Q loss + backward of the stock Q ensemble in one launch (parameter gradients only)."""
+                       grad_params, workspace, reduce_mode, grad_x0=None):
+    """Q loss + backward of the stock Q ensemble in one launch (parameter gradients; with `grad_x0` [E, N, in0] also
+    the members' gradients w.r.t. the state input)."""
     global _last_work
     _last_work = mlp_flops(desc, E, N, backward=True, param_grads=True)
     p0, rs0, ms0 = _rows_view(x0)
     p1, rs1, ms1 = _rows_view(x1)
     assert target_q.is_contiguous() and target_q.numel() == E * N and y.is_contiguous() and y.numel() == N
-    _check(load().asac_mlp_backward_qloss(C.byref(desc), _p(params), member_stride, E, p0, rs0, ms0, p1, rs1, ms1, N,
-                                          _p(target_q), _p(y), _p(weights), float(clip_eps), _p(loss_out),
-                                          _p(grad_params), _p(workspace), int(reduce_mode), _stream()),
+    assert grad_x0 is None or (grad_x0.is_contiguous() and grad_x0.numel() == E * N * desc.in0)
+    _check(load().asac_mlp_backward_qloss_gx(C.byref(desc), _p(params), member_stride, E, p0, rs0, ms0, p1, rs1, ms1, N,
+                                             _p(target_q), _p(y), _p(weights), float(clip_eps), _p(loss_out), _p(grad_x0),
+                                             _p(grad_params), _p(workspace), int(reduce_mode), _stream()),
            'asac_mlp_backward_qloss')
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 43
+#define ASAC_ABI_VERSION 44
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -519,6 +519,15 @@ int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc_host, const float* param
                             const float* target_q, const float* y, const float* weights, float clip_eps,
                             float* loss_out, float* grad_params, float* workspace, int reduce_mode,
                             void* stream);
+/* ... also returning the gradient of the summed member losses w.r.t. the STATE input, grad_x0 [E][N][in0] (one per
+ * member; the caller sums them): a trainable representation's Q step needs no separate critic forward / loss launch
+ * (sac_base.py:1539-1570 with the representation in the graph). */
+int asac_mlp_backward_qloss_gx(const asac_mlp_desc_t* desc_host, const float* params, int64_t member_stride, int E,
+                               const float* x0, int64_t x0_row_stride, int64_t x0_member_stride,
+                               const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
+                               const float* target_q, const float* y, const float* weights, float clip_eps,
+                               float* loss_out, float* grad_x0, float* grad_params, float* workspace, int reduce_mode,
+                               void* stream);
 
 /* The policy step's Q backward (sac_base.py:1896-1903): the gradient of mean_b(-min_{e in subset} q_e)
  * w.r.t. the ensemble outputs is formed on chip from the value table q_table [E][N] the preceding
