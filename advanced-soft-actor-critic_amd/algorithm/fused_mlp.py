@@ -374,17 +374,19 @@ class StockMLP:
 
     def policy_step_fused_ok(self, critics: 'StockMLP', N: int) -> bool:
         """may `policy_step_fused` replace the critics' forward + `backward_policy_q` + `backward_policy_sample`?"""
-        return (self.E == 1 and critics.E == 2 and self.grad_params is not None and
+        return (self.E == 1 and critics.E >= 2 and self.grad_params is not None and
                 native.policy_step_fused_ok(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
                                             self.member_stride, N))
 
-    def policy_step_fused(self, critics: 'StockMLP', x0, action, eps, log_alpha, q_out=None, defer=False):
-        """Gaussian-head policy (E = 1) against two stock critics: the whole policy step in one launch
-        (`asac_policy_step_fused`); `q_out` [2, N, 1] receives the critics' values of (x0, action)."""
+    def policy_step_fused(self, critics: 'StockMLP', x0, action, eps, log_alpha, q_out=None, defer=False, subset=None):
+        """Gaussian-head policy (E = 1) against the TWO critics the objective samples (`subset`: device i32[2], None =
+        members 0 and 1 of a two-member ensemble): the whole policy step in one launch (`asac_policy_step_fused`);
+        `q_out` [E, N, 1] receives those critics' values of (x0, action)."""
         N = x0.shape[-2]
+        assert subset is not None or critics.E == 2
         native.policy_step_fused(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
                                  self.member_stride, x0, N, action, eps, log_alpha, q_out, self.grad_params,
-                                 self._workspace_for(N), self._reduce_mode(defer))
+                                 self._workspace_for(N), self._reduce_mode(defer), subset=subset)
         self._deferred_rows = N if defer else None
 
     def adam_partials(self, opt, loss_out=None):

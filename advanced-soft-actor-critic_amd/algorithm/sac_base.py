@@ -1251,11 +1251,12 @@ class SAC_Base(AuxHeadsMixin):
         self._pi_stats_src = (logp, scale)
         opt = self.optimizer_policy
         fold = self._dist is None and (opt.start, opt.stop) == (self._fpi._start, self._fpi._start + self._fpi.member_stride)
-        if (self._fused_policy_step and self.ensemble_q_sample == E and a_tanh.is_contiguous()
+        if (self._fused_policy_step and self.ensemble_q_sample == 2 and a_tanh.is_contiguous()
                 and self._fpi.policy_step_fused_ok(self._fq, B)):
-            # two critics, both sampled: critics forward, objective gradient, critics backward to the action, sampling
-            # backward and policy backward in ONE launch (bit-identical to the chain below)
-            self._fpi.policy_step_fused(self._fq, x, a_tanh, self._eps_pi, self.log_c_alpha, q_out=self._pi_q, defer=fold)
+            # two critics sampled (of two or more): critics forward, objective gradient, critics backward to the action,
+            # sampling backward and policy backward in ONE launch (bit-identical to the chain below)
+            self._fpi.policy_step_fused(self._fq, x, a_tanh, self._eps_pi, self.log_c_alpha, q_out=self._pi_q, defer=fold,
+                                        subset=sub if E != 2 else None)
         else:
             c_qs = self._fq._launch_forward(x, a_tanh, out=self._pi_q)                   # [E, B, 1]
             # objective gradients formed on chip: dL/dq inside the Q backward (from the value table), dL/dlogp =

@@ -1094,8 +1094,9 @@ struct PsLds {
 static_assert(sizeof(PsPiLds) <= 2 * sizeof(PsQLds), "the policy phase reuses the critics' LDS");
 
 struct PolicyStepArgs {
-    MlpArgs q, pi;          // q: E = 2 members, x0 = states, x1 = sampled actions; pi: x0 = states, eps, log_alpha, partial
-    float* q_out;           // [2][N] the value table (statistics) or NULL
+    MlpArgs q, pi;          // q: x0 = states, x1 = sampled actions, subset = the TWO members the objective samples (device
+                            // indices, NULL = members 0 and 1); pi: x0 = states, eps, log_alpha, partial
+    float* q_out;           // [E][N] the value table (statistics; the two sampled members' rows are written) or NULL
 };
 
 // a 16-row input tile with 512 threads: 2 of the 16 x 64 slots per thread
@@ -1171,7 +1172,10 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     MLP_STAMP(0);
 
     // ---- staging: both critics -> LDS, the policy's parameters and this tile's noise -> registers ---------------
-    const StageScalars s0 = stage_scalars<3>(a.q, 0), s1 = stage_scalars<3>(a.q, 1), sp = stage_scalars<3>(a.pi, 0);
+    // the two critics of the objective's subset (an ensemble of more members: the others get no gradient from
+    // mean_b -min_{e in subset} q_e, so they are not evaluated at all); the order of the subset breaks ties
+    const int e0 = a.q.subset ? a.q.subset[0] : 0, e1 = a.q.subset ? a.q.subset[1] : 1;
+    const StageScalars s0 = stage_scalars<3>(a.q, e0), s1 = stage_scalars<3>(a.q, e1), sp = stage_scalars<3>(a.pi, 0);
     float in_q[2], in_pi[2];
     ps_fetch_tile(s0, row0, in_q);
     ps_fetch_tile(sp, row0, in_pi);
@@ -1227,7 +1231,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
                 const int lrow = 4 * (lane >> 4) + r;
                 const float qv = raw[r] + Q.head_bias[0];
                 L.qv[m][lrow] = qv;
-                if (a.q_out && row0 + lrow < N) a.q_out[(int64_t)m * N + row0 + lrow] = qv;
+                if (a.q_out && row0 + lrow < N) a.q_out[(int64_t)(m ? e1 : e0) * N + row0 + lrow] = qv;
             }
         }
     }
@@ -2020,8 +2024,8 @@ int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_para
 int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
                            const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
                            const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
-                           const float* log_alpha, float* q_out, float* pi_grad_params, float* workspace,
-                           int reduce_mode, void* stream) {
+                           const float* log_alpha, const int32_t* subset, float* q_out, float* pi_grad_params,
+                           float* workspace, int reduce_mode, void* stream) {
     if (!asac_policy_step_fused_ok(q_desc, q_params, q_member_stride, pi_desc, pi_params, pi_member_stride, N) ||
         !x || !action || !eps || !log_alpha || !pi_grad_params || !workspace)
         return bad_arg("asac_policy_step_fused");
@@ -2030,6 +2034,7 @@ int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params,
     a.q = make_args(q_desc, q_params, q_member_stride, x, x_row_stride, 0, action, A, 0, N);
     a.pi = make_args(pi_desc, pi_params, pi_member_stride, x, x_row_stride, 0, nullptr, 0, 0, N);
     if (!offsets32(a.q) || !offsets32(a.pi)) return bad_arg("asac_policy_step_fused: offsets");
+    a.q.subset = subset;
     a.pi.eps = eps;
     a.pi.log_alpha = log_alpha;
     a.pi.partial = workspace;

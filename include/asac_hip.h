@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 44
+#define ASAC_ABI_VERSION 45
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -544,7 +544,10 @@ int asac_mlp_backward_policy_q(const asac_mlp_desc_t* desc_host, const float* pa
  * forward on (x, action), d(mean_b -min_e q_e)/dq, both critics' backward to the action, the rsample / tanh /
  * log-prob backward (dL/dlogp = exp(*log_alpha) / N) and the policy's backward — what asac_mlp_forward +
  * asac_mlp_backward_policy_q (E = E_sample = 2) + asac_mlp_backward_policy_sample compute in three launches,
- * bit for bit (same MFMA chains).  A workgroup of 8 waves owns a 16-row tile end to end; nothing but the policy's
+ * bit for bit (same MFMA chains).  An ensemble of more than two critics with E_sample = 2 qualifies too: `subset`
+ * (device i32[2], NULL = members 0, 1) names the two the objective samples — the others get no gradient from it and
+ * are not evaluated; q_out is then [E][N] with those two rows written.
+ * A workgroup of 8 waves owns a 16-row tile end to end; nothing but the policy's
  * per-tile parameter-gradient partials (workspace, tiles = asac_mlp_backward_tiles(N, 1); reduce_mode as above)
  * and the value table q_out [2][N] (optional) leaves the chip.
  *   x [N] rows of in0 floats (row stride x_row_stride), action [N][A] = tanh(loc + eps * scale), eps [N][A].
@@ -555,8 +558,8 @@ int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_para
 int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
                            const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
                            const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
-                           const float* log_alpha, float* q_out, float* pi_grad_params, float* workspace,
-                           int reduce_mode, void* stream);
+                           const float* log_alpha, const int32_t* subset, float* q_out, float* pi_grad_params,
+                           float* workspace, int reduce_mode, void* stream);
 
 /* The policy step's policy backward (sac_base.py:1883-1906, stock Gaussian-head ModelPolicy): the
  * gradient of the objective w.r.t. (loc | scale) — asac_squash_sample_bwd's math with dL/dlogp =

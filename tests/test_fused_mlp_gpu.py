@@ -188,9 +188,23 @@ def test_policy_step_in_one_launch_is_the_chain_bit_for_bit(N, S, A):
     got_partials = fpi._workspace[:tiles * fpi.member_stride].view(tiles, -1)[:, :used]
     assert torch.equal(got_partials, want_partials), 'per-tile partials'
     assert qgroup.grad.count_nonzero() == 0
-    # three critics, or too many rows for 16-row tiles: not eligible (the learner keeps the chain)
-    _, _, fq3 = _setup(3, S, A)
-    assert not fpi.policy_step_fused_ok(fq3, N) and not fpi.policy_step_fused_ok(fq, 4097)
+    assert not fpi.policy_step_fused_ok(fq, 4097)      # too many rows for 16-row tiles: the learner keeps the chain
+    # an ensemble of four with two sampled: only the subset's members are evaluated, in the subset's order
+    _, qgroup4, fq4 = _setup(4, S, A)
+    for pair in ((2, 0), (1, 3)):
+        sub = torch.tensor(pair, dtype=torch.int32, device='cuda')
+        q4 = fq4._launch_forward(x, a)
+        ga4 = fq4.backward_policy_q(x, a, q4.view(4, N), sub, 2)
+        pgroup.grad.zero_()
+        fpi.backward_policy_sample(x, eps, ga4, log_alpha)
+        want4 = pgroup.grad.clone()
+        q_out4 = torch.zeros(4, N, 1, device='cuda')
+        pgroup.grad.zero_()
+        fpi.policy_step_fused(fq4, x, a, eps, log_alpha, q_out=q_out4, subset=sub)
+        assert torch.equal(pgroup.grad, want4), pair
+        for e in pair:
+            assert torch.equal(q_out4[e], q4[e])
+        assert qgroup4.grad.count_nonzero() == 0
 
 
 @pytest.mark.parametrize('B,T,S,A,E,window', [(256, 5, 6, 2, 2, False), (256, 5, 6, 2, 2, True), (37, 3, 8, 4, 3, True),
