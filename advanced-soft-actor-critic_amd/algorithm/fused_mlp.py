@@ -378,15 +378,20 @@ class StockMLP:
                 native.policy_step_fused_ok(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
                                             self.member_stride, N))
 
-    def policy_step_fused(self, critics: 'StockMLP', x0, action, eps, log_alpha, q_out=None, defer=False, subset=None):
+    def policy_step_fused(self, critics: 'StockMLP', x0, action, eps, log_alpha, q_out=None, defer=False, subset=None,
+                          sample_out=None):
         """Gaussian-head policy (E = 1) against the TWO critics the objective samples (`subset`: device i32[2], None =
         members 0 and 1 of a two-member ensemble): the whole policy step in one launch (`asac_policy_step_fused`);
-        `q_out` [E, N, 1] receives those critics' values of (x0, action)."""
+        `q_out` [E, N, 1] receives those critics' values of (x0, action).  `action` None: the action is sampled inside
+        the launch (no policy-forward / sampling launch in front of it) and lands in `sample_out` = (a_tanh [N, A],
+        logp [N], ls [N, 2A] | None)."""
         N = x0.shape[-2]
         assert subset is not None or critics.E == 2
+        a_out, logp_out, ls_out = sample_out if action is None else (None, None, None)
         native.policy_step_fused(critics.desc, critics.params, critics.member_stride, self.desc, self.params,
                                  self.member_stride, x0, N, action, eps, log_alpha, q_out, self.grad_params,
-                                 self._workspace_for(N), self._reduce_mode(defer), subset=subset)
+                                 self._workspace_for(N), self._reduce_mode(defer), subset=subset, a_out=a_out,
+                                 logp_out=logp_out, ls_out=ls_out)
         self._deferred_rows = N if defer else None
 
     def adam_partials(self, opt, loss_out=None):

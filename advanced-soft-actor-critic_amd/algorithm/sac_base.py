@@ -1236,27 +1236,37 @@ class SAC_Base(AuxHeadsMixin):
         A, E = self.c_action_size, self.ensemble_q_num
         x = StockMLP._rows(state, self.state_size)
         B = x.shape[0]
-        if ls is None:
-            ls = self._fpi._launch_forward(x, None)[0]
-        loc, scale = ls[..., :A], ls[..., A:]
-        if self._pi_sampled:        # drawn by the target computation's launch from the same `ls`
-            a_tanh, logp, self._pi_sampled = self._pi_a, self._pi_logp, False
-        else:
+        fusable = (self._fused_policy_step and self.ensemble_q_sample == 2 and self._fpi.policy_step_fused_ok(self._fq, B))
+        sample_out = None
+        if ls is None and not self._pi_sampled and fusable:
+            # nothing of the policy's forward is at hand (trainable representation: the state is new): the one-launch
+            # policy step samples the action itself
+            f32 = dict(dtype=torch.float32, device=self.device)
             self.noise.normal_(self._eps_pi)
-            a_tanh = torch.empty((B, A), dtype=torch.float32, device=self.device)
-            logp = torch.empty(B, dtype=torch.float32, device=self.device)
-            native.squash_sample_fwd(loc, scale, self._eps_pi, a_tanh, logp)
+            sample_out = (torch.empty((B, A), **f32), torch.empty(B, **f32), torch.empty((B, 2 * A), **f32))
+            a_tanh, logp, scale = sample_out[0], sample_out[1], sample_out[2][:, A:]
+        else:
+            if ls is None:
+                ls = self._fpi._launch_forward(x, None)[0]
+            loc, scale = ls[..., :A], ls[..., A:]
+            if self._pi_sampled:        # drawn by the target computation's launch from the same `ls`
+                a_tanh, logp, self._pi_sampled = self._pi_a, self._pi_logp, False
+            else:
+                self.noise.normal_(self._eps_pi)
+                a_tanh = torch.empty((B, A), dtype=torch.float32, device=self.device)
+                logp = torch.empty(B, dtype=torch.float32, device=self.device)
+                native.squash_sample_fwd(loc, scale, self._eps_pi, a_tanh, logp)
         sub = self._subsets['pi_c']
         self.noise.subset_(sub, E)
         self._pi_stats_src = (logp, scale)
         opt = self.optimizer_policy
         fold = self._dist is None and (opt.start, opt.stop) == (self._fpi._start, self._fpi._start + self._fpi.member_stride)
-        if (self._fused_policy_step and self.ensemble_q_sample == 2 and a_tanh.is_contiguous()
-                and self._fpi.policy_step_fused_ok(self._fq, B)):
+        if fusable and a_tanh.is_contiguous():
             # two critics sampled (of two or more): critics forward, objective gradient, critics backward to the action,
             # sampling backward and policy backward in ONE launch (bit-identical to the chain below)
-            self._fpi.policy_step_fused(self._fq, x, a_tanh, self._eps_pi, self.log_c_alpha, q_out=self._pi_q, defer=fold,
-                                        subset=sub if E != 2 else None)
+            self._fpi.policy_step_fused(self._fq, x, None if sample_out is not None else a_tanh, self._eps_pi,
+                                        self.log_c_alpha, q_out=self._pi_q, defer=fold, subset=sub if E != 2 else None,
+                                        sample_out=sample_out)
         else:
             c_qs = self._fq._launch_forward(x, a_tanh, out=self._pi_q)                   # [E, B, 1]
             # objective gradients formed on chip: dL/dq inside the Q backward (from the value table), dL/dlogp =

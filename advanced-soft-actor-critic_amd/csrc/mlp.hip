@@ -1090,6 +1090,8 @@ struct PsLds {
     PsQLds q[2];                           // the policy phase's PsPiLds overlays this
     float ga[2][kPsRows * kHeadPad];       // the members' action gradients of the tile
     float qv[2][kPsRows];                  // the members' values of the tile's rows
+    float ls[kPsRows * 2 * kHeadPad];      // sampling on chip: (loc | scale) of the tile, row pitch 32
+    float act[kPsRows * kHeadPad];         // ... and the sampled actions
 };
 static_assert(sizeof(PsPiLds) <= 2 * sizeof(PsQLds), "the policy phase reuses the critics' LDS");
 
@@ -1097,6 +1099,12 @@ struct PolicyStepArgs {
     MlpArgs q, pi;          // q: x0 = states, x1 = sampled actions, subset = the TWO members the objective samples (device
                             // indices, NULL = members 0 and 1); pi: x0 = states, eps, log_alpha, partial
     float* q_out;           // [E][N] the value table (statistics; the two sampled members' rows are written) or NULL
+    // q.x1 == NULL: the action is SAMPLED HERE, tanh(loc + eps * scale) from a first run of the policy on the tile (its
+    // weights are in registers anyway and go to LDS twice), instead of arriving from a policy-forward and a sampling
+    // launch of its own; outputs for the statistics / the caller:
+    float* a_out;           // [N][A]
+    float* logp_out;        // [N]
+    float* ls_out;          // [N][2A] (loc | scale) or NULL
 };
 
 // a 16-row input tile with 512 threads: 2 of the 16 x 64 slots per thread
@@ -1176,8 +1184,9 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     // mean_b -min_{e in subset} q_e, so they are not evaluated at all); the order of the subset breaks ties
     const int e0 = a.q.subset ? a.q.subset[0] : 0, e1 = a.q.subset ? a.q.subset[1] : 1;
     const StageScalars s0 = stage_scalars<3>(a.q, e0), s1 = stage_scalars<3>(a.q, e1), sp = stage_scalars<3>(a.pi, 0);
-    float in_q[2], in_pi[2];
-    ps_fetch_tile(s0, row0, in_q);
+    const bool sample_here = a.q.x1 == nullptr;
+    float in_q[2] = {0.f, 0.f}, in_pi[2];
+    if (!sample_here) ps_fetch_tile(s0, row0, in_q);
     ps_fetch_tile(sp, row0, in_pi);
     StagedNet<kPsThreads> r0, r1, rp;
     net_fetch_fixed<kPsThreads, 3>(s0, r0);
@@ -1189,11 +1198,78 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
         if ((int)threadIdx.x < kPsRows * A && row0 + lrow < N) ev = a.pi.eps[(row0 + lrow) * A + d];
         gl = expf(*a.pi.log_alpha) * (1.f / (float)N);
     }
-    ps_put_tile(in_q, L.q[0].xs[0]);
-    ps_put_tile(in_q, L.q[1].xs[0]);
+    if (sample_here) {
+        // ---- the policy on the tile, once, for the action: weights -> LDS (they return from the registers later) ------
+        net_put_fixed<kPsThreads, 3>(rp, P);
+        ps_put_tile(in_pi, P.x[0]);
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (wave < 4) {
+                const float* xin = P.x[l & 1];
+                float* xout = P.x[(l & 1) ^ 1];
+                const f32x4 acc = l > 0 ? gemm_tile(xin, P.w[l], kMaxW, 0, wave) : gemm_tile(xin, P.w[l], round4(K0p), 0, wave);
+                const int pc = wave * 16 + (lane & 15);
+                const float bias = P.bias[l][pc];
+                const bool res = a.pi.d.residual[l] != 0;
+                f32x2_g ya, yb, unused;
+                gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
+                gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
+                const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    float y = yv[r];
+                    if (res) y += xin[row * kP + pc];
+                    xout[row * kP + pc] = y;
+                }
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {       // three layers: the last activations sit in P.x[1]
+            const f32x4 acc = gemm_tile(P.x[1], P.head, kMaxW, 0, 0);
+            const int hc = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = 4 * (lane >> 4) + r;
+                const float v = head_value(a.pi.d, hc, acc[r] + P.head_bias[hc]);
+                L.ls[lrow * 2 * kHeadPad + hc] = v;
+                if (a.ls_out && row0 + lrow < N && hc < 2 * A) a.ls_out[(row0 + lrow) * (2 * A) + hc] = v;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kPsRows) {      // one lane per row: the sampling launch's device function (asac_squash.h)
+            const int lrow = threadIdx.x;
+            const int64_t r = row0 + lrow;
+            float* arow = L.act + lrow * kHeadPad;
+            if (r < N) {
+                float lp;
+                squash_sample_at(L.ls + lrow * 2 * kHeadPad, L.ls + lrow * 2 * kHeadPad + A, a.pi.eps + r * A, A, arow, &lp, nullptr);
+                for (int d = 0; d < A; ++d) a.a_out[r * A + d] = arow[d];
+                a.logp_out[r] = lp;
+            } else {
+                for (int d = 0; d < A; ++d) arow[d] = 0.f;
+            }
+        }
+        __syncthreads();       // the policy is done with the LDS the critics' weights go to
+        ps_put_tile(in_pi, L.q[0].xs[0]);
+        ps_put_tile(in_pi, L.q[1].xs[0]);
+    } else {
+        ps_put_tile(in_q, L.q[0].xs[0]);
+        ps_put_tile(in_q, L.q[1].xs[0]);
+    }
     net_put_fixed<kPsThreads, 3>(r0, L.q[0]);
     net_put_fixed<kPsThreads, 3>(r1, L.q[1]);
     __syncthreads();
+    if (sample_here) {         // the sampled actions into the critics' input tiles
+        if ((int)threadIdx.x < kPsRows * A) {
+            const int lrow = threadIdx.x / A, d = threadIdx.x - lrow * A;
+            const float v = L.act[lrow * kHeadPad + d];
+            L.q[0].xs[0][lrow * kP + S + d] = v;
+            L.q[1].xs[0][lrow * kP + S + d] = v;
+        }
+        __syncthreads();
+    }
     MLP_STAMP(1);
 
     // ---- critics forward (derivatives of the activations stay in registers) ------------------------------------
@@ -2024,10 +2100,11 @@ int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_para
 int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
                            const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
                            const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
-                           const float* log_alpha, const int32_t* subset, float* q_out, float* pi_grad_params,
-                           float* workspace, int reduce_mode, void* stream) {
+                           const float* log_alpha, const int32_t* subset, float* q_out, float* a_tanh_out,
+                           float* logp_out, float* ls_out, float* pi_grad_params, float* workspace, int reduce_mode,
+                           void* stream) {
     if (!asac_policy_step_fused_ok(q_desc, q_params, q_member_stride, pi_desc, pi_params, pi_member_stride, N) ||
-        !x || !action || !eps || !log_alpha || !pi_grad_params || !workspace)
+        !x || !eps || !log_alpha || !pi_grad_params || !workspace || (!action && (!a_tanh_out || !logp_out)))
         return bad_arg("asac_policy_step_fused");
     PolicyStepArgs a{};
     const int A = pi_desc->head_cols[0];
@@ -2035,6 +2112,9 @@ int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params,
     a.pi = make_args(pi_desc, pi_params, pi_member_stride, x, x_row_stride, 0, nullptr, 0, 0, N);
     if (!offsets32(a.q) || !offsets32(a.pi)) return bad_arg("asac_policy_step_fused: offsets");
     a.q.subset = subset;
+    a.a_out = a_tanh_out;
+    a.logp_out = logp_out;
+    a.ls_out = ls_out;
     a.pi.eps = eps;
     a.pi.log_alpha = log_alpha;
     a.pi.partial = workspace;

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 45
+ABI_VERSION = 46
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -202,7 +202,8 @@ _SIGNATURES = {
                                             C.c_int64, C.c_int64]),
     'asac_policy_step_fused': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.POINTER(MlpDesc), C.c_void_p,
                                          C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'asac_mlp_param_extent': (C.c_int64, [C.POINTER(MlpDesc)]),
     'asac_adam_step_partials': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
                                           C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -835,7 +836,8 @@ def policy_step_fused_ok(q_desc, q_params, q_member_stride, pi_desc, pi_params, 
 
 @_profiled
 def policy_step_fused(q_desc, q_params, q_member_stride, pi_desc, pi_params, pi_member_stride, x, N, action, eps,
-                      log_alpha, q_out, pi_grad_params, workspace, reduce_mode, subset=None):
+                      log_alpha, q_out, pi_grad_params, workspace, reduce_mode, subset=None, a_out=None, logp_out=None,
+                      ls_out=None):
     """The stock networks' whole policy step (two critics) in one launch: critics forward on (x, action), objective
     gradient, critics backward to the action, sampling backward, policy backward (per-tile partials / reduced)."""
     global _last_work
@@ -843,12 +845,18 @@ def policy_step_fused(q_desc, q_params, q_member_stride, pi_desc, pi_params, pi_
                   + mlp_flops(pi_desc, 1, N, backward=True, param_grads=True))
     p0, rs0, _ = _rows_view(x)
     A = pi_desc.head_cols[0]
-    assert action.is_contiguous() and action.numel() == N * A and eps.is_contiguous() and eps.numel() == N * A
+    assert eps.is_contiguous() and eps.numel() == N * A
+    if action is not None:
+        assert action.is_contiguous() and action.numel() == N * A
+    else:       # sampled on chip
+        assert a_out.is_contiguous() and a_out.numel() == N * A and logp_out.is_contiguous() and logp_out.numel() == N
+        assert ls_out is None or (ls_out.is_contiguous() and ls_out.numel() == 2 * N * A)
     assert q_out is None or (q_out.is_contiguous() and q_out.numel() % N == 0 and q_out.numel() >= 2 * N)
     assert subset is None or (subset.dtype == torch.int32 and subset.numel() == 2)
     _check(load().asac_policy_step_fused(C.byref(q_desc), _p(q_params), q_member_stride, C.byref(pi_desc), _p(pi_params),
                                          pi_member_stride, p0, rs0, N, _p(action), _p(eps), _p(log_alpha), _p(subset),
-                                         _p(q_out), _p(pi_grad_params), _p(workspace), int(reduce_mode), _stream()),
+                                         _p(q_out), _p(a_out), _p(logp_out), _p(ls_out), _p(pi_grad_params), _p(workspace),
+                                         int(reduce_mode), _stream()),
            'asac_policy_step_fused')
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 45
+#define ASAC_ABI_VERSION 46
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -551,6 +551,9 @@ int asac_mlp_backward_policy_q(const asac_mlp_desc_t* desc_host, const float* pa
  * per-tile parameter-gradient partials (workspace, tiles = asac_mlp_backward_tiles(N, 1); reduce_mode as above)
  * and the value table q_out [2][N] (optional) leaves the chip.
  *   x [N] rows of in0 floats (row stride x_row_stride), action [N][A] = tanh(loc + eps * scale), eps [N][A].
+ *   action == NULL: the action is sampled HERE from a first run of the policy on the tile (what asac_mlp_forward +
+ *   asac_squash_sample_fwd would have produced, bit for bit) and stored in a_tanh_out [N][A] with its log-probability
+ *   logp_out [N] and, optionally, the policy's output ls_out [N][2A] (loc | scale).
  * asac_policy_step_fused_ok: 1 when the shapes qualify (both networks three 64-wide blocks on <= 64 inputs with
  * 16-byte aligned weights, scalar-head critics on (in0 | A), Gaussian-head policy on in0, N <= 4096). */
 int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
@@ -558,8 +561,9 @@ int asac_policy_step_fused_ok(const asac_mlp_desc_t* q_desc, const float* q_para
 int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params, int64_t q_member_stride,
                            const asac_mlp_desc_t* pi_desc, const float* pi_params, int64_t pi_member_stride,
                            const float* x, int64_t x_row_stride, int64_t N, const float* action, const float* eps,
-                           const float* log_alpha, const int32_t* subset, float* q_out, float* pi_grad_params,
-                           float* workspace, int reduce_mode, void* stream);
+                           const float* log_alpha, const int32_t* subset, float* q_out, float* a_tanh_out,
+                           float* logp_out, float* ls_out, float* pi_grad_params, float* workspace, int reduce_mode,
+                           void* stream);
 
 /* The policy step's policy backward (sac_base.py:1883-1906, stock Gaussian-head ModelPolicy): the
  * gradient of the objective w.r.t. (loc | scale) — asac_squash_sample_bwd's math with dL/dlogp =

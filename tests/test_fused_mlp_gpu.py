@@ -188,6 +188,13 @@ def test_policy_step_in_one_launch_is_the_chain_bit_for_bit(N, S, A):
     got_partials = fpi._workspace[:tiles * fpi.member_stride].view(tiles, -1)[:, :used]
     assert torch.equal(got_partials, want_partials), 'per-tile partials'
     assert qgroup.grad.count_nonzero() == 0
+    # the action sampled inside the launch == policy forward + sampling launch in front of it
+    a_g, lp_g, ls_g = torch.zeros(N, A, device='cuda'), torch.zeros(N, device='cuda'), torch.zeros(N, 2 * A, device='cuda')
+    pgroup.grad.zero_()
+    q_out.zero_()
+    fpi.policy_step_fused(fq, x, None, eps, log_alpha, q_out=q_out, sample_out=(a_g, lp_g, ls_g))
+    assert torch.equal(a_g, a) and torch.equal(lp_g, logp) and torch.equal(ls_g, ls), 'sampled on chip'
+    assert torch.equal(q_out, q) and torch.equal(pgroup.grad, want)
     assert not fpi.policy_step_fused_ok(fq, 4097)      # too many rows for 16-row tiles: the learner keeps the chain
     # an ensemble of four with two sampled: only the subset's members are evaluated, in the subset's order
     _, qgroup4, fq4 = _setup(4, S, A)

@@ -90,7 +90,7 @@ int main() {
         const int reps = 200;
         double acc[16] = {0};
         for (int r = 0; r < reps; ++r) {
-            asac_policy_step_fused(&dq, params, stride, &dp, params, stride, x0, S, N, act, eps, la, qout, grad, ws,
+            asac_policy_step_fused(&dq, params, stride, &dp, params, stride, x0, S, N, act, eps, la, nullptr, qout, nullptr, nullptr, nullptr, grad, ws,
                                    ASAC_MLP_REDUCE_DEFER, nullptr);
             hipDeviceSynchronize();
             unsigned long long st[32];
