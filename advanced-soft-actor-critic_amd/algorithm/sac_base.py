@@ -1128,11 +1128,16 @@ class SAC_Base(AuxHeadsMixin):
             with torch.no_grad():
                 x0 = StockMLP._rows(base.detach()[:, t], self.state_size)
                 a0 = StockMLP._rows(c_action, self.c_action_size)
-                t_q = self._ftq._launch_forward(x0, a0, out=self._tq_buf)
-                _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states.detach(), nx_actions,
+                # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window
+                states_y = nx_states.detach()
+                job_tq, t_q = self._ftq.job(x0, a0, out=self._tq_buf)
+                job_pi, ls_y = self._fpi.job(StockMLP._rows_in_place(states_y, self.state_size), None)
+                native.mlp_forward_multi([job_tq, job_pi])
+                _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, states_y, nx_actions,
                                      n_rewards, n_dones, n_mu_probs if self.use_n_step_is else None,
                                      eps_buf=self._eps_y, subset_prefix='y', y_out=self._y_buf,
-                                     policy_sample=policy_sample)
+                                     policy_sample=policy_sample,
+                                     ls=ls_y[0].view(*states_y.shape[:2], 2 * self.c_action_size))
                 w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                 g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
                                              self.clip_epsilon, self._loss_q_e, state_grads=True)
@@ -1616,7 +1621,7 @@ class SAC_Base(AuxHeadsMixin):
         # asac_sidecar.h): the mu-probability write-back elects in the sampling launch and writes in the TD error's
         # forward launch, which also carries the temperature step
         sc_elect = sc_write = sc_alpha = None
-        side_cq = td_q_table = None
+        side_cq = td_q_table = ls_td = None
         fused_b = False
         self._vtrace_sidecars = self._pending_alpha = None
         if stock and self.use_n_step_is:
@@ -1704,8 +1709,15 @@ class SAC_Base(AuxHeadsMixin):
                                                  sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None] or None)
                         td_q_table = td_q_table.view(self.ensemble_q_num, *bnx_states.shape[:2])
                     elif sc_write is not None or sc_alpha is not None:
+                        # ... with the policy over the TARGET states (the TD target's policy forward) riding along
                         job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                        native.mlp_forward_multi([job_q], sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
+                        jobs_td = [job_q]
+                        if not self.d_action_sizes and self.c_action_size:
+                            states_td = bnx_target_states[:, b:]
+                            job_pi_td, ls_td = self._fpi.job(StockMLP._rows_in_place(states_td, self.state_size), None)
+                            jobs_td.append(job_pi_td)
+                            ls_td = ls_td[0].view(*states_td.shape[:2], 2 * self.c_action_size)
+                        native.mlp_forward_multi(jobs_td, sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
                     else:
                         self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
@@ -1744,7 +1756,7 @@ class SAC_Base(AuxHeadsMixin):
             td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
                                     bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
                                     bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
-                                    ls=ls_win if td_sample is not None else None, sample=td_sample,
+                                    ls=ls_win if td_sample is not None else ls_td, sample=td_sample,
                                     stored_pi=probs_win if td_sample is not None else None, c_q=side_cq,
                                     q_table=td_q_table)
             assert not self._vtrace_sidecars, 'the TD error\'s return launch did not take its sidecars'
