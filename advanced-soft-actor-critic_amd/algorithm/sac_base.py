@@ -1621,7 +1621,7 @@ class SAC_Base(AuxHeadsMixin):
         # asac_sidecar.h): the mu-probability write-back elects in the sampling launch and writes in the TD error's
         # forward launch, which also carries the temperature step
         sc_elect = sc_write = sc_alpha = None
-        side_cq = td_q_table = ls_td = None
+        side_cq = td_q_table = ls_td = td_pi = td_rows = None
         fused_b = False
         self._vtrace_sidecars = self._pending_alpha = None
         if stock and self.use_n_step_is:
@@ -1673,7 +1673,19 @@ class SAC_Base(AuxHeadsMixin):
                     self._vtrace_sidecars = [sc_write]
                     fused_b = True
                 else:
-                    ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
+                    # the TD target's policy forward (over the TARGET states, where they are not the online ones) rides
+                    # beside the window's, its sample beside the window's elementwise jobs
+                    td_own = self.use_priority and not same_states
+                    if td_own:
+                        states_td = bnx_target_states[:, b:]
+                        td_rows = StockMLP._rows_in_place(states_td, self.state_size)
+                        job_win, ls_out = self._fpi.job(rows_win, None)
+                        job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
+                        native.mlp_forward_multi([job_win, job_pi_td])
+                        ls_win = ls_out[0].view(B_, L_, 2 * A)
+                        ls_td = ls_td_out[0].view(B_, n + 1, 2 * A)
+                    else:
+                        ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
                     # ... and ONE elementwise launch on it: the temperature step's sample, pi(stored actions)
                     # over the window, the TD target's sample
                     probs_win = torch.empty((B_, L_, A), **f32)
@@ -1686,6 +1698,12 @@ class SAC_Base(AuxHeadsMixin):
                         self.noise.normal_(self._eps_td)
                         td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
                         jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
+                    elif td_own:
+                        self.noise.normal_(self._eps_td)
+                        td_sample = (torch.empty((B_, n + 1, A), **f32), torch.empty((B_, n + 1), **f32))
+                        td_pi = torch.empty((B_, n + 1, A), **f32)
+                        jobs.append(native.squash_job(ls_td[..., :A], ls_td[..., A:], self._eps_td, *td_sample,
+                                                      action=bnx_actions[:, b:], prob_out=td_pi))
                     # (with priorities the TD error's online-Q launch follows and hosts the second pass + the temperature step)
                     if self.use_priority and self._use_sidecars and not self._parallel_branches and rb.sharded is None:
                         sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
@@ -1703,21 +1721,15 @@ class SAC_Base(AuxHeadsMixin):
                         # the TD error's online Q of (s_b, a_b) and its target ensemble on the sampled
                         # window actions: two networks, one launch
                         job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                        job_tq, td_q_table = self._ftq.job(StockMLP._rows(bnx_target_states, self.state_size),
-                                                          StockMLP._rows(td_sample[0], self.c_action_size))
+                        job_tq, td_q_table = self._ftq.job(
+                            td_rows if td_rows is not None else StockMLP._rows(bnx_target_states, self.state_size),
+                            StockMLP._rows(td_sample[0], self.c_action_size))
                         native.mlp_forward_multi([job_q, job_tq],
                                                  sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None] or None)
-                        td_q_table = td_q_table.view(self.ensemble_q_num, *bnx_states.shape[:2])
+                        td_q_table = td_q_table.view(self.ensemble_q_num, *td_sample[1].shape)
                     elif sc_write is not None or sc_alpha is not None:
-                        # ... with the policy over the TARGET states (the TD target's policy forward) riding along
                         job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                        jobs_td = [job_q]
-                        if not self.d_action_sizes and self.c_action_size:
-                            states_td = bnx_target_states[:, b:]
-                            job_pi_td, ls_td = self._fpi.job(StockMLP._rows_in_place(states_td, self.state_size), None)
-                            jobs_td.append(job_pi_td)
-                            ls_td = ls_td[0].view(*states_td.shape[:2], 2 * self.c_action_size)
-                        native.mlp_forward_multi(jobs_td, sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
+                        native.mlp_forward_multi([job_q], sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
                     else:
                         self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
@@ -1756,8 +1768,10 @@ class SAC_Base(AuxHeadsMixin):
             td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
                                     bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
                                     bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
-                                    ls=ls_win if td_sample is not None else ls_td, sample=td_sample,
-                                    stored_pi=probs_win if td_sample is not None else None, c_q=side_cq,
+                                    ls=None if td_sample is None else (ls_td if td_pi is not None else ls_win),
+                                    sample=td_sample,
+                                    stored_pi=None if td_sample is None else (td_pi if td_pi is not None else probs_win),
+                                    c_q=side_cq,
                                     q_table=td_q_table)
             assert not self._vtrace_sidecars, 'the TD error\'s return launch did not take its sidecars'
             rb.update(ids, td, sidecars=[sc for sc in (self._pending_alpha, hidden_write) if sc is not None] or None)
