@@ -215,6 +215,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
         self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
+        self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
         assert self._dist_sampling in ('throughput', 'parity')
@@ -1141,7 +1142,11 @@ class SAC_Base(AuxHeadsMixin):
                 w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                 g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
                                              self.clip_epsilon, self._loss_q_e, state_grads=True)
-                g_base = torch.zeros_like(base)
+                # d loss / d (window states): zero except at position t — a buffer that stays zero elsewhere, so only the
+                # slice is written each step (no memset launch)
+                g_base = self._g_state_base
+                if g_base is None or g_base.shape != base.shape:
+                    g_base = self._g_state_base = torch.zeros_like(base)
                 torch.sum(g0, dim=0, out=g_base[:, t])
             with direct_param_grads():
                 torch.autograd.backward([base], [g_base])
