@@ -317,6 +317,18 @@ class PrioritizedReplayBuffer:
         with torch.cuda.device(self.device):
             self._update_ids(ids.reshape(-1), td.reshape(-1).contiguous(), stale_check=True, sidecars=sidecars)
 
+    def td_update_ok(self, ids, n: int) -> bool:
+        return (self.sharded is None and isinstance(ids, torch.Tensor) and ids.dim() == 1 and ids.is_contiguous()
+                and native.td_update_ok(ids.numel(), n))
+
+    def td_update(self, vtrace_args, ids: torch.Tensor, sidecars=None, alpha_step=None) -> None:
+        """`update(ids, td)` where td is the TD error `vtrace_args` describes (native.VtraceArgs with q_online and
+        td_error_out set): return and priority update in one launch (reference sac_base.py:2182-2245 +
+        replay_buffer.py:412-427).  `alpha_step`: the temperature step to run first, if it is still pending."""
+        with torch.cuda.device(self.device):
+            native.td_update(vtrace_args, self._tree, self.capacity, ids, self._slot_ids, self.alpha, self.td_error_min,
+                             self.td_error_max, self._winner, self._nan_flag, sidecars=sidecars, alpha_step=alpha_step)
+
     def update_transitions(self, data_ids, key: str, data) -> None:
         """Overwrite `key` rows for ids still resident (replay_buffer.py:429-434); later duplicates
         win, like NumPy fancy assignment."""

@@ -214,6 +214,8 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
+        self._fused_td_update = bool(hip_config.get('fused_td_update', True))
+        self._td_update_with = None     # (replay buffer, ids): the TD error's return launch also updates the priorities
         self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
         self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
@@ -1021,8 +1023,13 @@ class SAC_Base(AuxHeadsMixin):
             sidecars = None
             if q_online is not None and self._vtrace_sidecars:     # the TD error's launch hosts the pending write-backs
                 sidecars, self._vtrace_sidecars = self._vtrace_sidecars, None
-            native.vtrace_return_min(args, sidecars=sidecars,
-                                     pending_alpha=self._pending_alpha if q_online is not None else None)
+            if q_online is not None and self._td_update_with is not None and args.td_error_out:
+                (rb, ids), self._td_update_with = self._td_update_with, None
+                rb.td_update(args, ids, sidecars=sidecars, alpha_step=self._pending_alpha)
+                self._pending_alpha = None
+            else:
+                native.vtrace_return_min(args, sidecars=sidecars,
+                                         pending_alpha=self._pending_alpha if q_online is not None else None)
             c_y = y_out.unsqueeze(-1)
         return d_y, c_y
 
@@ -1770,6 +1777,10 @@ class SAC_Base(AuxHeadsMixin):
                                                                hidden_rows, side=True)
             self._vtrace_sidecars = list(self._vtrace_sidecars or ()) + [h_elect]
         if self.use_priority:
+            # no write pass waiting for the update's launch: the TD error's return and the priority update are one launch
+            merged = (self._fused_td_update and hidden_write is None and self._use_sidecars and not self._parallel_branches
+                      and bool(self.c_action_size) and not self.d_action_sizes and rb.td_update_ok(ids, n))
+            self._td_update_with = (rb, ids) if merged else None
             td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
                                     bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
                                     bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
@@ -1779,8 +1790,12 @@ class SAC_Base(AuxHeadsMixin):
                                     c_q=side_cq,
                                     q_table=td_q_table)
             assert not self._vtrace_sidecars, 'the TD error\'s return launch did not take its sidecars'
-            rb.update(ids, td, sidecars=[sc for sc in (self._pending_alpha, hidden_write) if sc is not None] or None)
-            self._pending_alpha = None
+            if merged and self._td_update_with is None:
+                assert self._pending_alpha is None      # the return's launch ran the temperature step and the update
+            else:
+                self._td_update_with = None
+                rb.update(ids, td, sidecars=[sc for sc in (self._pending_alpha, hidden_write) if sc is not None] or None)
+                self._pending_alpha = None
         if self.seq_hidden_state_shape[-1] != 0 and hidden_write is None:
             rb.update_window_transitions(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
                                          next_hidden.detach().contiguous())

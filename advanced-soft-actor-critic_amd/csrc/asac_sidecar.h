@@ -58,28 +58,69 @@ struct AlphaAdamArgs {
 //   dL/dlog_alpha = mean_b(-logp_b) - target   into grad[slot], then Adam over the n (= 2) temperature
 // parameters [log_d_alpha, log_c_alpha] exactly as k_adam would.  Called by EVERY thread of a workgroup of >= 256
 // threads; the first 256 do the work in a fixed order (the result does not depend on the host kernel's size).
-__device__ __forceinline__ void alpha_adam_block(const AlphaAdamArgs& a, float* red /* LDS, 256 floats */) {
+// -> the new value of parameter `slot` (in every thread).
+// red[0] <- the sum of red[0..256) in the order of the halving tree (stride 128, 64, ... 1: red[i] += red[i + stride]).
+// The strides below a wave's width stay inside wave 0: lane exchanges, no barrier rounds — the same additions.
+// Called by every thread of the workgroup, red[] written and a barrier passed; returns after a barrier.
+__device__ __forceinline__ void alpha_reduce_256(float* red) {
     const int tid = threadIdx.x;
+    if (tid < 128) red[tid] += red[tid + 128];
+    __syncthreads();
+    if (tid < 64) {
+        float v = red[tid] + red[tid + 64];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+        if (tid == 0) red[0] = v;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float alpha_adam_block(const AlphaAdamArgs& a, float* red /* LDS, 256 floats */) {
+    const int tid = threadIdx.x;
+    // everything the step reads is requested before the reduction's barriers (one round of loads, not three); every
+    // thread also follows the parameter `slot` in registers: the new temperature is RETURNED, nobody re-reads it
+    const int64_t done = *a.steps_done;
     float part = 0.f;
     if (tid < 256)
         for (int b = tid; b < a.B; b += 256) part += -a.logp[b] - a.target;
+    const bool mine = tid < 256 && tid < a.n;
+    float p = 0.f, g = 0.f, m = 0.f, v = 0.f;
+    if (mine) p = a.param[tid], g = a.grad[tid], m = a.exp_avg[tid], v = a.exp_avg_sq[tid];
+    float ps = a.param[a.slot], ms = a.exp_avg[a.slot], vs = a.exp_avg_sq[a.slot];
+    // the bias corrections (two double-precision pow: the long pole of the step) by ONE wave — the second, idle once
+    // the reduction's first stage is through — while the first finishes the sum; a 1024-thread host workgroup would
+    // otherwise run them in all of its 16 waves, four deep on every SIMD
+    float step_size = 0.f, bc2_sqrt = 0.f;
+    if ((tid >> 6) == 1) {
+        const double t = (double)(done + 1);
+        step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));
+        bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
+    }
     if (tid < 256) red[tid] = part;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
+    if (tid < 128) red[tid] += red[tid + 128];
+    __syncthreads();
+    if (tid < 64) {                  // (the halving tree's last six strides stay inside wave 0: alpha_reduce_256)
+        float s = red[tid] + red[tid + 64];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (tid == 0) red[0] = s;
     }
+    if (tid == 64) red[192] = step_size, red[193] = bc2_sqrt;
+    __syncthreads();
     const float g_slot = red[0] / (float)a.B;
+    step_size = red[192], bc2_sqrt = red[193];
     if (tid == 0) a.grad[a.slot] = g_slot;
-    const int64_t done = *a.steps_done;
-    __syncthreads();                                   // every lane has read the counter
     if (a.advance && tid == 0) *a.steps_done = done + 1;
-    const double t = (double)(done + 1);
-    const float step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
+    if (mine) {
+        adam1(p, tid == a.slot ? g_slot : g, m, v, a.c, step_size, bc2_sqrt);
+        a.param[tid] = p, a.exp_avg[tid] = m, a.exp_avg_sq[tid] = v;
+    }
     if (tid < 256)
-        for (int i = tid; i < a.n; i += 256)
+        for (int i = tid + 256; i < a.n; i += 256)
             adam1(a.param[i], i == a.slot ? g_slot : a.grad[i], a.exp_avg[i], a.exp_avg_sq[i], a.c, step_size, bc2_sqrt);
+    adam1(ps, g_slot, ms, vs, a.c, step_size, bc2_sqrt);
+    return ps;
 }
 
 // The value the temperature parameter `slot` WILL have after alpha_adam_block(a), computed without writing anything:
@@ -98,10 +139,7 @@ __device__ __forceinline__ float alpha_adam_preview(const AlphaAdamArgs& a, floa
     const float bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
     red[tid] = part;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
+    alpha_reduce_256(red);
     const float g_slot = red[0] / (float)a.B;
     __syncthreads();                                    // (the caller reuses `red`)
     adam1(p, g_slot, m, v, a.c, step_size, bc2_sqrt);

@@ -6,6 +6,7 @@
 #include "asac_common.h"
 #include "asac_sidecar.h"
 #include "asac_squash.h"
+#include "asac_tree_update.h"
 #include "asac_vtrace.h"
 
 #include <cmath>
@@ -232,6 +233,87 @@ __global__ __launch_bounds__(256) void k_vtrace_return_min_sc(const VtraceDev v,
     vtrace_return_min_wg(v, lds, x.has_pending ? &x.pending : nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The step's last two launches as ONE: the TD errors' return (K4 with mean_e|q_e - y|) and the priority update (K6)
+// that consumes them.  The update is a single workgroup anyway (the tree climb is a chain of dependent rounds), so that
+// workgroup first forms the returns of all B rows itself — one round of loads for its B n items, the scan of a row by one
+// lane in the return kernel's association order (bit-identical) — and goes straight on to the election and the climb:
+// no launch boundary, no trip of the TD errors through memory before their first use.  A pending temperature step
+// (asac_sidecar.h ALPHA_ADAM) is RUN by this workgroup first (the return needs its result; nobody else reads the
+// temperature in this launch); sidecar jobs are workgroups 1...
+// LDS: [B][pitch] d_t | [B][pitch] c_t | [B] V(s_0), pitch = (n + 1) | 1.
+// ------------------------------------------------------------------------------------------------
+struct TdUpdateArgs {
+    asac_vtrace_args_t a;
+    float* tree;
+    const int64_t* ids;
+    const int64_t* slot_ids;
+    int32_t* winner;
+    int32_t* nan_flag;
+    int32_t capacity, levels, seg, has_alpha;
+    float alpha_pow, td_min, td_max;
+    AlphaAdamArgs alpha;
+};
+
+template <int NSC>
+__global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u, const SidecarsT<NSC> sc) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (blockIdx.x > 0) {
+        sidecar_run(sc, (int)blockIdx.x - 1, lds);
+        return;
+    }
+    const asac_vtrace_args_t& a = u.a;
+    const int n = a.n, B = a.B, pitch = (n + 1) | 1;
+    float* s_d = lds;
+    float* s_c = s_d + B * pitch;
+    float* s_v0 = s_c + B * pitch;
+    int* s_leaf = reinterpret_cast<int*>(s_v0 + ((B + 63) & ~63));      // [whole waves + 4]
+    // everything that does not wait for the TD errors is requested now: this thread's row id (-> its ring slot, the id
+    // map's entry: is the row still resident?), its item of the return; the temperature step's loads follow
+    const int row = threadIdx.x;
+    int64_t id = 0;
+    if (row < B) id = u.ids[row];
+    const int f0 = threadIdx.x;
+    const bool have0 = f0 < B * n;
+    VtraceStepRaw raw0{};
+    if (have0) raw0 = vtrace_step_load(a, f0 / n, f0 - (f0 / n) * n);
+    int leaf1 = 0;
+    if (row < B) {
+        const int slot = ring_slot(id, u.capacity);
+        if (u.slot_ids == nullptr || u.slot_ids[slot] == id) leaf1 = slot + u.capacity;
+    }
+    float log_alpha;
+    if (u.has_alpha) log_alpha = alpha_adam_block(u.alpha, lds);
+    else log_alpha = *a.log_alpha;
+    __syncthreads();
+    const float alpha = expf(log_alpha);
+    for (int f = threadIdx.x; f < B * n; f += blockDim.x) {
+        const int r = f / n, t = f - r * n;
+        float d, c;
+        const float v_t = f == f0 ? vtrace_step_finish(a, raw0, alpha, &d, &c) : vtrace_step_terms(a, r, t, alpha, &d, &c);
+        if (t == 0) s_v0[r] = v_t;
+        s_d[r * pitch + t] = d;
+        s_c[r * pitch + t] = c;
+    }
+    __syncthreads();
+    // what follows has one lane per ROW (B <= blockDim.x): waves without a row leave (a finished wave no longer counts
+    // at the barriers of the climb: 4 waves instead of 16 at each of them for a batch of 256)
+    if ((int)(threadIdx.x & ~63u) >= B) return;
+    float y = 0.f, td = 0.f;
+    if (row < B) {
+        y = s_v0[row] + vtrace_scan_row(s_d + row * pitch, s_c + row * pitch, n, u.seg);
+        float s = 0.f;
+        for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * B + row] - y);
+        td = s / (float)a.E_online;
+    }
+    // (the outputs are stored behind the election: a store in front of it would make its barrier wait for the
+    // acknowledgement from L2; this way it travels with the leaves')
+    const bool fine = sumtree_update_wg_own(u.tree, u.levels, B, leaf1, td, u.alpha_pow, u.td_min, u.td_max, u.nan_flag, s_leaf,
+                                            min((int)blockDim.x, (B + 63) & ~63),
+                                            [&] { if (row < B) a.y_out[row] = y, a.td_error_out[row] = td; });
+    if (!fine && row < B) a.y_out[row] = y, a.td_error_out[row] = td;
+}
+
 // precomputed-V variant of phase 1a (discrete / hybrid branches hand V in directly)
 __global__ __launch_bounds__(256) void k_vtrace_direct(const VtraceDev v, const float* __restrict__ v_n,
                                                        const float* __restrict__ v_next,
@@ -378,6 +460,17 @@ __global__ __launch_bounds__(256) void k_gauss_head_bwd(const float* __restrict_
 
 using namespace asac;
 
+static int set_lds_limit_fn(const void* fn, size_t bytes, bool& done, const char* where) {
+    if (done) return 0;
+    hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err != hipSuccess) {
+        set_error(err, where);
+        return (int)err;
+    }
+    done = true;
+    return 0;
+}
+
 extern "C" {
 
 int asac_squash_sample_fwd(const float* loc, const float* scale, int64_t ls_row_stride, const float* eps,
@@ -492,7 +585,7 @@ int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_si
         while (R > 1 && R * h.n > 512) R >>= 1;
     while (R > 1 && (size_t)(2 * R * v.pitch + R) * sizeof(float) > 64 * 1024) R >>= 1;
     v.R = R;
-    v.seg = huge ? 1 : 4;
+    v.seg = vtrace_scan_lanes(h.B, h.n);
     size_t lds = (size_t)(2 * R * v.pitch + R) * sizeof(float);
     if (lds > 64 * 1024) return bad_arg("asac_vtrace_return_min: n too large");
     if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);        // (a sidecar workgroup's reduction scratch)
@@ -514,6 +607,51 @@ int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_si
         }
     }
     return finish_launch("asac_vtrace_return_min");
+}
+
+int asac_td_update(const asac_vtrace_args_t* args_host, float* tree, int capacity, const int64_t* ids,
+                   const int64_t* slot_ids, float alpha, float td_min, float td_max, int32_t* winner, int32_t* nan_flag,
+                   const asac_sidecar_t* sidecars_host, int n_sidecars, const asac_sidecar_t* alpha_step, void* stream) {
+    if (!args_host) return bad_arg("asac_td_update");
+    const asac_vtrace_args_t& h = *args_host;
+    if (h.B <= 0 || h.B > kUpdateBlock || h.n <= 0 || !h.y_out || !h.q || h.E_sample <= 0 || h.E_sample > ASAC_MAX_ENSEMBLE ||
+        !h.q_online || h.E_online <= 0 || !h.td_error_out || (h.use_n_step_is && (!h.mu_prob || !h.pi_prob || h.A <= 0)))
+        return bad_arg("asac_td_update: return arguments");
+    if (!tree || capacity <= 0 || (capacity & (capacity - 1)) || !ids || !winner || !nan_flag)
+        return bad_arg("asac_td_update: tree arguments");
+    SidecarsDev sc{}, none{}, al{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_td_update: sidecar");
+    if (alpha_step && (alpha_step->kind != ASAC_SIDECAR_ALPHA_ADAM || sidecars_prepare(alpha_step, 1, al) ||
+                       h.log_alpha != alpha_step->param + alpha_step->slot))
+        return bad_arg("asac_td_update: temperature step");
+    const int pitch = (h.n + 1) | 1;
+    // the return's tiles, V(s_0), the leaves of the election (a whole number of waves)
+    size_t lds = (size_t)(2 * h.B * pitch + 2 * ((h.B + 63) & ~63) + 4) * sizeof(float);
+    if (lds > 128 * 1024) return bad_arg("asac_td_update: window too long for one workgroup");
+    if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
+    TdUpdateArgs u{};
+    const int threads = (int64_t)h.B * h.n <= 256 ? 256 : kUpdateBlock;
+    u.a = h;
+    u.tree = tree; u.ids = ids; u.slot_ids = slot_ids; u.winner = winner; u.nan_flag = nan_flag;
+    u.capacity = capacity; u.levels = ilog2(capacity); u.seg = vtrace_scan_lanes(h.B, h.n);
+    u.alpha_pow = alpha; u.td_min = td_min; u.td_max = td_max;
+    u.has_alpha = alpha_step ? 1 : 0;
+    if (alpha_step) u.alpha = al.j[0].alpha;
+    static bool attr1 = false, attr4 = false;
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: sidecars and the temperature step ride once)
+        const bool last = rep == g_launch_repeat - 1;
+        TdUpdateArgs ur = u;
+        if (!last) ur.has_alpha = 0;
+        const dim3 grid(1u + (unsigned)(last ? sc.blocks : 0));
+        if (sc.n <= 1) {
+            if (int rc = set_lds_limit_fn(reinterpret_cast<const void*>(k_td_update<1>), 128 * 1024, attr1, "asac_td_update")) return rc;
+            hipLaunchKernelGGL(k_td_update<1>, grid, dim3(threads), lds, as_stream(stream), ur, sidecars_first<1>(last ? sc : none));
+        } else {
+            if (int rc = set_lds_limit_fn(reinterpret_cast<const void*>(k_td_update<ASAC_MAX_SIDECARS>), 128 * 1024, attr4, "asac_td_update")) return rc;
+            hipLaunchKernelGGL(k_td_update<ASAC_MAX_SIDECARS>, grid, dim3(threads), lds, as_stream(stream), ur, last ? sc : none);
+        }
+    }
+    return finish_launch("asac_td_update");
 }
 
 int asac_vtrace_return_direct(const asac_vtrace_args_t* args_host, const float* v_n,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 46
+ABI_VERSION = 47
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -165,6 +165,9 @@ _SIGNATURES = {
     'asac_vtrace_return_min': (C.c_int, [C.POINTER(VtraceArgs), C.c_void_p]),
     'asac_vtrace_return_min_sc': (C.c_int, [C.POINTER(VtraceArgs), C.POINTER(Sidecar), C.c_int, C.POINTER(Sidecar),
                                             C.c_void_p]),
+    'asac_td_update': (C.c_int, [C.POINTER(VtraceArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.POINTER(Sidecar), C.c_int, C.POINTER(Sidecar),
+                                 C.c_void_p]),
     'asac_sumtree_update_sc': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                          C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Sidecar), C.c_int,
                                          C.c_void_p]),
@@ -639,6 +642,22 @@ def vtrace_return_min(args: VtraceArgs, sidecars=None, pending_alpha: 'Sidecar |
     _check(load().asac_vtrace_return_min_sc(C.byref(args), sc, n_sc,
                                             C.byref(pending_alpha) if pending_alpha is not None else None, _stream()),
            'asac_vtrace_return_min')
+
+
+def td_update_ok(B: int, n: int) -> bool:
+    """can `td_update` take a batch of B windows of n steps (one workgroup, its LDS)?"""
+    return 0 < B <= 1024 and (2 * B * ((n + 1) | 1) + 2 * ((B + 63) & ~63) + 4) * 4 <= 128 * 1024
+
+
+@_profiled
+def td_update(args: VtraceArgs, tree, capacity, ids, slot_ids, alpha, td_min, td_max, winner, nan_flag, sidecars=None,
+              alpha_step: 'Sidecar | None' = None):
+    """the TD errors' return (args.q_online / td_error_out set) + the priority update of `ids` with them: one launch"""
+    assert ids.dtype == torch.int64 and ids.numel() == args.B and winner.dtype == torch.int32
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_td_update(C.byref(args), _p(tree), capacity, _p(ids), _p(slot_ids), alpha, td_min, td_max,
+                                 _p(winner), _p(nan_flag), sc, n_sc,
+                                 C.byref(alpha_step) if alpha_step is not None else None, _stream()), 'asac_td_update')
 
 
 @_profiled

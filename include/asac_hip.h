@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 46
+#define ASAC_ABI_VERSION 47
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -359,6 +359,17 @@ int asac_vtrace_return_min(const asac_vtrace_args_t* args_host, void* stream);
  * (args.log_alpha must be its parameter slot); the job itself rides in a later launch (asac_sumtree_update_sc). */
 int asac_vtrace_return_min_sc(const asac_vtrace_args_t* args_host, const asac_sidecar_t* sidecars_host,
                               int n_sidecars, const asac_sidecar_t* pending_alpha, void* stream);
+/* The TD errors' return and the priority update that consumes them as ONE launch (asac_vtrace_return_min with
+ * q_online/td_error_out set, then asac_sumtree_update mode 0 over ids[0..B) with those TD errors): the update's single
+ * workgroup forms the B returns itself (bit-identical to the return kernel's) and goes on to the tree without a launch
+ * boundary.  `alpha_step` (optional): an ASAC_SIDECAR_ALPHA_ADAM job that precedes the return in the reference's order
+ * (sac_base.py:1913-1949 before 2182-2245) and has not run yet — the workgroup RUNS it first (args.log_alpha must be
+ * its parameter slot).  Sidecar jobs ride as workgroups 1...  Replaces sac_base.py:2182-2245 + replay_buffer.py:412-427
+ * for one batch; B <= 1024 and 2 B (n+2) + 2 B floats of LDS <= 128 KB.  The `winner` scratch is not touched (the
+ * last-writer election among the batch's rows runs on chip). */
+int asac_td_update(const asac_vtrace_args_t* args_host, float* tree, int capacity, const int64_t* ids,
+                   const int64_t* slot_ids, float alpha, float td_min, float td_max, int32_t* winner, int32_t* nan_flag,
+                   const asac_sidecar_t* sidecars_host, int n_sidecars, const asac_sidecar_t* alpha_step, void* stream);
 /* asac_sumtree_update (declared above) with sidecar jobs riding as extra workgroups */
 int asac_sumtree_update_sc(float* tree, int capacity, int k, const int64_t* ids, const int64_t* slot_ids,
                            const float* td_error, float alpha, float td_min, float td_max, int mode, int32_t* winner,

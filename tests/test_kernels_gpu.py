@@ -366,7 +366,7 @@ def test_return_with_the_pending_temperature_step(nat, golden_dir):
     la0 = float(np.asarray(g[f'{tag}_log_alpha']).reshape(-1)[0])
     alpha_logp = dev(rng.standard_normal(B).astype(np.float32) * 2)
 
-    def run(deferred):
+    def run(deferred, merged=False):
         seg = torch.tensor([0.3, la0], device='cuda')      # [log_d_alpha, log_c_alpha]
         state = [torch.zeros(2, device='cuda'), torch.full((2,), 0.01, device='cuda'), torch.full((2,), 1e-3, device='cuda')]
         steps = torch.tensor(7, dtype=torch.int64, device='cuda')
@@ -380,7 +380,9 @@ def test_return_with_the_pending_temperature_step(nat, golden_dir):
                          subset_n=sub_n, subset_next=sub_next, E_sample=Es)
         a.q_online, a.E_online, a.td_error_out = q_on.data_ptr(), E, td.data_ptr()
         job = nat.sidecar_alpha_adam(alpha_logp, -float(A), 1, seg, *state, 3e-4, 0.9, 0.999, 1e-8, steps, advance_counter=True)
-        if deferred:
+        if merged:      # ... and the return itself inside the priority update's launch, the temperature step in front
+            nat.td_update(a, tree, C, ids, slot_ids, 0.9, 0.01, 1.0, winner, nan_flag, alpha_step=job)
+        elif deferred:
             nat.vtrace_return_min(a, pending_alpha=job)
             assert float(seg[1]) == float(np.float32(la0)), 'the return launch only previews the step'
             nat.sumtree_update(tree, C, ids, slot_ids, td, 0.9, 0.01, 1.0, 0, winner, nan_flag, sidecars=[job])
@@ -390,9 +392,55 @@ def test_return_with_the_pending_temperature_step(nat, golden_dir):
             nat.sumtree_update(tree, C, ids, slot_ids, td, 0.9, 0.01, 1.0, 0, winner, nan_flag)
         return [y, td, seg, *state, steps, tree]
 
-    want, got = run(False), run(True)
+    want = run(False)
     assert float(want[2][1]) != float(np.float32(la0))
-    for name, w_, g_ in zip(('y', 'td', 'temperatures', 'grad', 'exp_avg', 'exp_avg_sq', 'steps', 'tree'), want, got):
+    for got in (run(True), run(True, merged=True)):
+        for name, w_, g_ in zip(('y', 'td', 'temperatures', 'grad', 'exp_avg', 'exp_avg_sq', 'steps', 'tree'), want, got):
+            assert torch.equal(w_, g_), name
+
+
+@pytest.mark.parametrize('B,n', [(256, 1), (256, 3), (64, 8), (300, 17), (1024, 5), (1000, 14)])
+@pytest.mark.parametrize('use_is,ordered', [(True, True), (False, True), (True, False)])
+def test_td_error_and_priority_update_in_one_launch(nat, B, n, use_is, ordered):
+    """asac_td_update == asac_vtrace_return_min (TD errors) + asac_sumtree_update, bit for bit: returns, TD errors, the
+    tree (duplicate ids: the last writer wins; stale ids are skipped) — ids in leaf order (the sampler's) and in any order."""
+    torch.manual_seed(B * 31 + n)
+    E, A, C = 3, 2, 2048
+    f = dict(device='cuda')
+    q = torch.randn(E, B, n + 1, **f)
+    logp, log_alpha = torch.randn(B, n + 1, **f), torch.tensor([-1.2], **f)
+    reward, done = torch.randn(B, n, **f), torch.rand(B, n, **f) < 0.1
+    last, pad = torch.rand(B, n, **f) < 0.05, torch.rand(B, n, **f) < 0.1
+    mu, pi = torch.rand(B, n, A, **f) + 0.05, torch.rand(B, n + 1, A, **f) + 0.05
+    gr, lr = torch.logspace(0, n - 1, n, 0.99).cuda(), torch.logspace(0, n - 1, n, 0.95).cuda()
+    q_on = torch.randn(E, B, **f)
+    ids = torch.randint(0, C, (B,), device='cuda')
+    ids[B // 2:B // 2 + 8] = ids[:8]                    # duplicates
+    if ordered:      # what the stratified sampler hands out: leaf order (duplicates are neighbours, stale rows between them)
+        ids = ids.sort().values
+    slot0 = torch.arange(C, dtype=torch.int64, device='cuda')
+    slot0[ids[3]] += C                                  # overwritten since it was sampled: skipped
+    start = DevTree(nat, C, extra=2 * 4096)
+    start.set_priorities(np.arange(C), np.random.default_rng(0).random(C).astype(np.float32))
+    base_tree = start.tree
+    rows = torch.randn(B, 4, **f)
+
+    def run(merged):
+        tree, slot_ids = base_tree.clone(), slot0.clone()
+        winner, nan_flag = torch.full((C + 2 * 4096,), -1, dtype=torch.int32, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+        y, td = torch.zeros(B, **f), torch.zeros(B, **f)
+        a = _vtrace_args(nat, q=q, logp=logp, log_alpha=log_alpha, reward=reward, done=done, last=last, pad=pad, mu=mu, pi=pi,
+                         A=A, gamma_ratio=gr, lambda_ratio=lr, gamma=0.99, rho=1.0, c=1.0, use_is=use_is, y=y,
+                         q_online=q_on, td=td)
+        if merged:
+            nat.td_update(a, tree, C, ids, slot_ids, 0.9, 0.01, 1.0, winner, nan_flag)
+        else:
+            nat.vtrace_return_min(a)
+            nat.sumtree_update(tree, C, ids, slot_ids, td, 0.9, 0.01, 1.0, 0, winner, nan_flag)
+        assert int(nan_flag) == 0 and bool((winner[:C] == -1).all())
+        return y, td, tree
+
+    for name, w_, g_ in zip(('y', 'td', 'tree'), run(False), run(True)):
         assert torch.equal(w_, g_), name
 
 
