@@ -1778,8 +1778,11 @@ class SAC_Base(AuxHeadsMixin):
             self._vtrace_sidecars = list(self._vtrace_sidecars or ()) + [h_elect]
         if self.use_priority:
             # no write pass waiting for the update's launch: the TD error's return and the priority update are one launch
+            # (one workgroup forms every return: it pays while each of its threads has at most one step of one window —
+            # measured: B 256 n 4 +2.5 %, B 512 n 3 -0.8 %, B 1024 n 3 -0.3 %)
             merged = (self._fused_td_update and hidden_write is None and self._use_sidecars and not self._parallel_branches
-                      and bool(self.c_action_size) and not self.d_action_sizes and rb.td_update_ok(ids, n))
+                      and bool(self.c_action_size) and not self.d_action_sizes and ids.numel() * n <= 1024
+                      and rb.td_update_ok(ids, n))
             self._td_update_with = (rb, ids) if merged else None
             td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
                                     bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
