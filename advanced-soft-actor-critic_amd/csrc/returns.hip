@@ -173,6 +173,15 @@ __device__ __forceinline__ void vtrace_return_min_wg(const VtraceDev& v, float* 
     const bool have0 = f0 < R * n && row0 + f0 / n < a.B;
     VtraceStepRaw raw0{};
     if (have0) raw0 = vtrace_step_load(a, row0 + f0 / n, f0 - (f0 / n) * n);
+    // ... and so are the online critics' values of the row this lane will finish (TD error variant)
+    float q_on[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int r = threadIdx.x / SEG, b = row0 + r;
+        if (a.td_error_out && r < R && b < a.B && threadIdx.x == r * SEG) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q_on[j] = a.q_online[(int64_t)min(j, a.E_online - 1) * a.B + b];
+        }
+    }
     float alpha = a.q ? expf(*a.log_alpha) : 0.f;
     if (pending) alpha = expf(alpha_adam_preview(*pending, lds));
     for (int f = threadIdx.x; f < R * n; f += blockDim.x) {
@@ -213,7 +222,13 @@ __device__ __forceinline__ void vtrace_return_min_wg(const VtraceDev& v, float* 
     a.y_out[b] = y;
     if (a.td_error_out) {
         float s = 0.f;
-        for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * a.B + b] - y);
+        if (a.E_online <= 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < a.E_online) s += fabsf(q_on[e] - y);
+        } else {
+            for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * a.B + b] - y);
+        }
         a.td_error_out[b] = s / (float)a.E_online;
     }
 }
@@ -278,9 +293,12 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     VtraceStepRaw raw0{};
     if (have0) raw0 = vtrace_step_load(a, f0 / n, f0 - (f0 / n) * n);
     int leaf1 = 0;
+    float q_on[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < B) {
         const int slot = ring_slot(id, u.capacity);
         if (u.slot_ids == nullptr || u.slot_ids[slot] == id) leaf1 = slot + u.capacity;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q_on[j] = a.q_online[(int64_t)min(j, a.E_online - 1) * B + row];
     }
     float log_alpha;
     if (u.has_alpha) log_alpha = alpha_adam_block(u.alpha, lds);
@@ -303,11 +321,16 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     if (row < B) {
         y = s_v0[row] + vtrace_scan_row(s_d + row * pitch, s_c + row * pitch, n, u.seg);
         float s = 0.f;
-        for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * B + row] - y);
+        if (a.E_online <= 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < a.E_online) s += fabsf(q_on[e] - y);
+        } else {
+            for (int e = 0; e < a.E_online; ++e) s += fabsf(a.q_online[(int64_t)e * B + row] - y);
+        }
         td = s / (float)a.E_online;
     }
-    // (the outputs are stored behind the election: a store in front of it would make its barrier wait for the
-    // acknowledgement from L2; this way it travels with the leaves')
+    // (the outputs are stored with the leaves, behind the election)
     const bool fine = sumtree_update_wg_own(u.tree, u.levels, B, leaf1, td, u.alpha_pow, u.td_min, u.td_max, u.nan_flag, s_leaf,
                                             min((int)blockDim.x, (B + 63) & ~63),
                                             [&] { if (row < B) a.y_out[row] = y, a.td_error_out[row] = td; });
