@@ -92,8 +92,10 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd',
               'asac_adam_step_partials': 'asac::k_adam_partials', 'asac_adam_step': 'asac::k_adam',
               'asac_step_prologue': 'asac::k_noise_fill', 'asac_policy_sample_q_forward': 'asac::k_pi_sample_q',
-              'asac_policy_step_fused': 'asac::k_policy_step', 'asac_rows_move': 'asac::k_rows_move'}
-SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min')
+              'asac_policy_step_fused': 'asac::k_policy_step', 'asac_rows_move': 'asac::k_rows_move',
+              'asac_td_update': 'asac::k_td_update'}
+SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
+                 'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
 ROUND = 'r02'
 
 
@@ -158,6 +160,8 @@ def algorithmic_bytes(P_polyak, P_seg):
         'asac_squash_prob': B * (n + 1) * A * 4 * 4,
         'asac_polyak': 12 * P_polyak,                                    # K5
         'asac_sumtree_update': B * (4 + 8 + 8 + 4) + 12 * B * D,         # K6
+        'asac_td_update': B * (n * (4 + 1 + 1 + 1 + 4 + 4) + E * (n + 1) * 4 + (n + 1) * 4 + 4) + B * (4 * E + 4)   # K4 (TD error)
+        + B * (8 + 8 + 4) + 12 * B * D,                                  # + K6 (the TD errors stay in registers)
         'asac_scatter_rows_if_id_match': B * (b + n) * (8 + 4 * A),      # K7 (mu_prob)
         'asac_q_loss_fwd_bwd': E * B * 4 * 3 + B * 8,
         'asac_adam_step': 28 * P_seg,
