@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     const int n = a.n, B = a.B, pitch = (n + 1) | 1;
     float* s_d = lds;
     float* s_c = s_d + B * pitch;
-    float* s_v0 = s_c + B * pitch;
+    float* s_v0 = lds + ((2 * B * pitch + 3) & ~3);                     // (16-byte aligned: so are the arrays behind it)
     int* s_leaf = reinterpret_cast<int*>(s_v0 + ((B + 63) & ~63));      // [whole waves + 4]
     // everything that does not wait for the TD errors is requested now: this thread's row id (-> its ring slot, the id
     // map's entry: is the row still resident?), its item of the return; the temperature step's loads follow
@@ -649,7 +649,7 @@ int asac_td_update(const asac_vtrace_args_t* args_host, float* tree, int capacit
         return bad_arg("asac_td_update: temperature step");
     const int pitch = (h.n + 1) | 1;
     // the return's tiles, V(s_0), the leaves of the election (a whole number of waves)
-    size_t lds = (size_t)(2 * h.B * pitch + 2 * ((h.B + 63) & ~63) + 4) * sizeof(float);
+    size_t lds = (size_t)(((2 * h.B * pitch + 3) & ~3) + 2 * ((h.B + 63) & ~63) + 4) * sizeof(float);
     if (lds > 128 * 1024) return bad_arg("asac_td_update: window too long for one workgroup");
     if (lds < 256 * sizeof(float)) lds = 256 * sizeof(float);
     TdUpdateArgs u{};

@@ -646,7 +646,7 @@ def vtrace_return_min(args: VtraceArgs, sidecars=None, pending_alpha: 'Sidecar |
 
 def td_update_ok(B: int, n: int) -> bool:
     """can `td_update` take a batch of B windows of n steps (one workgroup, its LDS)?"""
-    return 0 < B <= 1024 and (2 * B * ((n + 1) | 1) + 2 * ((B + 63) & ~63) + 4) * 4 <= 128 * 1024
+    return 0 < B <= 1024 and (((2 * B * ((n + 1) | 1) + 3) & ~3) + 2 * ((B + 63) & ~63) + 4) * 4 <= 128 * 1024
 
 
 @_profiled
