@@ -245,16 +245,18 @@ class DeviceNoise:
     def begin_step_with_sample(self, step_counter, rb, flat, subsets=None, ensemble: int = 0, polyak=None,
                                zero=None) -> bool:
         """`begin_step` and the replay buffer's stratified sample (`rb.sample_into_static`'s tree walk) as ONE launch
-        when that form applies (this source feeds the sampler, batch <= 1024, weights normalised locally);
-        -> whether it did (the caller then runs only the buffer's gather)."""
-        if (rb.uniform_source is not self or rb.min_ratio_reducer is not None or rb.sharded is not None
+        when that form applies (this source feeds the sampler, batch <= 1024); with a sharded replay
+        (`rb.min_ratio_reducer`) the launch leaves the IS weights to `rb.sample_into_static`, which needs the MIN over
+        ranks first;  -> whether it did (the caller then runs only the buffer's weights / gather)."""
+        if (rb.uniform_source is not self or rb.sharded is not None
                 or rb.batch_size > native.PROLOGUE_SAMPLE_MAX_BATCH):
             return False
         if subsets is not None and subsets.shape[1] == ensemble:
             subsets = None
         native.step_prologue_sample(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
                                     rb.capacity, rb.batch_size, rb._slot_ids, rb._beta, rb.beta_increment_per_sampling,
-                                    rb._leaf, rb._p, rb._ids, rb._w, rb._min_p)
+                                    rb._leaf, rb._p, rb._ids, rb._w if rb.min_ratio_reducer is None else None,
+                                    rb._min_p)
         self._prefilled = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
                            for t in (rb._u, flat, subsets) if t is not None]
         return True

@@ -281,10 +281,11 @@ class PrioritizedReplayBuffer:
             native.sumtree_sample(self._tree, C, B, self._u, self._slot_ids, self._beta,
                                   self.beta_increment_per_sampling, self._leaf, self._p, self._ids,
                                   self._w if reducer is None else None, self._min_p)
-        if reducer is not None and not sampled:
+        if reducer is not None:
             # sharded replay: weights are normalised by the GLOBAL minimum sampling ratio
             # (parallel.py): local min(p)/sum(p) -> MIN all-reduce -> stand-alone weight kernel
-            torch.div(self._min_p[0:1], self._tree[0:1], out=self._min_p[1:2])
+            if not sampled:       # (the step prologue's sampler stores the ratio itself)
+                torch.div(self._min_p[0:1], self._tree[0:1], out=self._min_p[1:2])
             reducer(self._min_p[1:2])
             native.per_is_weights(self._p, B, self._tree, self._min_p[1:2], self._beta,
                                   self.beta_increment_per_sampling, self._w)

@@ -1458,10 +1458,13 @@ class SAC_Base(AuxHeadsMixin):
 
     def _alpha_sidecar(self, logp):
         """the continuous-only temperature step (`_train_alpha`'s one-launch form) as a sidecar job, or None when
-        that form does not apply (data parallel, an optimizer over more than the two temperatures)"""
+        that form does not apply (an optimizer over more than the two temperatures).  Data parallel: the caller
+        averages `logp` over the ranks between the launch that writes it and the launch that hosts the job
+        (`_alpha_logp_over_ranks`): the gradient mean_b(-logp_b) - target is linear in it, so the job then applies the
+        rank-averaged gradient — one collective on B floats instead of gradient launch + collective + Adam launch"""
         seg0, seg1 = self._params.segments['alpha']
         opt = self.optimizer_alpha
-        if self._dist is not None or (opt.start, opt.stop) != (seg0, seg1) or self.d_action_sizes:
+        if (opt.start, opt.stop) != (seg0, seg1) or self.d_action_sizes:
             return None
         g = self._params
         last = self.curiosity is None and not self.use_rnd      # the step's last optimizer launch advances the counter
@@ -1469,6 +1472,10 @@ class SAC_Base(AuxHeadsMixin):
         return native.sidecar_alpha_adam(logp, self.target_c_alpha * -float(self.c_action_size), 1, g.flat[seg0:seg1],
                                          g.grad[seg0:seg1], opt.exp_avg[seg0:seg1], opt.exp_avg_sq[seg0:seg1], opt.lr,
                                          opt.betas[0], opt.betas[1], opt.eps, opt.steps_done, advance_counter=last)
+
+    def _alpha_logp_over_ranks(self, logp) -> None:
+        if self._dist is not None:
+            self._dist.all_reduce_grads(logp, 0, logp.numel())
 
     def _train_curiosity(self, n_padding_masks, nx_states, n_actions):
         # the reference differentiates w.r.t. the model's parameters only (`backward(inputs=parameters)`,
@@ -1678,7 +1685,9 @@ class SAC_Base(AuxHeadsMixin):
                     if auto_alpha:
                         sc_alpha = self._alpha_sidecar(alpha_logp)
                     native.policy_sample_q_forward(job_b, [job_q], sidecars=[sc_elect])
-                    self._pending_alpha = sc_alpha      # (None: data parallel / a wider optimizer -> `_train_alpha` below)
+                    if sc_alpha is not None:
+                        self._alpha_logp_over_ranks(alpha_logp)
+                    self._pending_alpha = sc_alpha      # (None: a wider optimizer -> `_train_alpha` below)
                     ls_win = ls_out[0].view(B_, L_, 2 * A)
                     td_q_table = td_q_table.view(self.ensemble_q_num, B_, L_)
                     side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
@@ -1722,6 +1731,8 @@ class SAC_Base(AuxHeadsMixin):
                         if auto_alpha:
                             sc_alpha = self._alpha_sidecar(alpha_logp)
                     native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
+                    if sc_alpha is not None:
+                        self._alpha_logp_over_ranks(alpha_logp)
         # side stream from here to the end of the step: the TD error's online Q and the mu-probability
         # write-back (its own election scratch) beside the temperature step / TD target / tree update
         if probs_win is not None and not fused_b:

@@ -150,7 +150,12 @@ __device__ __forceinline__ void sumtree_sample_body(
         float bm = red[0];
         for (int w = 1; w < kSampleBlock / kWave; ++w) bm = fminf(bm, red[w]);
         red[0] = bm;
-        if (FUSE_WEIGHTS) {
+        if (FUSE_WEIGHTS && !w_out) {
+            // weights deferred (sharded replay: they are normalised by the minimum sampling ratio over ALL ranks'
+            // shards): min p and this shard's ratio out, beta untouched — asac_per_is_weights finishes after the MIN
+            min_p_out[0] = bm;
+            min_p_out[1] = bm / root;
+        } else if (FUSE_WEIGHTS) {
             const double b = fmin(1.0, *beta_state + beta_increment);
             *beta_state = b;
             s_beta = b;
@@ -164,7 +169,7 @@ __device__ __forceinline__ void sumtree_sample_body(
             atomicMin(reinterpret_cast<unsigned int*>(min_p_out), __float_as_uint(bm));
         }
     }
-    if (FUSE_WEIGHTS) {
+    if (FUSE_WEIGHTS && w_out) {
         __syncthreads();
         const float min_ratio = red[0] / root;                 // min(p/total) == min(p)/total
 #pragma unroll
@@ -218,6 +223,17 @@ __global__ void k_is_weights(const float* __restrict__ p, int batch, const float
     const double b = advance_beta ? fmin(1.0, *beta_state + beta_increment) : *beta_state;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch) w_out[i] = is_weight(p[i], *total, *min_ratio, b);
+}
+
+// ... the same for batches of one workgroup, beta advanced by the launch itself (every thread has read the old value)
+__global__ __launch_bounds__(256) void k_is_weights_advance(const float* __restrict__ p, int batch, const float* total,
+                                                            const float* min_ratio, double* beta_state,
+                                                            double beta_increment, float* __restrict__ w_out) {
+    const double b = fmin(1.0, *beta_state + beta_increment);
+    const float tot = *total, mr = *min_ratio;
+    __syncthreads();
+    if (threadIdx.x == 0) *beta_state = b;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x) w_out[i] = is_weight(p[i], tot, mr, b);
 }
 
 __global__ void k_advance_beta(double* beta_state, double beta_increment) {
@@ -422,7 +438,7 @@ int asac_step_prologue_sample(float* target, const float* source, int64_t n_poly
         return bad_arg("asac_step_prologue_sample");
     if (n_subsets > 0 && (!subsets_out || E_sample < 1 || E_sample > E || E > ASAC_MAX_ENSEMBLE))
         return bad_arg("asac_step_prologue_sample: subsets");
-    if (capacity <= 0 || (capacity & (capacity - 1)) || batch <= 0 || batch > kFusedSampleMax || !is_weights_out ||
+    if (capacity <= 0 || (capacity & (capacity - 1)) || batch <= 0 || batch > kFusedSampleMax ||
         !min_p_out || !tree || !slot_ids || !beta_state)
         return bad_arg("asac_step_prologue_sample: sampler");
     const int64_t lanes = (n_normal + 3) / 4 + (batch + 1) / 2 + n_subsets;
@@ -446,6 +462,11 @@ int asac_per_is_weights(const float* p, int batch, const float* total, const flo
     if (batch <= 0) return bad_arg("asac_per_is_weights");
     hipStream_t s = as_stream(stream);
     const int blocks = (batch + 255) / 256;
+    if (batch <= kFusedSampleMax && g_launch_repeat == 1) {
+        ASAC_LAUNCH(k_is_weights_advance, dim3(1), dim3(256), 0, s, p, batch, total, min_ratio, beta_state, beta_increment,
+                    is_weights_out);
+        return finish_launch("asac_per_is_weights");
+    }
     ASAC_LAUNCH(k_is_weights, dim3(blocks), dim3(256), 0, s, p, batch, total, min_ratio,
                        beta_state, beta_increment, is_weights_out, 1);
     ASAC_LAUNCH(k_advance_beta, dim3(1), dim3(1), 0, s, beta_state, beta_increment);

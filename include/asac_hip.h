@@ -788,7 +788,10 @@ int asac_step_prologue(float* target, const float* source, int64_t n_polyak, flo
 /* asac_step_prologue and the single-workgroup form of asac_sumtree_sample (batch <= 1024, IS weights fused) as ONE
  * launch, the first of a captured train step: workgroup 0 samples, drawing its n = `batch` stratified uniforms itself
  * (the very numbers asac_step_prologue would have stored in uniform_out, which it also fills), the other
- * workgroups are the prologue's.  replay_buffer.py:185-205, 347-354 + sac_base.py:745-764. */
+ * workgroups are the prologue's.  replay_buffer.py:185-205, 347-354 + sac_base.py:745-764.
+ * is_weights_out == NULL defers the weights (sharded replay: they are normalised by the minimum sampling ratio over
+ * all ranks' shards): min_p_out[0] = min p, min_p_out[1] = min p / total, beta untouched; after the MIN all-reduce of
+ * min_p_out[1], asac_per_is_weights advances beta and writes the weights. */
 int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
                               int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
                               float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,

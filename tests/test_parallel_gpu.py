@@ -95,6 +95,59 @@ def test_parity_sampling_single_rank_equals_plain_sampler():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('plugin,kw', [('nn_vec', dict(n_step=4, burn_in_step=0)),
+                                       ('nn_rnn', dict(n_step=3, burn_in_step=2, seq_encoder='RNN'))])
+@pytest.mark.parametrize('graph', [False, True])
+def test_throughput_mode_single_rank_equals_plain_step(plugin, kw, graph):
+    """world size 1 with the collectives forced on (`always=True`: every RCCL call of the data-parallel step is
+    issued, each an identity): the data-parallel step — sampler with deferred IS weights + MIN all-reduce, gradient
+    all-reduces in front of every Adam, the temperature step on the rank-averaged log-probabilities — must leave
+    bit-identical weights, priorities and write-backs to the plain step's, eagerly and as a captured graph."""
+    import torch.distributed as dist
+    import asac_amd  # noqa: F401
+    from algorithm.parallel import DataParallelContext
+    from algorithm.sac_base import SAC_Base
+    from algorithm.utils.enums import SEQ_ENCODER
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{_free_port()}', rank=0, world_size=1,
+                            device_id=torch.device('cuda:0'))
+    try:
+        kw = dict(kw)
+        hidden = (2, 8) if 'seq_encoder' in kw else (0,)
+        if 'seq_encoder' in kw:
+            kw['seq_encoder'] = SEQ_ENCODER.RNN
+
+        def make(ctx):
+            torch.manual_seed(5)
+            return SAC_Base(['vector'], [(6,)], [], 2, None, pu.plugin(plugin), device='cuda:0', batch_size=32, seed=11,
+                            replay_config={'capacity': 512},
+                            hip_config={'use_graph': graph, 'graph_warmup': 2, 'dist': ctx}, **kw)
+        plain, dp = make(None), make(DataParallelContext(always=True))
+        assert dp.replay_buffer.min_ratio_reducer is not None
+        dp._params.flat.copy_(plain._params.flat)
+        dp._target_params.flat.copy_(plain._target_params.flat)
+        rng = np.random.default_rng(0)
+        for T in (60, 45, 70, 80, 33):
+            ep = pu.synthetic_episode(rng, [(6,)], [], 2, hidden, T)
+            plain.put_episode(**ep)
+            dp.put_episode(**ep)
+        for step in range(6):
+            plain.train()
+            dp.train()
+            a, b = plain.replay_buffer, dp.replay_buffer
+            assert torch.equal(a._ids, b._ids), f'step {step}: ids'
+            assert torch.equal(a._w, b._w), f'step {step}: IS weights'
+            assert float(a._beta) == float(b._beta)
+            assert torch.equal(a._tree, b._tree), f'step {step}: priorities written back'
+            assert torch.equal(a._columns['mu_prob'], b._columns['mu_prob'])
+            assert torch.equal(plain._params.flat, dp._params.flat), f'step {step}: weights'
+        if graph:
+            assert plain._graph is not None and dp._graph is not None
+        plain.close()
+        dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _two_rank_worker(rank, port, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
