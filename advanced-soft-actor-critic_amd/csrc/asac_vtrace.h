@@ -1,6 +1,6 @@
 // Per-step and per-row pieces of the n-step V-trace return (reference sac_base.py:1244-1295, 1423-1464),
-// shared by the stand-alone return kernel (returns.hip), the Q backward that forms its own target
-// (mlp.hip) and the priority update that forms its own TD error (sumtree.hip).
+// shared by the stand-alone return kernels and the priority update that forms its own TD errors (returns.hip:
+// k_vtrace_return_min(_sc), k_td_update).
 #pragma once
 #include "asac_common.h"
 

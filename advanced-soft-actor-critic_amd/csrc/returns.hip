@@ -255,8 +255,10 @@ __global__ __launch_bounds__(256) void k_vtrace_return_min_sc(const VtraceDev v,
 // lane in the return kernel's association order (bit-identical) — and goes straight on to the election and the climb:
 // no launch boundary, no trip of the TD errors through memory before their first use.  A pending temperature step
 // (asac_sidecar.h ALPHA_ADAM) is RUN by this workgroup first (the return needs its result; nobody else reads the
-// temperature in this launch); sidecar jobs are workgroups 1...
-// LDS: [B][pitch] d_t | [B][pitch] c_t | [B] V(s_0), pitch = (n + 1) | 1.
+// temperature in this launch); sidecar jobs are workgroups 1...  The ids, the id map's entries and the online
+// critics' values of the rows are requested at kernel entry, under the return's loads; the last writer of a leaf is
+// elected in LDS (asac_tree_update.h sumtree_update_wg_own): the `winner` scratch is not touched.
+// LDS: [B][pitch] d_t | [B][pitch] c_t | [B] V(s_0) | [B + 4] leaves, pitch = (n + 1) | 1, each part 16-byte aligned.
 // ------------------------------------------------------------------------------------------------
 struct TdUpdateArgs {
     asac_vtrace_args_t a;
