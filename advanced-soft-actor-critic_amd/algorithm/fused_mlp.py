@@ -355,6 +355,17 @@ class StockMLP:
         self._deferred_rows = N if defer else None
         return g0
 
+    def backward_qloss_return_ok(self, N: int, ret) -> bool:
+        return native.mlp_backward_qloss_return_ok(self.desc, self.params, self.member_stride, self.E, N, ret)
+
+    def backward_qloss_return(self, x0, x1, target_q, ret, weights, clip_eps, loss_out, defer=False):
+        """`backward_qloss` with the return target `ret` (native.VtraceArgs, its launch not issued) formed inside."""
+        N = x0.shape[-2]
+        native.mlp_backward_qloss_return(self.desc, self.params, self.member_stride, self.E, x0, x1, N, target_q, ret,
+                                         weights, clip_eps, loss_out, self.grad_params, self._workspace_for(N),
+                                         self._reduce_mode(defer))
+        self._deferred_rows = N if defer else None
+
     def backward_policy_q(self, x0, x1, q_table, subset, E_sample):
         """-> [E, N, in1] action gradients of mean_b(-min_{e in subset} q_e) (`q_table` [E, N] from the
         forward on the same inputs)."""

@@ -215,6 +215,9 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
         self._fused_td_update = bool(hip_config.get('fused_td_update', True))
+        self._fused_q_return = bool(hip_config.get('fused_q_return', True))
+        self._defer_return = False      # `_get_y`: hand the return's arguments back (`_deferred_return`) instead of launching
+        self._deferred_return = None
         self._td_update_with = None     # (replay buffer, ids): the TD error's return launch also updates the priorities
         self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
         self._g_state_base = None
@@ -1023,7 +1026,10 @@ class SAC_Base(AuxHeadsMixin):
             sidecars = None
             if q_online is not None and self._vtrace_sidecars:     # the TD error's launch hosts the pending write-backs
                 sidecars, self._vtrace_sidecars = self._vtrace_sidecars, None
-            if q_online is not None and self._td_update_with is not None and args.td_error_out:
+            if self._defer_return and q_online is None and sidecars is None:
+                # (the caller's Q-loss backward forms this return itself; everything `args` points to is the caller's)
+                self._deferred_return = (args, (q_tab, logp, c_pi, sub_n, sub_next))
+            elif q_online is not None and self._td_update_with is not None and args.td_error_out:
                 (rb, ids), self._td_update_with = self._td_update_with, None
                 rb.td_update(args, ids, sidecars=sidecars, alpha_step=self._pending_alpha)
                 self._pending_alpha = None
@@ -1088,10 +1094,14 @@ class SAC_Base(AuxHeadsMixin):
                 self._pi_sampled = True
             native.policy_sample_q_forward(fused, [job_tq])
             ls = ls[0].view(B, T, 2 * A)
+            # the return target is formed by the Q-loss backward's own workgroups where that form applies: its
+            # arguments are assembled as always, its launch is not issued
+            self._defer_return, self._deferred_return = self._fused_q_return, None
             _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
                                  n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
                                  subset_prefix='y', y_out=self._y_buf, ls=ls, sample=(a_y, logp_y), stored_pi=c_pi,
                                  q_table=q_tab.view(E, B, T))
+            self._defer_return = False
         else:
             # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window
             native.mlp_forward_multi([job_tq, job_pi])
@@ -1104,8 +1114,15 @@ class SAC_Base(AuxHeadsMixin):
         # GPU the tile reduction of the parameter gradients is folded into the Adam launch
         opt = self.optimizer_q_list[0]
         fold = self._dist is None and opt.start == self._fq._start and self._params.span('rep')[0] == self._params.span('rep')[1]
-        self._fq.backward_qloss(x0, a0, self._tq_buf.view(E, B), c_y.reshape(-1), w, self.clip_epsilon,
-                                self._loss_q_e, defer=fold)
+        ret, self._deferred_return = self._deferred_return, None
+        if ret is not None and self._fq.backward_qloss_return_ok(B, ret[0]):
+            self._fq.backward_qloss_return(x0, a0, self._tq_buf.view(E, B), ret[0], w, self.clip_epsilon, self._loss_q_e,
+                                           defer=fold)
+        else:
+            if ret is not None:
+                native.vtrace_return_min(ret[0])
+            self._fq.backward_qloss(x0, a0, self._tq_buf.view(E, B), c_y.reshape(-1), w, self.clip_epsilon,
+                                    self._loss_q_e, defer=fold)
         if fold:
             self._fq.adam_partials(opt, loss_out=self._loss_q_e)
         else:

@@ -23,6 +23,7 @@
 #include "asac_gelu.h"
 #include "asac_sidecar.h"
 #include "asac_squash.h"
+#include "asac_vtrace.h"
 
 #include <cmath>
 
@@ -782,8 +783,22 @@ __device__ __forceinline__ void grad_bias(const float* __restrict__ delta, int j
     if (lane < 16 && c < J) out[c] = s;
 }
 
-template <int TM, bool WIDE, int NB>
-__global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
+// RET: the Q-loss backward forms its own return target (asac_mlp_backward_qloss_return): every workgroup evaluates
+// the n-step V-trace return of ITS tile's rows (asac_vtrace.h: the return kernel's per-step terms and its scan
+// association, bit-identical) instead of reading y from a launch in front.  The (row, step) loads are issued right
+// behind the weight staging's — one round, travelling under it — so the tile's y is in LDS long before the loss phase
+// wants it: the return launch (K4) and its boundary leave the step's chain.  LDS behind the tile struct:
+// [TM][pitch] d_t | [TM][pitch] c_t | [TM] V(s_0) | [TM] y, pitch = (n + 1) | 1.
+template <bool RET>
+struct RetIn {};
+template <>
+struct RetIn<true> {
+    asac_vtrace_args_t v;
+    int32_t seg;              // vtrace_scan_lanes(B, n): the stand-alone kernel's scan association
+};
+
+template <int TM, bool WIDE, int NB, bool RET = false>
+__global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetIn<RET> rv) {
     constexpr int THREADS = threads_of<TM>();
     constexpr int RT = TM / 16;
     constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
@@ -820,8 +835,33 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
         }
         StagedNet<THREADS> regs;
         net_fetch_fixed<THREADS, NB>(q, regs);
-        put_input_tile<THREADS>(in_lo, L.x[0]);
-        net_put_fixed<THREADS, NB>(regs, L);
+        if constexpr (RET) {
+            const asac_vtrace_args_t& v = rv.v;
+            const int n = v.n, pitch = (n + 1) | 1;
+            float* s_d = reinterpret_cast<float*>(smem_raw + sizeof(MlpBwdLds<TM>));
+            float* s_c = s_d + TM * pitch;
+            float* s_v0 = s_c + TM * pitch;
+            const int f = threadIdx.x, fr = f / n, ft = f - fr * n;
+            const bool have = f < TM * n && row0 + fr < a.N;
+            VtraceStepRaw raw{};
+            float log_alpha = 0.f;
+            if (have) {
+                raw = vtrace_step_load(v, (int)(row0 + fr), ft);
+                log_alpha = *v.log_alpha;
+            }
+            put_input_tile<THREADS>(in_lo, L.x[0]);
+            net_put_fixed<THREADS, NB>(regs, L);
+            if (have) {
+                float d, cc;
+                const float v_t = vtrace_step_finish(v, raw, expf(log_alpha), &d, &cc);
+                if (ft == 0) s_v0[fr] = v_t;
+                s_d[fr * pitch + ft] = d;
+                s_c[fr * pitch + ft] = cc;
+            }
+        } else {
+            put_input_tile<THREADS>(in_lo, L.x[0]);
+            net_put_fixed<THREADS, NB>(regs, L);
+        }
         L.delta[r * kP + c] = gin;
     } else {
         float in_lo[4], in_hi[4];
@@ -843,6 +883,20 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
     }
     __syncthreads();
     MLP_STAMP(1);
+    if constexpr (RET) {     // one lane per row of the tile: y = V(s_0) + scan; first read in the loss phase (barriers between)
+        const asac_vtrace_args_t& v = rv.v;
+        const int n = v.n, pitch = (n + 1) | 1;
+        float* s_d = reinterpret_cast<float*>(smem_raw + sizeof(MlpBwdLds<TM>));
+        float* s_c = s_d + TM * pitch;
+        float* s_v0 = s_c + TM * pitch;
+        float* s_y = s_v0 + TM;
+        if ((int)threadIdx.x < TM && row0 + threadIdx.x < a.N) {
+            const int r = threadIdx.x;
+            const float y = s_v0[r] + vtrace_scan_row(s_d + r * pitch, s_c + r * pitch, n, rv.seg);
+            s_y[r] = y;
+            if (e == 0) v.y_out[row0 + r] = y;
+        }
+    }
 
     // ---- forward recompute ----------------------------------------------------------------------------
     f32x4 z[kMaxB];          // gelu'(pre-activation) of this wave's fragment, per block
@@ -954,9 +1008,17 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a) {
                     const int lrow = wave * 16 + 4 * (lane >> 4) + r;
                     const int64_t row = row0 + lrow;
                     float g = 0.f;
-                    if (row < a.N)
-                        part += clipped_q_loss_row(raw[r] + L.head_bias[0], a.tq[(int64_t)e * a.N + row], a.y[row],
+                    if (row < a.N) {
+                        float y_row;
+                        if constexpr (RET) {
+                            const int pitch = (rv.v.n + 1) | 1;
+                            y_row = reinterpret_cast<const float*>(smem_raw + sizeof(MlpBwdLds<TM>))[(2 * pitch + 1) * TM + lrow];
+                        } else {
+                            y_row = a.y[row];
+                        }
+                        part += clipped_q_loss_row(raw[r] + L.head_bias[0], a.tq[(int64_t)e * a.N + row], y_row,
                                                    a.w ? a.w[row] : 1.f, a.clip_eps, &g);
+                    }
                     L.delta[lrow * kP] = inv_n * g;
                 }
                 loss_red[wave * 4 + (lane >> 4)] = part;
@@ -1918,31 +1980,40 @@ static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const Si
 }
 
 template <int TM>
-static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int tiles, hipStream_t s) {
-    static bool attr_done = false, attr_wide = false, attr_stock = false;
+static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int tiles, hipStream_t s,
+                           const RetIn<true>* ret = nullptr) {
+    static bool attr_done = false, attr_wide = false, attr_stock = false, attr_ret = false;
     const bool wide = desc->in0 + desc->in1 > kMaxW;
     const bool stock = !wide && stock3(*desc, a.params, a.member_stride) && offsets32(a);
+    if (ret) {             // (asac_mlp_backward_qloss_return_ok has said yes: stock network, the tile's steps fit)
+        const size_t lds = sizeof(MlpBwdLds<TM>) + (size_t)(2 * ((ret->v.n + 1) | 1) + 2) * TM * sizeof(float);
+        if (!stock || TM * ret->v.n > threads_of<TM>() || lds > 128 * 1024) return bad_arg(where);
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, true>), 128 * 1024, attr_ret, where))
+            return rc;
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true>), dim3(tiles, E), dim3(threads_of<TM>()), lds, s, a, *ret);
+        return 0;
+    }
     if (int rc = wide    ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, true, 0>), sizeof(MlpBwdLds<TM>), attr_wide, where)
                  : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3>), sizeof(MlpBwdLds<TM>), attr_stock, where)
                          : set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 0>), sizeof(MlpBwdLds<TM>), attr_done, where))
         return rc;
     if (wide)
-        ASAC_LAUNCH((k_mlp_bwd<TM, true, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+        ASAC_LAUNCH((k_mlp_bwd<TM, true, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else if (stock)
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a);
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     return 0;
 }
 
 static int mlp_backward_common(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int64_t N,
                                int64_t member_stride, float* grad_params, float* workspace, int reduce_mode,
-                               float* loss_out, hipStream_t s) {
+                               float* loss_out, hipStream_t s, const RetIn<true>* ret = nullptr) {
     const int tiles = (int)asac_mlp_backward_tiles(N, E);
     a.partial = grad_params ? workspace : nullptr;
     a.loss_partial = workspace ? workspace + (int64_t)tiles * E * member_stride : nullptr;
-    if (int rc = mlp_tile_rows(N, E) == 16 ? launch_backward<16>(where, desc, a, E, tiles, s)
-                                           : launch_backward<32>(where, desc, a, E, tiles, s))
+    if (int rc = mlp_tile_rows(N, E) == 16 ? launch_backward<16>(where, desc, a, E, tiles, s, ret)
+                                           : launch_backward<32>(where, desc, a, E, tiles, s, ret))
         return rc;
     if (grad_params && reduce_mode != ASAC_MLP_REDUCE_DEFER) {
         const int64_t used = asac_mlp_param_extent(desc);
@@ -2246,6 +2317,45 @@ int asac_mlp_backward_qloss(const asac_mlp_desc_t* desc, const float* params, in
     return asac_mlp_backward_qloss_gx(desc, params, member_stride, E, x0, x0_row_stride, x0_member_stride, x1, x1_row_stride,
                                       x1_member_stride, N, target_q, y, weights, clip_eps, loss_out, nullptr, grad_params,
                                       workspace, reduce_mode, stream);
+}
+
+int asac_mlp_backward_qloss_return_ok(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,
+                                      int64_t N, const asac_vtrace_args_t* ret) {
+    if (!desc || !desc_ok(*desc) || !ret || E <= 0 || N <= 0 || ret->B != N || ret->n <= 0 || !ret->q || !ret->y_out ||
+        ret->E_sample <= 0 || ret->E_sample > ASAC_MAX_ENSEMBLE || ret->td_error_out)
+        return 0;
+    if (desc->in0 + desc->in1 > kMaxW || !stock3(*desc, params, member_stride)) return 0;
+    const int tm = mlp_tile_rows(N, E);
+    const size_t lds = (tm == 16 ? sizeof(MlpBwdLds<16>) : sizeof(MlpBwdLds<32>)) +
+                       (size_t)(2 * ((ret->n + 1) | 1) + 2) * tm * sizeof(float);
+    return tm * ret->n <= tm * 16 && lds <= 128 * 1024;
+}
+
+int asac_mlp_backward_qloss_return(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,
+                                   const float* x0, int64_t x0_row_stride, int64_t x0_member_stride,
+                                   const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
+                                   const float* target_q, const asac_vtrace_args_t* ret, const float* weights,
+                                   float clip_eps, float* loss_out, float* grad_params, float* workspace,
+                                   int reduce_mode, void* stream) {
+    if (!desc || !desc_ok(*desc) || E <= 0 || N <= 0 || !x0 || (desc->in1 > 0 && !x1) || !target_q || !ret ||
+        !grad_params || !workspace || clip_eps <= 0.f)
+        return bad_arg("asac_mlp_backward_qloss_return");
+    if (desc->head_cols[0] != 1 || desc->head_cols[1] != 0 || desc->head_transform != 0)
+        return bad_arg("asac_mlp_backward_qloss_return: not a scalar-head network");
+    if (reduce_mode != ASAC_MLP_REDUCE_DEFER && !loss_out) return bad_arg("asac_mlp_backward_qloss_return: loss_out");
+    if (!asac_mlp_backward_qloss_return_ok(desc, params, member_stride, E, N, ret) ||
+        (ret->use_n_step_is && (!ret->mu_prob || !ret->pi_prob || ret->A <= 0)))
+        return bad_arg("asac_mlp_backward_qloss_return: return arguments");
+    MlpArgs a = make_args(desc, params, member_stride, x0, x0_row_stride, x0_member_stride, x1, x1_row_stride,
+                          x1_member_stride, N);
+    if (!offsets32(a)) return bad_arg("asac_mlp_backward_qloss_return: offsets");
+    a.tq = target_q;
+    a.y = ret->y_out;
+    a.w = weights;
+    a.clip_eps = clip_eps;
+    RetIn<true> rv{*ret, vtrace_scan_lanes(ret->B, ret->n)};
+    return mlp_backward_common("asac_mlp_backward_qloss_return", desc, a, E, N, member_stride, grad_params, workspace,
+                               reduce_mode, loss_out, as_stream(stream), &rv);
 }
 
 int asac_mlp_backward_qloss_gx(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,

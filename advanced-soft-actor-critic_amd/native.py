@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 47
+ABI_VERSION = 48
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -191,6 +191,12 @@ _SIGNATURES = {
                                              C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_void_p]),
+    'asac_mlp_backward_qloss_return_ok': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_int64,
+                                                    C.POINTER(VtraceArgs)]),
+    'asac_mlp_backward_qloss_return': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                                 C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                                 C.POINTER(VtraceArgs), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_int, C.c_void_p]),
     'asac_mlp_backward_policy_q': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                              C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -818,6 +824,25 @@ def mlp_backward_qloss(desc, params, member_stride, E, x0, x1, N, target_q, y, w
                                              _p(target_q), _p(y), _p(weights), float(clip_eps), _p(loss_out), _p(grad_x0),
                                              _p(grad_params), _p(workspace), int(reduce_mode), _stream()),
            'asac_mlp_backward_qloss')
+
+
+def mlp_backward_qloss_return_ok(desc, params, member_stride, E, N, ret: VtraceArgs) -> bool:
+    return bool(load().asac_mlp_backward_qloss_return_ok(C.byref(desc), _p(params), member_stride, E, N, C.byref(ret)))
+
+
+@_profiled
+def mlp_backward_qloss_return(desc, params, member_stride, E, x0, x1, N, target_q, ret: VtraceArgs, weights, clip_eps,
+                              loss_out, grad_params, workspace, reduce_mode):
+    """`mlp_backward_qloss` whose workgroups form the return target `ret` describes themselves (no return launch)"""
+    global _last_work
+    _last_work = mlp_flops(desc, E, N, backward=True, param_grads=True)
+    p0, rs0, ms0 = _rows_view(x0)
+    p1, rs1, ms1 = _rows_view(x1)
+    assert target_q.is_contiguous() and target_q.numel() == E * N
+    _check(load().asac_mlp_backward_qloss_return(C.byref(desc), _p(params), member_stride, E, p0, rs0, ms0, p1, rs1, ms1,
+                                                 N, _p(target_q), C.byref(ret), _p(weights), float(clip_eps),
+                                                 _p(loss_out), _p(grad_params), _p(workspace), int(reduce_mode),
+                                                 _stream()), 'asac_mlp_backward_qloss_return')
 
 
 @_profiled

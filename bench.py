@@ -81,6 +81,7 @@ def synthetic_episode(rng, T):
 # entry point -> the kernel that does its work (rocprofv3 names; template arguments dropped)
 _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': 'asac::k_mlp_fwd_multi',
               'asac_mlp_backward': 'asac::k_mlp_bwd', 'asac_mlp_backward_qloss': 'asac::k_mlp_bwd',
+              'asac_mlp_backward_qloss_return': 'asac::k_mlp_bwd',
               'asac_mlp_backward_policy_q': 'asac::k_mlp_bwd', 'asac_mlp_backward_policy_sample': 'asac::k_mlp_bwd',
               'asac_window_gather_pad': 'asac::k_window_gather_pad', 'asac_vtrace_return_min': 'asac::k_vtrace_return_min',
               'asac_sumtree_sample': 'asac::k_sumtree_sample', 'asac_step_prologue_sample': 'asac::k_prologue_sample',

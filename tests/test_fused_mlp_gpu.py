@@ -114,6 +114,69 @@ def test_q_loss_backward_and_adam_from_partials(N, weighted):
     assert torch.equal(group.flat, want) and torch.equal(m, want_m)
 
 
+@pytest.mark.parametrize('B,n,E,Es,use_is', [(256, 4, 2, 2, True), (100, 1, 3, 2, True), (33, 7, 2, 2, False),
+                                              (1024, 3, 4, 2, True), (256, 16, 2, 2, True)])
+def test_q_loss_backward_forming_its_own_return_is_the_chain_bit_for_bit(B, n, E, Es, use_is):
+    """`asac_mlp_backward_qloss_return` == `asac_vtrace_return_min` followed by `asac_mlp_backward_qloss`: the return
+    target y, the per-member losses and every parameter gradient, bit for bit (reduced in the launch and deferred)."""
+    from asac_amd import native as nat
+    S, A, clip = 6, 2, 0.2
+    mods, group, mlp = _setup(E, S, A)
+    f = dict(device='cuda')
+    torch.manual_seed(B + n)
+    x, a = torch.randn(B, S, **f), torch.randn(B, A, **f).tanh()
+    tq = torch.randn(E, B, **f) * 0.3
+    w = torch.rand(B, **f) + 0.5
+    q = torch.randn(E, B, n + 1, **f)
+    logp, log_alpha = torch.randn(B, n + 1, **f), torch.tensor([-1.2], **f)
+    reward, done = torch.randn(B, n, **f), torch.rand(B, n, **f) < 0.1
+    last, pad = torch.rand(B, n, **f) < 0.05, torch.rand(B, n, **f) < 0.1
+    mu, pi = torch.rand(B, n, A, **f) + 0.05, torch.rand(B, n + 1, A, **f) + 0.05
+    gr, lr = torch.logspace(0, n - 1, n, 0.99).cuda(), torch.logspace(0, n - 1, n, 0.95).cuda()
+    sub_n = torch.randperm(E, **f)[:Es].to(torch.int32) if Es != E else None
+    sub_next = torch.randperm(E, **f)[:Es].to(torch.int32) if Es != E else None
+
+    def ret_args(y):
+        r = nat.VtraceArgs()
+        r.q = q.data_ptr()
+        r.q_stride_e, r.q_stride_b, r.q_stride_t = q.stride(0), q.stride(1), q.stride(2)
+        r.logp, r.log_alpha, r.E_sample = logp.data_ptr(), log_alpha.data_ptr(), Es
+        r.subset_n = sub_n.data_ptr() if sub_n is not None else None
+        r.subset_next = sub_next.data_ptr() if sub_next is not None else None
+        r.reward, r.reward_stride = reward.data_ptr(), reward.stride(0)
+        r.done, r.last_mask, r.padding_mask, r.mask_stride = done.data_ptr(), last.data_ptr(), pad.data_ptr(), done.stride(0)
+        if use_is:
+            r.mu_prob, r.mu_stride_b, r.mu_stride_t, r.mu_offset = mu.data_ptr(), mu.stride(0), mu.stride(1), 0
+            r.pi_prob, r.pi_stride_b, r.pi_stride_t, r.A = pi.data_ptr(), pi.stride(0), pi.stride(1), A
+        r.gamma_ratio, r.lambda_ratio = gr.data_ptr(), lr.data_ptr()
+        r.gamma, r.v_rho, r.v_c, r.use_n_step_is, r.B, r.n = 0.99, 1.0, 1.0, int(use_is), B, n
+        r.y_out = y.data_ptr()
+        return r
+
+    def run(fused, defer):
+        group.grad.zero_()
+        y, loss = torch.zeros(B, **f), torch.zeros(E, **f)
+        r = ret_args(y)
+        if fused:
+            assert mlp.backward_qloss_return_ok(B, r)
+            mlp.backward_qloss_return(x, a, tq, r, w, clip, loss, defer=defer)
+        else:
+            nat.vtrace_return_min(r)
+            mlp.backward_qloss(x, a, tq, y, w, clip, loss, defer=defer)
+        partials = mlp._workspace_for(B).clone() if defer else None
+        return y, loss.clone(), group.grad.clone(), partials
+
+    mlp.accumulate = False
+    for defer in (False, True):
+        want, got = run(False, defer), run(True, defer)
+        for name, w_, g_ in zip(('y', 'loss', 'grads', 'partials'), want, got):
+            if w_ is not None:
+                assert torch.equal(w_, g_), (name, defer)
+    r = ret_args(torch.zeros(B, **f))
+    r.n = 17
+    assert not mlp.backward_qloss_return_ok(B, r), 'more steps per tile than threads: the two launches'
+
+
 @pytest.mark.parametrize('N', [256, 45])
 def test_policy_step_fused_backwards_match_the_kernel_chain(N):
     """`asac_mlp_backward_policy_q` / `_policy_sample` against the launches they fold (objective kernel +
