@@ -454,7 +454,9 @@ def main():
                             'traffic_source': sorted(srcs) if traffic is not None else None,
                             'note': 'K1+K2 sample / IS weights (with the step prologue fused into the same launch: Polyak '
                                     'and the draws are counted in its bytes), K3 window gather, K4 return + ensemble min '
-                                    '(both launches); SURVEY.md §8d: at this batch the group moves < 1 MB per step, '
+                                    '(the launches that exist as such: where the return target is formed inside the Q-loss '
+                                    'backward and the TD error\'s return inside the priority update, the latter launch is '
+                                    'listed with its K4 + K6 bytes and the former is part of k_mlp_bwd); SURVEY.md §8d: at this batch the group moves < 1 MB per step, '
                                     'three orders below what HBM delivers in one launch latency — see `sweep`'}
 
     sweep = configs = None
