@@ -358,13 +358,15 @@ class StockMLP:
     def backward_qloss_return_ok(self, N: int, ret) -> bool:
         return native.mlp_backward_qloss_return_ok(self.desc, self.params, self.member_stride, self.E, N, ret)
 
-    def backward_qloss_return(self, x0, x1, target_q, ret, weights, clip_eps, loss_out, defer=False):
+    def backward_qloss_return(self, x0, x1, target_q, ret, weights, clip_eps, loss_out, defer=False, state_grads=False):
         """`backward_qloss` with the return target `ret` (native.VtraceArgs, its launch not issued) formed inside."""
         N = x0.shape[-2]
+        g0 = torch.empty((self.E, N, self.in0), dtype=torch.float32, device=self.device) if state_grads else None
         native.mlp_backward_qloss_return(self.desc, self.params, self.member_stride, self.E, x0, x1, N, target_q, ret,
                                          weights, clip_eps, loss_out, self.grad_params, self._workspace_for(N),
-                                         self._reduce_mode(defer))
+                                         self._reduce_mode(defer), grad_x0=g0)
         self._deferred_rows = N if defer else None
+        return g0
 
     def backward_policy_q(self, x0, x1, q_table, subset, E_sample):
         """-> [E, N, in1] action gradients of mean_b(-min_{e in subset} q_e) (`q_table` [E, N] from the

@@ -1158,14 +1158,24 @@ class SAC_Base(AuxHeadsMixin):
                 job_tq, t_q = self._ftq.job(x0, a0, out=self._tq_buf)
                 job_pi, ls_y = self._fpi.job(StockMLP._rows_in_place(states_y, self.state_size), None)
                 native.mlp_forward_multi([job_tq, job_pi])
+                self._defer_return, self._deferred_return = self._fused_q_return, None
                 _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, states_y, nx_actions,
                                      n_rewards, n_dones, n_mu_probs if self.use_n_step_is else None,
                                      eps_buf=self._eps_y, subset_prefix='y', y_out=self._y_buf,
                                      policy_sample=policy_sample,
                                      ls=ls_y[0].view(*states_y.shape[:2], 2 * self.c_action_size))
+                self._defer_return = False
                 w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
-                g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
-                                             self.clip_epsilon, self._loss_q_e, state_grads=True)
+                ret, self._deferred_return = self._deferred_return, None
+                if ret is not None and self._fq.backward_qloss_return_ok(x0.shape[-2], ret[0]):
+                    # (short windows: the return target is formed by the backward's own workgroups, no launch of its own)
+                    g0 = self._fq.backward_qloss_return(x0, a0, t_q.view(self.ensemble_q_num, -1), ret[0], w,
+                                                        self.clip_epsilon, self._loss_q_e, state_grads=True)
+                else:
+                    if ret is not None:
+                        native.vtrace_return_min(ret[0])
+                    g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
+                                                 self.clip_epsilon, self._loss_q_e, state_grads=True)
                 # d loss / d (window states): zero except at position t — a buffer that stays zero elsewhere, so only the
                 # slice is written each step (no memset launch)
                 g_base = self._g_state_base

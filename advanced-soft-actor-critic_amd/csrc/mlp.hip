@@ -2335,7 +2335,7 @@ int asac_mlp_backward_qloss_return(const asac_mlp_desc_t* desc, const float* par
                                    const float* x0, int64_t x0_row_stride, int64_t x0_member_stride,
                                    const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
                                    const float* target_q, const asac_vtrace_args_t* ret, const float* weights,
-                                   float clip_eps, float* loss_out, float* grad_params, float* workspace,
+                                   float clip_eps, float* loss_out, float* grad_x0, float* grad_params, float* workspace,
                                    int reduce_mode, void* stream) {
     if (!desc || !desc_ok(*desc) || E <= 0 || N <= 0 || !x0 || (desc->in1 > 0 && !x1) || !target_q || !ret ||
         !grad_params || !workspace || clip_eps <= 0.f)
@@ -2353,6 +2353,7 @@ int asac_mlp_backward_qloss_return(const asac_mlp_desc_t* desc, const float* par
     a.y = ret->y_out;
     a.w = weights;
     a.clip_eps = clip_eps;
+    a.gx0 = grad_x0;
     RetIn<true> rv{*ret, vtrace_scan_lanes(ret->B, ret->n)};
     return mlp_backward_common("asac_mlp_backward_qloss_return", desc, a, E, N, member_stride, grad_params, workspace,
                                reduce_mode, loss_out, as_stream(stream), &rv);

@@ -196,7 +196,7 @@ _SIGNATURES = {
     'asac_mlp_backward_qloss_return': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                                  C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                                  C.POINTER(VtraceArgs), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p, C.c_int, C.c_void_p]),
+                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'asac_mlp_backward_policy_q': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                              C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -832,16 +832,17 @@ def mlp_backward_qloss_return_ok(desc, params, member_stride, E, N, ret: VtraceA
 
 @_profiled
 def mlp_backward_qloss_return(desc, params, member_stride, E, x0, x1, N, target_q, ret: VtraceArgs, weights, clip_eps,
-                              loss_out, grad_params, workspace, reduce_mode):
+                              loss_out, grad_params, workspace, reduce_mode, grad_x0=None):
     """`mlp_backward_qloss` whose workgroups form the return target `ret` describes themselves (no return launch)"""
     global _last_work
     _last_work = mlp_flops(desc, E, N, backward=True, param_grads=True)
     p0, rs0, ms0 = _rows_view(x0)
     p1, rs1, ms1 = _rows_view(x1)
     assert target_q.is_contiguous() and target_q.numel() == E * N
+    assert grad_x0 is None or (grad_x0.is_contiguous() and grad_x0.numel() == E * N * desc.in0)
     _check(load().asac_mlp_backward_qloss_return(C.byref(desc), _p(params), member_stride, E, p0, rs0, ms0, p1, rs1, ms1,
                                                  N, _p(target_q), C.byref(ret), _p(weights), float(clip_eps),
-                                                 _p(loss_out), _p(grad_params), _p(workspace), int(reduce_mode),
+                                                 _p(loss_out), _p(grad_x0), _p(grad_params), _p(workspace), int(reduce_mode),
                                                  _stream()), 'asac_mlp_backward_qloss_return')
 
 

@@ -544,14 +544,14 @@ int asac_mlp_backward_qloss_gx(const asac_mlp_desc_t* desc_host, const float* pa
  * workgroup evaluates the n-step V-trace return `ret` describes for ITS tile's rows — the loads travel under the weight
  * staging, the per-step terms and the scan association are asac_vtrace_return_min's (bit-identical y) — so no return
  * launch precedes the Q step.  ret->y_out [N] is written as well (member 0's workgroups); ret->td_error_out must be
- * NULL, ret->B == N.  `_ok`: stock three-block network, n <= 16, the tile's steps fit LDS (otherwise: the two launches). */
+ * NULL, ret->B == N; grad_x0 as in asac_mlp_backward_qloss_gx (or NULL).  `_ok`: stock three-block network, n <= 16, the tile's steps fit LDS (otherwise: the two launches). */
 int asac_mlp_backward_qloss_return_ok(const asac_mlp_desc_t* desc_host, const float* params, int64_t member_stride, int E,
                                       int64_t N, const asac_vtrace_args_t* ret);
 int asac_mlp_backward_qloss_return(const asac_mlp_desc_t* desc_host, const float* params, int64_t member_stride, int E,
                                    const float* x0, int64_t x0_row_stride, int64_t x0_member_stride,
                                    const float* x1, int64_t x1_row_stride, int64_t x1_member_stride, int64_t N,
                                    const float* target_q, const asac_vtrace_args_t* ret, const float* weights,
-                                   float clip_eps, float* loss_out, float* grad_params, float* workspace,
+                                   float clip_eps, float* loss_out, float* grad_x0, float* grad_params, float* workspace,
                                    int reduce_mode, void* stream);
 
 /* The policy step's Q backward (sac_base.py:1896-1903): the gradient of mean_b(-min_{e in subset} q_e)

@@ -159,17 +159,17 @@ def test_q_loss_backward_forming_its_own_return_is_the_chain_bit_for_bit(B, n, E
         r = ret_args(y)
         if fused:
             assert mlp.backward_qloss_return_ok(B, r)
-            mlp.backward_qloss_return(x, a, tq, r, w, clip, loss, defer=defer)
+            g0 = mlp.backward_qloss_return(x, a, tq, r, w, clip, loss, defer=defer, state_grads=not defer)
         else:
             nat.vtrace_return_min(r)
-            mlp.backward_qloss(x, a, tq, y, w, clip, loss, defer=defer)
+            g0 = mlp.backward_qloss(x, a, tq, y, w, clip, loss, defer=defer, state_grads=not defer)
         partials = mlp._workspace_for(B).clone() if defer else None
-        return y, loss.clone(), group.grad.clone(), partials
+        return y, loss.clone(), group.grad.clone(), partials, g0
 
     mlp.accumulate = False
     for defer in (False, True):
         want, got = run(False, defer), run(True, defer)
-        for name, w_, g_ in zip(('y', 'loss', 'grads', 'partials'), want, got):
+        for name, w_, g_ in zip(('y', 'loss', 'grads', 'partials', 'state grads'), want, got):
             if w_ is not None:
                 assert torch.equal(w_, g_), (name, defer)
     r = ret_args(torch.zeros(B, **f))
