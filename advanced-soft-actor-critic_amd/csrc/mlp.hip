@@ -321,7 +321,8 @@ __device__ __forceinline__ float head_deriv(const asac_mlp_desc_t& d, int col, f
     return (raw >= -20.f && raw <= 0.5f) ? expf(raw) : 0.f;
 }
 
-struct MlpArgs {
+// (forward jobs carry only this part: kernel arguments are fetched on the launch's critical path, ~0.5-0.9 us per KB)
+struct MlpFwdArgs {
     asac_mlp_desc_t d;
     const float* params;
     int64_t member_stride;
@@ -335,6 +336,8 @@ struct MlpArgs {
     int32_t x0_T, pad_;
     int64_t N;
     float* out;          // [E][N][head columns]
+};
+struct MlpArgs : MlpFwdArgs {
     // backward only
     const float* gout;   // [E][N][head columns]
     float* gx0;          // [E][N][in0] or NULL
@@ -363,7 +366,7 @@ struct MlpArgs {
 // a TM x 64 input tile, 4 slots per thread: global -> registers (fetch) and registers -> LDS (put), so a tile
 // loop can have the next tile's rows in flight while the current one computes
 template <int THREADS, bool WINDOW = false>
-__device__ __forceinline__ void fetch_input_tile(const MlpArgs& a, int e, int64_t row0, float (&v)[4], int c0 = 0) {
+__device__ __forceinline__ void fetch_input_tile(const MlpFwdArgs& a, int e, int64_t row0, float (&v)[4], int c0 = 0) {
     // TM x 64 slots / (16 TM) threads = 4 each; columns >= in0+in1 are zero; c0 = 64: the second half of a wide input
     const int in0 = a.d.in0, in1 = a.d.in1;
 #pragma unroll
@@ -398,7 +401,7 @@ __device__ __forceinline__ void put_input_tile(const float (&v)[4], float* xs) {
 }
 
 template <int THREADS, bool WINDOW = false>
-__device__ __forceinline__ void load_input_tile(const MlpArgs& a, int e, int64_t row0, float* xs, int c0 = 0) {
+__device__ __forceinline__ void load_input_tile(const MlpFwdArgs& a, int e, int64_t row0, float* xs, int c0 = 0) {
     float v[4];
     fetch_input_tile<THREADS, WINDOW>(a, e, row0, v, c0);
     put_input_tile<THREADS>(v, xs);
@@ -419,7 +422,7 @@ struct StageScalars {
 #define ASAC_PIN(x) asm volatile("" : "+s"(x))
 
 template <int NB>
-__device__ __forceinline__ StageScalars stage_scalars(const MlpArgs& a, int e) {
+__device__ __forceinline__ StageScalars stage_scalars(const MlpFwdArgs& a, int e) {
     StageScalars q;
     q.P = a.params + e * a.member_stride;
     q.x0 = a.x0, q.x1 = a.d.in1 > 0 ? a.x1 : a.x0;
@@ -564,7 +567,7 @@ inline size_t mlp_fwd_lds_bytes(int n_blocks, bool wide = false, int TM = 32) {
 // are staged into LDS ONCE and reused by all of them (for window-sized inputs — tens of thousands of rows —
 // re-staging 36 KB of weights per tile would be most of the traffic).
 template <int TM, bool WINDOW, bool WIDE = false, int NB = 0>
-__device__ __forceinline__ void mlp_fwd_tiles(const MlpArgs& a, const int e, const int tile0, const int tile_stride,
+__device__ __forceinline__ void mlp_fwd_tiles(const MlpFwdArgs& a, const int e, const int tile0, const int tile_stride,
                                               MlpLds<TM>& L) {
     constexpr int THREADS = threads_of<TM>();
     constexpr int RT = TM / 16;                               // row tiles of a workgroup tile
@@ -666,7 +669,7 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpArgs& a, const int e, con
 }
 
 template <int TM, bool WIDE, int NB>
-__global__ __launch_bounds__(TM * 16) void k_mlp_fwd(const MlpArgs a) {
+__global__ __launch_bounds__(TM * 16) void k_mlp_fwd(const MlpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     mlp_fwd_tiles<TM, false, WIDE, NB>(a, blockIdx.y, blockIdx.x, gridDim.x, *reinterpret_cast<MlpLds<TM>*>(smem_raw));
 }
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_fwd(const MlpArgs a) {
 // Several independent forward passes (different networks / inputs) in ONE launch: blocks are dealt to the
 // jobs in order, a job's blocks to (tile, member) pairs.
 struct MlpMultiArgs {
-    MlpArgs job[ASAC_MLP_MAX_JOBS];
+    MlpFwdArgs job[ASAC_MLP_MAX_JOBS];
     int32_t E[ASAC_MLP_MAX_JOBS], first_block[ASAC_MLP_MAX_JOBS], tile_stride[ASAC_MLP_MAX_JOBS];
     int32_t n, blocks;      // jobs; workgroups of the jobs (sidecar workgroups follow)
 };
@@ -1543,7 +1546,7 @@ struct PiQCritic {       // a view with the member names net_put_fixed expects
 };
 
 struct PiQArgs {
-    MlpArgs pi, q;            // pi.out: [N][2A] (loc | scale) or NULL; q.out: [E][N]
+    MlpFwdArgs pi, q;            // pi.out: [N][2A] (loc | scale) or NULL; q.out: [E][N]
     int32_t E, tile_groups;   // critics; workgroups along the tile axis (they loop over the tiles)
     int32_t blocks;           // workgroups of the fused job = tile_groups * E
     // sampling (asac_squash_job_t): main sample over every row, optional stored-action probabilities, optional second
@@ -1911,14 +1914,14 @@ static bool stock3(const asac_mlp_desc_t& d, const float* params, int64_t member
     return true;
 }
 // ... and its 32-bit byte offsets need every row of the inputs within 2 GiB of the base
-static bool offsets32(const MlpArgs& a) {
+static bool offsets32(const MlpFwdArgs& a) {
     const int64_t lim = 0x7fffffffLL / 4;
     const int64_t span0 = a.x0_T > 0 ? (a.N / a.x0_T + 1) * a.x0_sb : a.N * a.x0_rs;
     return span0 + kMaxW < lim && a.N * a.x1_rs + kMaxW < lim && a.member_stride < lim;
 }
 
 template <int TM>
-static int launch_forward(const asac_mlp_desc_t* desc, const MlpArgs& a, int E, int64_t N, hipStream_t s) {
+static int launch_forward(const asac_mlp_desc_t* desc, const MlpFwdArgs& a, int E, int64_t N, hipStream_t s) {
     const bool wide = desc->in0 + desc->in1 > kMaxW;
     const size_t lds = mlp_fwd_lds_bytes(desc->n_blocks, wide, TM);
     const dim3 grid((unsigned)mlp_tile_groups(N, E, lds <= 80 * 1024 ? 2 : 1, TM), (unsigned)E);
