@@ -598,6 +598,50 @@ def test_step_prologue_is_polyak_plus_memset_plus_noise(nat, with_polyak, with_z
         assert whole.all()
 
 
+@pytest.mark.parametrize('B', [256, 700])
+def test_step_prologue_with_sampler_is_prologue_then_sampler(nat, B):
+    """`asac_step_prologue_sample` == `asac_step_prologue` followed by `asac_sumtree_sample` on the uniforms it drew:
+    leaves, priorities, ids, IS weights, beta, minimum, and the prologue's own outputs, bit for bit.  With the weights
+    deferred (is_weights_out = NULL: sharded replay) the launch leaves beta alone and stores min p and min p / total;
+    `asac_per_is_weights` on that ratio then writes the very same weights and advances beta, in one launch."""
+    C = 4096
+    rng = np.random.default_rng(5)
+    t = DevTree(nat, C, extra=2 * 4096)
+    idx = rng.permutation(C)[:3000]
+    t.set_priorities(idx, (rng.random(3000) + 0.01).astype(np.float32))
+    slot_ids = torch.arange(C, dtype=torch.int64, device='cuda') * 3 + 1
+    step = torch.full((1,), 11, dtype=torch.int64, device='cuda')
+    g = torch.Generator().manual_seed(1)
+    source = torch.randn(50_001, generator=g).cuda()
+    target0 = torch.randn(50_001, generator=g).cuda()
+
+    def outs():
+        return dict(leaf=torch.zeros(B, dtype=torch.int32, device='cuda'), p=torch.zeros(B, device='cuda'),
+                    ids=torch.zeros(B, dtype=torch.int64, device='cuda'), w=torch.zeros(B, device='cuda'),
+                    beta=torch.tensor([0.4], dtype=torch.float64, device='cuda'), minp=torch.zeros(2, device='cuda'),
+                    u=torch.zeros(B, dtype=torch.float64, device='cuda'), z=torch.zeros(1001, device='cuda'),
+                    target=target0.clone(), grad=torch.ones(777, device='cuda'))
+
+    a = outs()      # the two launches
+    nat.step_prologue((a['target'], source, 0.005), a['grad'], 99, step, a['u'], a['z'])
+    nat.sumtree_sample(t.tree, C, B, a['u'], slot_ids, a['beta'], 0.001, a['leaf'], a['p'], a['ids'], a['w'], a['minp'])
+    b = outs()      # one launch
+    nat.step_prologue_sample((b['target'], source, 0.005), b['grad'], 99, step, b['u'], b['z'], None, 0, t.tree, C, B,
+                             slot_ids, b['beta'], 0.001, b['leaf'], b['p'], b['ids'], b['w'], b['minp'])
+    for k in ('u', 'z', 'target', 'grad', 'leaf', 'p', 'ids', 'w', 'beta'):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a['minp'][0]) == float(b['minp'][0])
+    c = outs()      # one launch, weights deferred; then the weights
+    nat.step_prologue_sample((c['target'], source, 0.005), c['grad'], 99, step, c['u'], c['z'], None, 0, t.tree, C, B,
+                             slot_ids, c['beta'], 0.001, c['leaf'], c['p'], c['ids'], None, c['minp'])
+    assert float(c['beta']) == 0.4 and not c['w'].any()
+    assert float(c['minp'][0]) == float(a['minp'][0])
+    assert float(c['minp'][1]) == float(np.float32(a['minp'][0].item()) / np.float32(t.tree[0].item()))
+    nat.per_is_weights(c['p'], B, t.tree, c['minp'][1:2], c['beta'], 0.001, c['w'])
+    for k in ('leaf', 'p', 'ids', 'w', 'beta'):
+        assert torch.equal(a[k], c[k]), k
+
+
 def test_window_aux_matches_get_bnx_data_concatenations(nat):
     """`asac_window_aux` == the three concatenations of SAC_Base.get_bnx_data on window views."""
     import asac_amd  # noqa: F401
