@@ -29,12 +29,18 @@ struct GatherKeyDev {
     uint32_t first_block;    // prefix sum of blocks over the keys
 };
 
-struct GatherArgs {
-    GatherKeyDev key[ASAC_MAX_GATHER_KEYS];
+struct GatherArgs {          // what every key's blocks share
     int32_t n_keys;
     const int64_t* ids;
     const int32_t* index_ring;
     int32_t batch, prev_n, L, capacity;
+};
+// (sized key tables: a launch's argument block is fetched on its critical path, ~0.5-0.9 us per KB; the usual batches
+// have at most eight keys — 448 bytes less than the full table)
+template <int NK>
+struct GatherLaunch {
+    GatherKeyDev key[NK];
+    GatherArgs c;
 };
 
 __device__ __forceinline__ bool row_valid(const GatherArgs& a, int64_t id, int j) {
@@ -131,13 +137,15 @@ __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherK
     }
 }
 
-__global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const GatherArgs a) {
+template <int NK>
+__global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const GatherLaunch<NK> m) {
+    const GatherArgs& a = m.c;
     // which key does this block belong to?  (<= 16 entries, wave-uniform scan)
     int ki = 0;
 #pragma unroll 1
     for (int q = 1; q < a.n_keys; ++q)
-        if (blockIdx.x >= a.key[q].first_block) ki = q;
-    const GatherKeyDev& k = a.key[ki];
+        if (blockIdx.x >= m.key[q].first_block) ki = q;
+    const GatherKeyDev& k = m.key[ki];
     const int64_t rows = (int64_t)a.batch * a.L;
     const int64_t total_units = rows * k.units_per_row;
     const int64_t g0 = (int64_t)(blockIdx.x - k.first_block) * (kGatherBlock * kUnroll) + threadIdx.x;
@@ -220,7 +228,8 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
     if (n_keys <= 0 || n_keys > ASAC_MAX_GATHER_KEYS || batch <= 0 || prev_n < 0 || post_n < 0 ||
         capacity <= 0)
         return bad_arg("asac_window_gather_pad");
-    GatherArgs a;
+    GatherLaunch<ASAC_MAX_GATHER_KEYS> m{};
+    GatherArgs& a = m.c;
     a.n_keys = n_keys;
     a.ids = ids;
     a.index_ring = index_ring;
@@ -232,7 +241,7 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
     uint64_t blocks = 0;
     for (int q = 0; q < n_keys; ++q) {
         const asac_gather_key_t& h = keys_host[q];
-        GatherKeyDev& d = a.key[q];
+        GatherKeyDev& d = m.key[q];
         d.src = static_cast<const uint8_t*>(h.src);
         d.dst = static_cast<uint8_t*>(h.dst);
         d.pad_row = static_cast<const uint8_t*>(h.pad_row);
@@ -266,8 +275,15 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
         blocks += (uint64_t)((units + kGatherBlock * kUnroll - 1) / (kGatherBlock * kUnroll));
     }
     if (blocks == 0 || blocks > 0x7fffffffull) return bad_arg("asac_window_gather_pad: grid");
-    ASAC_LAUNCH(k_window_gather_pad, dim3((unsigned)blocks), dim3(kGatherBlock), 0,
-                       as_stream(stream), a);
+    if (n_keys <= 8) {
+        GatherLaunch<8> m8{};
+        for (int q = 0; q < n_keys; ++q) m8.key[q] = m.key[q];
+        m8.c = a;
+        ASAC_LAUNCH(k_window_gather_pad<8>, dim3((unsigned)blocks), dim3(kGatherBlock), 0, as_stream(stream), m8);
+    } else {
+        ASAC_LAUNCH(k_window_gather_pad<ASAC_MAX_GATHER_KEYS>, dim3((unsigned)blocks), dim3(kGatherBlock), 0,
+                    as_stream(stream), m);
+    }
     return finish_launch("asac_window_gather_pad");
 }
 
