@@ -1619,16 +1619,17 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
             cur ^= 1;
         }
         MLP_STAMP(2);
-        if (wave == 0) {
+        {
+            // the head tile is 16 x 16: every wave forms it (the same MFMA chain: the same values) and finishes ONE of
+            // the four rows a lane holds — the head transform (tanh on the location columns, exp on the scale columns,
+            // both branches taken by every wave) runs once per lane instead of four times on a single wave
             const f32x4 acc = gemm_tile(L.xs[cur], L.head, kMaxW, 0, 0);
             const int hc = lane & 15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = 4 * (lane >> 4) + r;
-                const float v = head_value(a.pi.d, hc, acc[r] + L.head_bias[hc]);
-                L.ls[lrow * 2 * kHeadPad + hc] = v;
-                if (writer && a.pi.out && row0 + lrow < N && hc < 2 * A) a.pi.out[(row0 + lrow) * (2 * A) + hc] = v;
-            }
+            const float mine = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
+            const int lrow = 4 * (lane >> 4) + wave;
+            const float v = head_value(a.pi.d, hc, mine + L.head_bias[hc]);
+            L.ls[lrow * 2 * kHeadPad + hc] = v;
+            if (writer && a.pi.out && row0 + lrow < N && hc < 2 * A) a.pi.out[(row0 + lrow) * (2 * A) + hc] = v;
         }
         __syncthreads();
         MLP_STAMP(3);
