@@ -652,8 +652,18 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpFwdArgs& a, const int e, 
         }
         if (more) put_input_tile<THREADS>(nxt, L.xs[cur ^ 1]);
         if (more && wide) put_input_tile<THREADS>(nxt_hi, x_hi);
-        // heads: one padded column tile, the first wave of every row tile
-        if (wave < RT) {
+        // heads: one padded column tile per row tile.  Transformed heads (tanh / exp per element, both branches taken by
+        // every wave) of short launches: all 4 RT waves form their row tile's head (the same MFMA chain: the same values)
+        // and each finishes ONE of the four rows a lane holds; otherwise the first wave of every row tile
+        if (a.d.head_transform == 1 && n_tiles <= 256) {      // (launches of at most a tile per CU: latency is what counts)
+            const int hrt = wave % RT, hr = wave / RT;
+            const f32x4 acc = gemm_tile(L.xs[cur], L.head, round4(K_last), hrt, 0);
+            const int col = lane & 15;
+            const float mine = hr == 0 ? acc[0] : hr == 1 ? acc[1] : hr == 2 ? acc[2] : acc[3];
+            const int64_t row = row0 + hrt * 16 + 4 * (lane >> 4) + hr;
+            if (row < a.N && col < O)
+                a.out[((int64_t)e * a.N + row) * O + col] = head_value(a.d, col, mine + L.head_bias[col]);
+        } else if (wave < RT) {
             const f32x4 acc = gemm_tile(L.xs[cur], L.head, round4(K_last), wave, 0);
             const int col = lane & 15;
 #pragma unroll
@@ -1291,16 +1301,14 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
             }
             __syncthreads();
         }
-        if (wave == 0) {       // three layers: the last activations sit in P.x[1]
+        if (wave < 4) {        // three layers: the last activations sit in P.x[1]; one of a lane's four rows per wave
             const f32x4 acc = gemm_tile(P.x[1], P.head, kMaxW, 0, 0);
             const int hc = lane & 15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = 4 * (lane >> 4) + r;
-                const float v = head_value(a.pi.d, hc, acc[r] + P.head_bias[hc]);
-                L.ls[lrow * 2 * kHeadPad + hc] = v;
-                if (a.ls_out && row0 + lrow < N && hc < 2 * A) a.ls_out[(row0 + lrow) * (2 * A) + hc] = v;
-            }
+            const float mine = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
+            const int lrow = 4 * (lane >> 4) + wave;
+            const float v = head_value(a.pi.d, hc, mine + P.head_bias[hc]);
+            L.ls[lrow * 2 * kHeadPad + hc] = v;
+            if (a.ls_out && row0 + lrow < N && hc < 2 * A) a.ls_out[(row0 + lrow) * (2 * A) + hc] = v;
         }
         __syncthreads();
         if (threadIdx.x < kPsRows) {      // one lane per row: the sampling launch's device function (asac_squash.h)
