@@ -34,6 +34,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in asac_hip.h but not exported'
 
 
+def test_integration_notes_name_every_entry_point():
+    """INTEGRATION.md maps every export to the reference lines it replaces: a new entry point without a row there is
+    a boundary change nobody wrote down."""
+    notes = (ROOT / 'INTEGRATION.md').read_text()
+    missing = [name for name in declared_symbols() if name not in notes]
+    assert not missing, missing
+
+
 def test_binding_covers_header_and_abi_version():
     from asac_amd import native
     assert sorted(native.EXPORTED_SYMBOLS) == declared_symbols()
