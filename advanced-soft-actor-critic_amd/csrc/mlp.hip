@@ -391,10 +391,10 @@ __device__ __forceinline__ void fetch_input_tile(const MlpFwdArgs& a, int e, int
     }
 }
 
-template <int THREADS>
-__device__ __forceinline__ void put_input_tile(const float (&v)[4], float* xs) {
+template <int THREADS, int SLOTS = 4>
+__device__ __forceinline__ void put_input_tile(const float (&v)[SLOTS], float* xs) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SLOTS; ++u) {
         const int i = threadIdx.x + u * THREADS;
         xs[(i >> 6) * kP + (i & 63)] = v[u];
     }
@@ -452,13 +452,13 @@ __device__ __forceinline__ int buf_ld(rsrc_t r, unsigned byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0);
 }
 
-template <int THREADS, bool WINDOW>
-__device__ __forceinline__ void fetch_input_tile_fixed(const StageScalars& q, int e, int64_t row0, float (&v)[4]) {
+template <int THREADS, bool WINDOW, int SLOTS = 4>
+__device__ __forceinline__ void fetch_input_tile_fixed(const StageScalars& q, int e, int64_t row0, float (&v)[SLOTS]) {
     const int in0 = q.in0, in1 = q.in1;
     const rsrc_t r0 = make_rsrc(q.x0 + e * q.x0_ms);
     const rsrc_t r1 = make_rsrc(q.x1 + e * q.x1_ms, in1 > 0 ? 0x7fffffffu : 0u);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < SLOTS; ++u) {
         const int i = threadIdx.x + u * THREADS;
         const int r = i >> 6, c = i & 63;
         const uint32_t row = (uint32_t)row0 + (uint32_t)r;
@@ -796,6 +796,41 @@ __device__ __forceinline__ void grad_bias(const float* __restrict__ delta, int j
     if (lane < 16 && c < J) out[c] = s;
 }
 
+// grad_weight<16> with the output's (J/16) x (K/16) MFMA tiles dealt over 8 waves (same chain per tile)
+__device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
+                                               int J, int K, float* __restrict__ out, int first_wave = 0) {
+    const int wave = ((threadIdx.x >> 6) + 8 - first_wave) & 7, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int njt = (J + 15) >> 4, nkt = (K + 15) >> 4;
+    const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int t = wave; t < njt * nkt; t += 8) {
+        const int jt = t / nkt, kt = t - jt * nkt;
+        float dv[4], xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dv[i] = delta[(4 * i + lk) * kP + jbase + jt * 16 + lr];
+            xv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], dv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], dv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], dv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], dv[3], acc1, 0, 0, 0);
+        const f32x4 acc = acc0 + acc1;
+        const int j = jt * 16 + lr, k0 = kt * 16 + 4 * lk;
+        if (j >= J) continue;
+        float* o = out + j * K + k0;
+        if (vec && k0 + 3 < K) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (k0 + r < K) o[r] = acc[r];
+        }
+    }
+}
+
 // RET: the Q-loss backward forms its own return target (asac_mlp_backward_qloss_return): every workgroup evaluates
 // the n-step V-trace return of ITS tile's rows (asac_vtrace.h: the return kernel's per-step terms and its scan
 // association, bit-identical) instead of reading y from a launch in front.  The (row, step) loads are issued right
@@ -810,9 +845,14 @@ struct RetIn<true> {
     int32_t seg;              // vtrace_scan_lanes(B, n): the stand-alone kernel's scan association
 };
 
-template <int TM, bool WIDE, int NB, bool RET = false>
-__global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetIn<RET> rv) {
-    constexpr int THREADS = threads_of<TM>();
+// W8 (16-row tiles of the stock networks only): EIGHT waves instead of four.  The forward recompute and the dX chains
+// have four column tiles, i.e. work for four waves — the other four stage (the loads and LDS writes of the staging are
+// dealt over all 512 threads) and take half of the weight-gradient tiles (ps_grad_weight: two 16 x 16 tiles per wave
+// and layer instead of four; the same MFMA chain per tile: the same partial sums), 0.8 -> 0.45 us per layer.
+template <int TM, bool WIDE, int NB, bool RET = false, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : TM * 16) void k_mlp_bwd(const MlpArgs a, const RetIn<RET> rv) {
+    static_assert(!W8 || (TM == 16 && NB == 3 && !WIDE), "eight waves: 16-row tiles of the stock networks");
+    constexpr int THREADS = W8 ? 512 : threads_of<TM>();
     constexpr int RT = TM / 16;
     constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
     static_assert(!(fixed && WIDE), "the fixed-shape path has a first layer of <= 64 inputs");
@@ -823,7 +863,8 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
     const float* P = a.params + e * a.member_stride;
     float* part = a.partial ? a.partial + ((int64_t)blockIdx.x * gridDim.y + e) * a.member_stride : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rt = wave % RT, ct = wave / RT;
+    const bool comp = !W8 || wave < 4;          // this wave owns a column tile of the forward / dX chains
+    const int rt = wave % RT, ct = comp ? wave / RT : 0;
     const int nb = fixed ? NB : a.d.n_blocks;
     const int K0 = a.d.in0 + a.d.in1;
     const int O = a.d.head_cols[0] + a.d.head_cols[1];
@@ -837,12 +878,13 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
     float* w_hi = L.w[nb < kMaxB ? nb : kMaxB - 1];
     if constexpr (fixed) {
         const StageScalars q = stage_scalars<NB>(a, e);
-        float in_lo[4];
-        fetch_input_tile_fixed<THREADS, false>(q, e, row0, in_lo);
-        const int r = threadIdx.x >> 4, c = threadIdx.x & 15;     // TM x 16 = THREADS slots
+        constexpr int SLOTS = TM * 64 / THREADS;                  // of the TM x 64 input tile per thread (4; W8: 2)
+        float in_lo[SLOTS];
+        fetch_input_tile_fixed<THREADS, false, SLOTS>(q, e, row0, in_lo);
+        const int r = threadIdx.x >> 4, c = threadIdx.x & 15;     // TM x 16 slots (W8: the first 256 threads)
         const int64_t row = row0 + r;
         float gin = 0.f;
-        if (a.gout) {       // (uniform)
+        if (a.gout && r < TM) {       // (a.gout: uniform)
             const float t = a.gout[((int64_t)e * a.N + (row < a.N ? row : a.N - 1)) * O + (c < O ? c : O - 1)];
             gin = (row < a.N && c < O) ? t : 0.f;
         }
@@ -862,7 +904,7 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
                 raw = vtrace_step_load(v, (int)(row0 + fr), ft);
                 log_alpha = *v.log_alpha;
             }
-            put_input_tile<THREADS>(in_lo, L.x[0]);
+            put_input_tile<THREADS, SLOTS>(in_lo, L.x[0]);
             net_put_fixed<THREADS, NB>(regs, L);
             if (have) {
                 float d, cc;
@@ -872,10 +914,10 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
                 s_c[fr * pitch + ft] = cc;
             }
         } else {
-            put_input_tile<THREADS>(in_lo, L.x[0]);
+            put_input_tile<THREADS, SLOTS>(in_lo, L.x[0]);
             net_put_fixed<THREADS, NB>(regs, L);
         }
-        L.delta[r * kP + c] = gin;
+        if (r < TM) L.delta[r * kP + c] = gin;
     } else {
         float in_lo[4], in_hi[4];
         fetch_input_tile<THREADS>(a, e, row0, in_lo);
@@ -921,6 +963,11 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
             const float* xin = L.x[l];
             float* xout = L.x[l + 1];
             if (l == 1) MLP_STAMP(20);
+            if (!comp) {              // (W8: waves 4..7 have no column tile)
+                __syncthreads();
+                K = W;
+                continue;
+            }
             f32x4 acc = (fixed && l > 0) ? gemm_tile(xin, L.w[l], kMaxW, rt, ct)
                                          : gemm_tile(xin, L.w[l], (l == 0 && wide) ? kMaxW : round4(K), rt, ct);
             if (l == 0 && wide) acc += gemm_tile(x_hi, w_hi, round4(K0 - kMaxW), rt, ct);
@@ -1066,13 +1113,15 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
         int jb = 0;
         for (int h = 0; h < 2; ++h) {
             if (a.d.head_cols[h] > 0) {
-                grad_weight<TM>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
+                if constexpr (W8) ps_grad_weight(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
+                else grad_weight<TM>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
                 grad_bias<TM>(L.delta, jb, a.d.head_cols[h], part + a.d.head_b_off[h]);
             }
             jb += a.d.head_cols[h];
         }
     }
-    f32x4 g = gemm_tile_nt(L.delta, L.head, kHeadPad, rt, ct);      // g[row][k], k over H
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (comp) g = gemm_tile_nt(L.delta, L.head, kHeadPad, rt, ct);      // g[row][k], k over H
     MLP_STAMP(4);
 
     // ---- blocks in reverse ---------------------------------------------------------------------------------
@@ -1083,10 +1132,12 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
             const int W = fixed ? kMaxW : a.d.width[l];
             const int Kin = (l == 0) ? K0 : (fixed ? kMaxW : a.d.width[l - 1]);
             __syncthreads();   // readers of the previous delta tile are done
+            if (comp) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rt * 16 + 4 * (lane >> 4) + r;
-                L.delta[row * kP + col] = col < W ? g[r] * z[l][r] : 0.f;     // z holds gelu'(pre-activation)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + 4 * (lane >> 4) + r;
+                    L.delta[row * kP + col] = col < W ? g[r] * z[l][r] : 0.f;     // z holds gelu'(pre-activation)
+                }
             }
             __syncthreads();
             if (l == 2) MLP_STAMP(16);
@@ -1094,6 +1145,8 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
                 if (l == 0 && wide) {
                     grad_weight<TM>(L.delta, 0, L.x[0], W, kMaxW, part + a.d.w_off[0], K0);
                     grad_weight<TM>(L.delta, 0, x_hi, W, K0 - kMaxW, part + a.d.w_off[0] + kMaxW, K0);
+                } else if constexpr (W8) {
+                    ps_grad_weight(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 } else {
                     grad_weight<TM>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 }
@@ -1102,14 +1155,16 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_bwd(const MlpArgs a, const RetI
                 if (l == 2) MLP_STAMP(18);
             }
             if (l == 0 && wide && (a.gx0 || a.gx1)) g_hi = gemm_tile_nt(L.delta, w_hi, round4(W), rt, ct);
-            f32x4 gin = gemm_tile_nt(L.delta, L.w[l], fixed ? kMaxW : round4(W), rt, ct);   // d x_{l-1}[row][k]
-            if (a.d.residual[l]) gin += g;
-            g = gin;
+            if (comp) {
+                f32x4 gin = gemm_tile_nt(L.delta, L.w[l], fixed ? kMaxW : round4(W), rt, ct);   // d x_{l-1}[row][k]
+                if (a.d.residual[l]) gin += g;
+                g = gin;
+            }
             MLP_STAMP(5 + (kMaxB - 1 - l));
         }
     }
     // ---- input gradients --------------------------------------------------------------------------------------
-    if (a.gx0 || a.gx1) {
+    if (comp && (a.gx0 || a.gx1)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + rt * 16 + 4 * (lane >> 4) + r;
@@ -1203,41 +1258,6 @@ __device__ __forceinline__ void ps_put_tile(const float (&v)[2], float* xs) {
     for (int u = 0; u < 2; ++u) {
         const int i = threadIdx.x + u * kPsThreads;
         xs[(i >> 6) * kP + (i & 63)] = v[u];
-    }
-}
-
-// grad_weight<16> with the output's (J/16) x (K/16) MFMA tiles dealt over 8 waves (same chain per tile)
-__device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
-                                               int J, int K, float* __restrict__ out, int first_wave = 0) {
-    const int wave = ((threadIdx.x >> 6) + 8 - first_wave) & 7, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int njt = (J + 15) >> 4, nkt = (K + 15) >> 4;
-    const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    for (int t = wave; t < njt * nkt; t += 8) {
-        const int jt = t / nkt, kt = t - jt * nkt;
-        float dv[4], xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            dv[i] = delta[(4 * i + lk) * kP + jbase + jt * 16 + lr];
-            xv[i] = xprev[(4 * i + lk) * kP + kt * 16 + lr];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[0], dv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[1], dv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[2], dv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[3], dv[3], acc1, 0, 0, 0);
-        const f32x4 acc = acc0 + acc1;
-        const int j = jt * 16 + lr, k0 = kt * 16 + 4 * lk;
-        if (j >= J) continue;
-        float* o = out + j * K + k0;
-        if (vec && k0 + 3 < K) {
-            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (k0 + r < K) o[r] = acc[r];
-        }
     }
 }
 
@@ -2000,19 +2020,21 @@ static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpAr
     if (ret) {             // (asac_mlp_backward_qloss_return_ok has said yes: stock network, the tile's steps fit)
         const size_t lds = sizeof(MlpBwdLds<TM>) + (size_t)(2 * ((ret->v.n + 1) | 1) + 2) * TM * sizeof(float);
         if (!stock || TM * ret->v.n > threads_of<TM>() || lds > 128 * 1024) return bad_arg(where);
-        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, true>), 128 * 1024, attr_ret, where))
+        constexpr bool w8 = TM == 16;            // (16-row tiles of the stock networks: eight waves, see k_mlp_bwd)
+        if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, true, w8>), 128 * 1024, attr_ret, where))
             return rc;
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true>), dim3(tiles, E), dim3(threads_of<TM>()), lds, s, a, *ret);
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true, w8>), dim3(tiles, E), dim3(w8 ? 512 : threads_of<TM>()), lds, s, a, *ret);
         return 0;
     }
     if (int rc = wide    ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, true, 0>), sizeof(MlpBwdLds<TM>), attr_wide, where)
-                 : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3>), sizeof(MlpBwdLds<TM>), attr_stock, where)
+                 : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, false, TM == 16>), sizeof(MlpBwdLds<TM>), attr_stock, where)
                          : set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 0>), sizeof(MlpBwdLds<TM>), attr_done, where))
         return rc;
     if (wide)
         ASAC_LAUNCH((k_mlp_bwd<TM, true, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else if (stock)
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, false, TM == 16>), dim3(tiles, E), dim3(TM == 16 ? 512 : threads_of<TM>()),
+                    sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else
         ASAC_LAUNCH((k_mlp_bwd<TM, false, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     return 0;
