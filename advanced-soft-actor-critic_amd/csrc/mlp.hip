@@ -1589,7 +1589,11 @@ struct PiQArgs {
 
 template <bool WINDOW>
 __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
-    constexpr int THREADS = 256;
+    // eight waves: the staging (loads and LDS writes of two networks and the input tile) is dealt over 512 threads —
+    // 1.5 us instead of 2.5; the forward chains have four column tiles: waves 4..7 only keep the barriers company there
+    constexpr int THREADS = 512;
+    constexpr int SLOTS = 2;                 // of the 16 x 64 input tile per thread
+    const bool comp = (threadIdx.x >> 6) < 4;
     const int e = (int)blockIdx.x % a.E, group = (int)blockIdx.x / a.E;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = wave * 16 + (lane & 15);
@@ -1602,12 +1606,12 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
 
     // ---- staging: the policy and critic e, one round trip ----------------------------------------------------------
     const StageScalars sp = stage_scalars<3>(a.pi, 0), sq = stage_scalars<3>(a.q, e);
-    float in_lo[4];
-    fetch_input_tile_fixed<THREADS, WINDOW>(sp, 0, (int64_t)group * 16, in_lo);
+    float in_lo[SLOTS];
+    fetch_input_tile_fixed<THREADS, WINDOW, SLOTS>(sp, 0, (int64_t)group * 16, in_lo);
     StagedNet<THREADS> rp, rq;
     net_fetch_fixed<THREADS, 3>(sp, rp);
     net_fetch_fixed<THREADS, 3>(sq, rq);
-    put_input_tile<THREADS>(in_lo, L.xs[0]);
+    put_input_tile<THREADS, SLOTS>(in_lo, L.xs[0]);
     net_put_fixed<THREADS, 3>(rp, L);
     // (critic e's weights stay in registers until the policy has run: its 36 KB are still travelling when the policy's
     // have landed — memory returns in order — and nothing needs them before the first critic layer)
@@ -1618,36 +1622,38 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
     for (int tile = group; tile < n_tiles; tile += a.tile_groups) {
         const int64_t row0 = (int64_t)tile * 16;
         if (tile != group) {       // (later tiles of a looping workgroup: the first one arrived with the weights)
-            fetch_input_tile_fixed<THREADS, WINDOW>(sp, 0, row0, in_lo);
+            fetch_input_tile_fixed<THREADS, WINDOW, SLOTS>(sp, 0, row0, in_lo);
             __syncthreads();
-            put_input_tile<THREADS>(in_lo, L.xs[0]);
+            put_input_tile<THREADS, SLOTS>(in_lo, L.xs[0]);
             __syncthreads();
         }
         // ---- policy forward ----------------------------------------------------------------------------------------
         int cur = 0;
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
-            const float* xin = L.xs[cur];
-            float* xout = L.xs[cur ^ 1];
-            const f32x4 acc = l > 0 ? gemm_tile(xin, L.w[l], kMaxW, 0, wave) : gemm_tile(xin, L.w[l], round4(K0p), 0, wave);
-            const float bias = L.bias[l][col];
-            const bool res = a.pi.d.residual[l] != 0;
-            f32x2_g ya, yb, unused;
-            gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
-            gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
-            const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+            if (comp) {
+                const float* xin = L.xs[cur];
+                float* xout = L.xs[cur ^ 1];
+                const f32x4 acc = l > 0 ? gemm_tile(xin, L.w[l], kMaxW, 0, wave) : gemm_tile(xin, L.w[l], round4(K0p), 0, wave);
+                const float bias = L.bias[l][col];
+                const bool res = a.pi.d.residual[l] != 0;
+                f32x2_g ya, yb, unused;
+                gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
+                gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
+                const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r;
-                float y = yv[r];
-                if (res) y += xin[row * kP + col];
-                xout[row * kP + col] = y;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    float y = yv[r];
+                    if (res) y += xin[row * kP + col];
+                    xout[row * kP + col] = y;
+                }
             }
             __syncthreads();
             cur ^= 1;
         }
         MLP_STAMP(2);
-        {
+        if (comp) {
             // the head tile is 16 x 16: every wave forms it (the same MFMA chain: the same values) and finishes ONE of
             // the four rows a lane holds — the head transform (tanh on the location columns, exp on the scale columns,
             // both branches taken by every wave) runs once per lane instead of four times on a single wave
@@ -1741,7 +1747,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
         }
         // ---- critic e on (state, sampled action) ---------------------------------------------------------------------
         if (tile == group) net_put_fixed<THREADS, 3>(rq, C);
-        put_input_tile<THREADS>(in_lo, L.xs[0]);         // the states again (columns >= S are zero)
+        put_input_tile<THREADS, SLOTS>(in_lo, L.xs[0]);         // the states again (columns >= S are zero)
         __syncthreads();
         MLP_STAMP(4);
         if ((int)threadIdx.x < 16 * A) {
@@ -1753,21 +1759,23 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
         cur = 0;
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
-            const float* xin = L.xs[cur];
-            float* xout = L.xs[cur ^ 1];
-            const f32x4 acc = l > 0 ? gemm_tile(xin, L.qw[l], kMaxW, 0, wave) : gemm_tile(xin, L.qw[l], round4(K0q), 0, wave);
-            const float bias = L.qbias[l][col];
-            const bool res = a.q.d.residual[l] != 0;
-            f32x2_g ya, yb, unused;
-            gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
-            gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
-            const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+            if (comp) {
+                const float* xin = L.xs[cur];
+                float* xout = L.xs[cur ^ 1];
+                const f32x4 acc = l > 0 ? gemm_tile(xin, L.qw[l], kMaxW, 0, wave) : gemm_tile(xin, L.qw[l], round4(K0q), 0, wave);
+                const float bias = L.qbias[l][col];
+                const bool res = a.q.d.residual[l] != 0;
+                f32x2_g ya, yb, unused;
+                gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
+                gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
+                const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * (lane >> 4) + r;
-                float y = yv[r];
-                if (res) y += xin[row * kP + col];
-                xout[row * kP + col] = y;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * (lane >> 4) + r;
+                    float y = yv[r];
+                    if (res) y += xin[row * kP + col];
+                    xout[row * kP + col] = y;
+                }
             }
             __syncthreads();
             cur ^= 1;
@@ -1795,9 +1803,12 @@ struct PiQLaunch {
 static_assert(sizeof(PiQLaunch) + sizeof(SidecarsDev) <= 4096, "kernel arguments of k_pi_sample_q");
 
 template <int NSC>
-__global__ __launch_bounds__(256) void k_pi_sample_q(const PiQLaunch m, const SidecarsT<NSC> sc) {
+__global__ __launch_bounds__(512) void k_pi_sample_q(const PiQLaunch m, const SidecarsT<NSC> sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int blk = (int)blockIdx.x;
+    // (the fused job's workgroups run eight waves; the plain forward jobs and the sidecars riding along are written
+    // for four: their workgroups let the other four go — a finished wave no longer counts at the barriers)
+    if (blk >= m.f.blocks && threadIdx.x >= 256) return;
     if (blk < m.f.blocks) {
         PiQLds& L = *reinterpret_cast<PiQLds*>(smem_raw);
         if (m.f.pi.x0_T > 0) pi_q_tiles<true>(m.f, L);
@@ -2333,10 +2344,10 @@ int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_
         const bool last = rep == g_launch_repeat - 1;
         const dim3 grid((unsigned)(f.blocks + blocks + (last ? sc.blocks : 0)));
         if (sc.n <= 1)
-            hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(256), sizeof(PiQLds), as_stream(stream), m,
+            hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(512), sizeof(PiQLds), as_stream(stream), m,
                                sidecars_first<1>(last ? sc : none));
         else
-            hipLaunchKernelGGL(k_pi_sample_q<ASAC_MAX_SIDECARS>, grid, dim3(256), sizeof(PiQLds), as_stream(stream), m,
+            hipLaunchKernelGGL(k_pi_sample_q<ASAC_MAX_SIDECARS>, grid, dim3(512), sizeof(PiQLds), as_stream(stream), m,
                                last ? sc : none);
     }
     return finish_launch("asac_policy_sample_q_forward");
