@@ -797,13 +797,14 @@ __device__ __forceinline__ void grad_bias(const float* __restrict__ delta, int j
 }
 
 // grad_weight<16> with the output's (J/16) x (K/16) MFMA tiles dealt over 8 waves (same chain per tile)
+template <int NW = 8>
 __device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
                                                int J, int K, float* __restrict__ out, int first_wave = 0) {
-    const int wave = ((threadIdx.x >> 6) + 8 - first_wave) & 7, lane = threadIdx.x & 63;
+    const int wave = ((threadIdx.x >> 6) + NW - first_wave) & (NW - 1), lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int njt = (J + 15) >> 4, nkt = (K + 15) >> 4;
     const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    for (int t = wave; t < njt * nkt; t += 8) {
+    for (int t = wave; t < njt * nkt; t += NW) {
         const int jt = t / nkt, kt = t - jt * nkt;
         float dv[4], xv[4];
 #pragma unroll
@@ -845,14 +846,14 @@ struct RetIn<true> {
     int32_t seg;              // vtrace_scan_lanes(B, n): the stand-alone kernel's scan association
 };
 
-// W8 (16-row tiles of the stock networks only): EIGHT waves instead of four.  The forward recompute and the dX chains
-// have four column tiles, i.e. work for four waves — the other four stage (the loads and LDS writes of the staging are
-// dealt over all 512 threads) and take half of the weight-gradient tiles (ps_grad_weight: two 16 x 16 tiles per wave
-// and layer instead of four; the same MFMA chain per tile: the same partial sums), 0.8 -> 0.45 us per layer.
-template <int TM, bool WIDE, int NB, bool RET = false, bool W8 = false>
-__global__ __launch_bounds__(W8 ? 512 : TM * 16) void k_mlp_bwd(const MlpArgs a, const RetIn<RET> rv) {
-    static_assert(!W8 || (TM == 16 && NB == 3 && !WIDE), "eight waves: 16-row tiles of the stock networks");
-    constexpr int THREADS = W8 ? 512 : threads_of<TM>();
+// W8 (16-row tiles of the stock networks only): EIGHT or SIXTEEN waves instead of four.  The forward recompute and the
+// dX chains have four column tiles, i.e. work for four waves — the others share the staging (its loads, LDS writes and
+// address arithmetic are dealt over all 512 / 1024 threads) and the weight-gradient tiles (ps_grad_weight: two / one
+// 16 x 16 tiles per wave and layer instead of four; the same MFMA chain per tile: the same partial sums).
+template <int TM, bool WIDE, int NB, bool RET = false, int W8 = 0>      // W8: 0, or the number of waves (8 / 16)
+__global__ __launch_bounds__(W8 ? 64 * W8 : TM * 16) void k_mlp_bwd(const MlpArgs a, const RetIn<RET> rv) {
+    static_assert(W8 == 0 || ((W8 == 8 || W8 == 16) && TM == 16 && NB == 3 && !WIDE), "8 / 16 waves: 16-row tiles of the stock networks");
+    constexpr int THREADS = W8 ? 64 * W8 : threads_of<TM>();
     constexpr int RT = TM / 16;
     constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
     static_assert(!(fixed && WIDE), "the fixed-shape path has a first layer of <= 64 inputs");
@@ -1113,7 +1114,7 @@ __global__ __launch_bounds__(W8 ? 512 : TM * 16) void k_mlp_bwd(const MlpArgs a,
         int jb = 0;
         for (int h = 0; h < 2; ++h) {
             if (a.d.head_cols[h] > 0) {
-                if constexpr (W8) ps_grad_weight(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
+                if constexpr (W8 != 0) ps_grad_weight<W8 ? W8 : 8>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
                 else grad_weight<TM>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
                 grad_bias<TM>(L.delta, jb, a.d.head_cols[h], part + a.d.head_b_off[h]);
             }
@@ -1145,8 +1146,8 @@ __global__ __launch_bounds__(W8 ? 512 : TM * 16) void k_mlp_bwd(const MlpArgs a,
                 if (l == 0 && wide) {
                     grad_weight<TM>(L.delta, 0, L.x[0], W, kMaxW, part + a.d.w_off[0], K0);
                     grad_weight<TM>(L.delta, 0, x_hi, W, K0 - kMaxW, part + a.d.w_off[0] + kMaxW, K0);
-                } else if constexpr (W8) {
-                    ps_grad_weight(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
+                } else if constexpr (W8 != 0) {
+                    ps_grad_weight<W8 ? W8 : 8>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 } else {
                     grad_weight<TM>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 }
@@ -2022,6 +2023,11 @@ static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const Si
     return finish_launch("asac_mlp_forward_multi");
 }
 
+// waves of k_mlp_bwd on the stock networks' 16-row tiles (A/B builds: -DASAC_BWD_WAVES=8; measured on cfg2, same box,
+// alternating libraries: 4 -> 8 waves +1.7 %, 8 -> 16 waves +0.9 %)
+#ifndef ASAC_BWD_WAVES
+#define ASAC_BWD_WAVES 16
+#endif
 template <int TM>
 static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpArgs& a, int E, int tiles, hipStream_t s,
                            const RetIn<true>* ret = nullptr) {
@@ -2031,20 +2037,21 @@ static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpAr
     if (ret) {             // (asac_mlp_backward_qloss_return_ok has said yes: stock network, the tile's steps fit)
         const size_t lds = sizeof(MlpBwdLds<TM>) + (size_t)(2 * ((ret->v.n + 1) | 1) + 2) * TM * sizeof(float);
         if (!stock || TM * ret->v.n > threads_of<TM>() || lds > 128 * 1024) return bad_arg(where);
-        constexpr bool w8 = TM == 16;            // (16-row tiles of the stock networks: eight waves, see k_mlp_bwd)
+        constexpr int w8 = TM == 16 ? ASAC_BWD_WAVES : 0;            // (16-row tiles of the stock networks: see k_mlp_bwd)
         if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, true, w8>), 128 * 1024, attr_ret, where))
             return rc;
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true, w8>), dim3(tiles, E), dim3(w8 ? 512 : threads_of<TM>()), lds, s, a, *ret);
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true, w8>), dim3(tiles, E), dim3(w8 ? 64 * w8 : threads_of<TM>()), lds, s, a, *ret);
         return 0;
     }
     if (int rc = wide    ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, true, 0>), sizeof(MlpBwdLds<TM>), attr_wide, where)
-                 : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, false, TM == 16>), sizeof(MlpBwdLds<TM>), attr_stock, where)
+                 : stock ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, false, TM == 16 ? ASAC_BWD_WAVES : 0>), sizeof(MlpBwdLds<TM>), attr_stock, where)
                          : set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 0>), sizeof(MlpBwdLds<TM>), attr_done, where))
         return rc;
     if (wide)
         ASAC_LAUNCH((k_mlp_bwd<TM, true, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else if (stock)
-        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, false, TM == 16>), dim3(tiles, E), dim3(TM == 16 ? 512 : threads_of<TM>()),
+        ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, false, TM == 16 ? ASAC_BWD_WAVES : 0>), dim3(tiles, E),
+                    dim3(TM == 16 ? 64 * ASAC_BWD_WAVES : threads_of<TM>()),
                     sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
     else
         ASAC_LAUNCH((k_mlp_bwd<TM, false, 0>), dim3(tiles, E), dim3(threads_of<TM>()), sizeof(MlpBwdLds<TM>), s, a, RetIn<false>{});
