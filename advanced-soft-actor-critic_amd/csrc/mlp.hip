@@ -797,14 +797,15 @@ __device__ __forceinline__ void grad_bias(const float* __restrict__ delta, int j
 }
 
 // grad_weight<16> with the output's (J/16) x (K/16) MFMA tiles dealt over 8 waves (same chain per tile)
-template <int NW = 8>
-__device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
-                                               int J, int K, float* __restrict__ out, int first_wave = 0) {
-    const int wave = ((threadIdx.x >> 6) + NW - first_wave) & (NW - 1), lane = threadIdx.x & 63;
+// ... by `workers` waves, this one being number `worker` of them (a wave with worker < 0 has no part in it)
+__device__ __forceinline__ void grad_weight_tiles(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
+                                                  int J, int K, float* __restrict__ out, int worker, int workers) {
+    if (worker < 0) return;
+    const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int njt = (J + 15) >> 4, nkt = (K + 15) >> 4;
     const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-    for (int t = wave; t < njt * nkt; t += NW) {
+    for (int t = worker; t < njt * nkt; t += workers) {
         const int jt = t / nkt, kt = t - jt * nkt;
         float dv[4], xv[4];
 #pragma unroll
@@ -830,6 +831,11 @@ __device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, 
                 if (k0 + r < K) o[r] = acc[r];
         }
     }
+}
+template <int NW = 8>
+__device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
+                                               int J, int K, float* __restrict__ out, int first_wave = 0) {
+    grad_weight_tiles(delta, jbase, xprev, J, K, out, ((threadIdx.x >> 6) + NW - first_wave) & (NW - 1), NW);
 }
 
 // RET: the Q-loss backward forms its own return target (asac_mlp_backward_qloss_return): every workgroup evaluates
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(W8 ? 64 * W8 : TM * 16) void k_mlp_bwd(const MlpArg
         int jb = 0;
         for (int h = 0; h < 2; ++h) {
             if (a.d.head_cols[h] > 0) {
-                if constexpr (W8 != 0) ps_grad_weight<W8 ? W8 : 8>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
+                if constexpr (W8 != 0) grad_weight_tiles(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h], wave - 4, W8 - 4);
                 else grad_weight<TM>(L.delta, jb, L.x[nb], a.d.head_cols[h], H, part + a.d.head_w_off[h]);
                 grad_bias<TM>(L.delta, jb, a.d.head_cols[h], part + a.d.head_b_off[h]);
             }
@@ -1147,7 +1153,9 @@ __global__ __launch_bounds__(W8 ? 64 * W8 : TM * 16) void k_mlp_bwd(const MlpArg
                     grad_weight<TM>(L.delta, 0, L.x[0], W, kMaxW, part + a.d.w_off[0], K0);
                     grad_weight<TM>(L.delta, 0, x_hi, W, K0 - kMaxW, part + a.d.w_off[0] + kMaxW, K0);
                 } else if constexpr (W8 != 0) {
-                    ps_grad_weight<W8 ? W8 : 8>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
+                    // (the waves without a column tile take the weight-gradient tiles; waves 0..3 go straight on to the
+                    // bias gradients and the dX chain: the two run side by side)
+                    grad_weight_tiles(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l], wave - 4, W8 - 4);
                 } else {
                     grad_weight<TM>(L.delta, 0, L.x[l], W, Kin, part + a.d.w_off[l]);
                 }
