@@ -285,6 +285,8 @@ def main():
                     help='weak: batch 256 per GPU; strong: global batch 256, 256/N rows per GPU (SURVEY 8d)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--steps-per-launch', type=int, default=4,
+                    help='train steps per call of SAC_Base.train_steps (one hipGraph replay holds that many steps; 1 = train())')
     ap.add_argument('--no-extras', action='store_true', help='skip the saturating-size sweep and the cfg3-5 side runs')
     ap.add_argument('--profile-steps', type=int, default=50)
     ap.add_argument('--fill', type=int, default=None, help='transitions resident before timing')
@@ -350,9 +352,16 @@ def main():
         agent.train()
     for _ in range(args.warmup):
         agent.train()
+    # EXACTLY `steps` train steps, issued as runs of `steps_per_launch` (SAC_Base.train_steps: one graph replay per run;
+    # the first run of that length captures its graph, so one is done before the clock starts) + single steps for the rest
+    spl = max(1, args.steps_per_launch)
+    if spl > 1:
+        agent.train_steps(spl)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // spl):
+        agent.train_steps(spl)
+    for _ in range(args.steps % spl):
         agent.train()
     sync_all()
     dt = time.perf_counter() - t0
@@ -360,6 +369,19 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # ... and the same number of steps once more as plain train() calls (one graph launch per step), reported beside it
+    dt_single = None
+    if spl > 1:
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            agent.train()
+        sync_all()
+        dt_single = time.perf_counter() - t1
+        if dist_ctx is not None:
+            t = torch.tensor([dt_single], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_single = float(t.item())
     graph_used = agent._graph is not None
     agent.replay_buffer.check_health()
 
@@ -477,6 +499,7 @@ def main():
             'metric': f'SAC train steps/sec (PER sample + grad step), batch {global_batch}',
             'value': round(value, 2), 'unit': 'train_steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4),
+            'value_one_step_per_launch': None if dt_single is None else round((world if args.scaling == 'weak' else 1) * args.steps / dt_single, 2),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{CFG["desc"]}, batch {CFG["batch_size"]} per GPU, {args.fill} transitions resident',
@@ -485,7 +508,8 @@ def main():
                        'replay_shard_capacity': CFG['capacity'] // world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'ranks': world, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
-                       'hipgraph': bool(graph_used)},
+                       'hipgraph': bool(graph_used),
+                       'steps_per_graph_launch': spl if (graph_used and agent._graph_runs.get(spl, (None, None, None))[2]) else 1},
             'roofline': roofline, 'roofline_hbm': roofline_hbm, 'sweep': sweep, 'configs': configs,
             'kernels': kernels, 'cpu_baseline': cpu,
         }

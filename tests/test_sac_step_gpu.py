@@ -208,6 +208,43 @@ def test_graph_replay_matches_eager(case):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('case', ['cfg2', 'cfg3'])
+def test_train_steps_is_the_train_calls_bit_for_bit(case):
+    """`train_steps(k)` replays ONE graph holding k steps: same launches, same order, same device-side counters and
+    draws as k `train()` calls — trees, weights, write-backs and the step counter equal bit for bit; a run in which a
+    summary / health check falls due goes step by step."""
+    import random
+    rng = np.random.default_rng(2)
+    hidden = (2, 8) if case == 'cfg3' else (0,)
+    eps_list = [pu.synthetic_episode(rng, [(6,)], [], 2, hidden, T) for T in (60, 45, 70, 80, 33)]
+    results = []
+    for runs in (False, True):
+        torch.manual_seed(3), np.random.seed(3), random.seed(3)
+        agent = make_agent(case, use_graph=True)
+        for ep in eps_list:
+            agent.put_episode(**ep)
+        torch.manual_seed(4)
+        for _ in range(8):          # eager warm-up, capture, first replays (the raw graph handle is taken)
+            agent.train()
+        assert agent._graph is not None and agent._graph_exec is not None
+        if runs:
+            agent.train_steps(4)
+            agent.train_steps(4)
+            agent.train_steps(3)
+            assert agent._graph_runs[4][2] is not None and agent._graph_runs[3][2] is not None
+        else:
+            for _ in range(11):
+                agent.train()
+        torch.cuda.synchronize()
+        results.append((agent.get_global_step(), agent.replay_buffer._tree.clone(), agent._params.flat.clone(),
+                        agent._target_params.flat.clone(), agent.replay_buffer._columns['mu_prob'].clone(),
+                        agent._opt_steps.clone(), agent.replay_buffer._beta.clone()))
+        agent.close()
+    assert results[0][0] == results[1][0]
+    for name, a, b in zip(('tree', 'weights', 'target weights', 'mu_prob', 'optimizer steps', 'beta'), results[0][1:], results[1][1:]):
+        assert torch.equal(a, b), name
+
+
 def test_data_parallel_path_single_rank_nccl():
     """The RCCL exchange steps (gradient mean all-reduce, global-min IS normalisation, weight
     broadcast) inside the eager AND the graph-captured step: with world_size 1 they change nothing
