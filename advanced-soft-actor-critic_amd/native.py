@@ -368,7 +368,9 @@ class LaunchProfiler:
             # a bracket also spans the host's time to issue the first launch when the device had run dry
             # (allocator hiccups): the median over calls is the robust per-launch figure, the mean is kept
             med = sorted(us)[len(us) // 2]
-            out[name] = {'calls': len(us), 'avg_us': sum(us) / len(us), 'min_us': min(us), 'med_us': med}
+            kept = [t for t in us if t <= 3.0 * med]       # (host-stall outliers: one 4 ms bracket in 50 doubles a mean)
+            out[name] = {'calls': len(us), 'avg_us': sum(kept) / len(kept), 'avg_us_raw': sum(us) / len(us),
+                         'min_us': min(us), 'med_us': med}
             pairs = [(t, ev[2]) for t, ev in zip(us, evs) if ev[2] is not None and t <= 3.0 * med]
             if pairs:   # wrappers that know their per-launch work (flops) report it: achieved = sum / sum over
                         # the calls that are not host-stall outliers (launch sizes differ, so no plain median)
