@@ -14,7 +14,12 @@
 namespace asac {
 
 constexpr int kGatherBlock = 256;
-constexpr int kUnroll = 4;   // units per thread: keeps >= 4 x 16 B loads in flight per lane
+// units per thread (template parameter UNROLL): 4 keeps >= 4 x 16 B loads in flight per lane — what a gather of
+// megabytes wants (70-75 % of the HBM peak); a gather of a few thousand units (the headline batch: 8 keys x 1 280 rows)
+// is a handful of workgroups that way, each thread walking four dependent id -> index ring -> row chains: with ONE
+// unit per thread and four times the workgroups the same launch is 4 us shorter (cfg2: +4 % steps/s, A/B on one box)
+constexpr int kUnrollLarge = 4;
+constexpr int64_t kSmallGatherBlocks = 1024;      // up to this many one-unit workgroups: UNROLL = 1
 
 struct GatherKeyDev {
     const uint8_t* src;
@@ -74,7 +79,7 @@ __device__ __forceinline__ uint8_t pad_value<uint8_t>(const GatherKeyDev& k, int
     return (uint8_t)(k.pad_word & 0xff);
 }
 
-template <typename Unit>
+template <typename Unit, int kUnroll>
 __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                            int64_t total_units) {
     // g indexes units of the dense destination [B, L, units_per_row]
@@ -105,6 +110,7 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
 }
 
 // conversion path: 4 source bytes -> 4 floats (uint8/255 or bool)
+template <int kUnroll>
 __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                               int64_t total_units) {
 #pragma unroll
@@ -137,7 +143,7 @@ __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherK
     }
 }
 
-template <int NK>
+template <int NK, int kUnroll>
 __global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const GatherLaunch<NK> m) {
     const GatherArgs& a = m.c;
     // which key does this block belong to?  (<= 16 entries, wave-uniform scan)
@@ -162,12 +168,12 @@ __global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const Gather
         return;
     }
     if (k.convert != ASAC_CVT_NONE) {
-        convert_units(a, k, g0, total_units);
+        convert_units<kUnroll>(a, k, g0, total_units);
         return;
     }
-    if (k.unit_log2 == 4) copy_units<uint4>(a, k, g0, total_units);
-    else if (k.unit_log2 == 2) copy_units<uint32_t>(a, k, g0, total_units);
-    else copy_units<uint8_t>(a, k, g0, total_units);
+    if (k.unit_log2 == 4) copy_units<uint4, kUnroll>(a, k, g0, total_units);
+    else if (k.unit_log2 == 2) copy_units<uint32_t, kUnroll>(a, k, g0, total_units);
+    else copy_units<uint8_t, kUnroll>(a, k, g0, total_units);
 }
 
 // K7 (asac_sidecar.h: ScatterArgs, scatter_elect_row, scatter_write_row)
@@ -270,18 +276,30 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
             d.unit_log2 = ul;
             d.units_per_row = h.row_bytes >> ul;
         }
-        d.first_block = (uint32_t)blocks;
-        const int64_t units = rows * d.units_per_row;
-        blocks += (uint64_t)((units + kGatherBlock * kUnroll - 1) / (kGatherBlock * kUnroll));
+    }
+    // one unit per thread while that keeps the launch within a few workgroups per CU, else four (see kUnrollLarge)
+    int64_t small_blocks = 0;
+    for (int q = 0; q < n_keys; ++q) small_blocks += (rows * m.key[q].units_per_row + kGatherBlock - 1) / kGatherBlock;
+    const int unroll = small_blocks <= kSmallGatherBlocks ? 1 : kUnrollLarge;
+    for (int q = 0; q < n_keys; ++q) {
+        m.key[q].first_block = (uint32_t)blocks;
+        const int64_t units = rows * m.key[q].units_per_row;
+        blocks += (uint64_t)((units + kGatherBlock * unroll - 1) / (kGatherBlock * unroll));
     }
     if (blocks == 0 || blocks > 0x7fffffffull) return bad_arg("asac_window_gather_pad: grid");
     if (n_keys <= 8) {
         GatherLaunch<8> m8{};
         for (int q = 0; q < n_keys; ++q) m8.key[q] = m.key[q];
         m8.c = a;
-        ASAC_LAUNCH(k_window_gather_pad<8>, dim3((unsigned)blocks), dim3(kGatherBlock), 0, as_stream(stream), m8);
+        if (unroll == 1)
+            ASAC_LAUNCH((k_window_gather_pad<8, 1>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, as_stream(stream), m8);
+        else
+            ASAC_LAUNCH((k_window_gather_pad<8, kUnrollLarge>), dim3((unsigned)blocks), dim3(kGatherBlock), 0, as_stream(stream), m8);
+    } else if (unroll == 1) {
+        ASAC_LAUNCH((k_window_gather_pad<ASAC_MAX_GATHER_KEYS, 1>), dim3((unsigned)blocks), dim3(kGatherBlock), 0,
+                    as_stream(stream), m);
     } else {
-        ASAC_LAUNCH(k_window_gather_pad<ASAC_MAX_GATHER_KEYS>, dim3((unsigned)blocks), dim3(kGatherBlock), 0,
+        ASAC_LAUNCH((k_window_gather_pad<ASAC_MAX_GATHER_KEYS, kUnrollLarge>), dim3((unsigned)blocks), dim3(kGatherBlock), 0,
                     as_stream(stream), m);
     }
     return finish_launch("asac_window_gather_pad");
