@@ -19,7 +19,7 @@ constexpr int kGatherBlock = 256;
 // is a handful of workgroups that way, each thread walking four dependent id -> index ring -> row chains: with ONE
 // unit per thread and four times the workgroups the same launch is 4 us shorter (cfg2: +4 % steps/s, A/B on one box)
 constexpr int kUnrollLarge = 4;
-constexpr int64_t kSmallGatherBlocks = 1024;      // up to this many one-unit workgroups: UNROLL = 1
+constexpr int64_t kSmallGatherBlocks = 8192;      // up to this many one-unit workgroups: UNROLL = 1 (cfg3: 1 100, +0.9 %)
 
 struct GatherKeyDev {
     const uint8_t* src;
