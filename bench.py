@@ -6,11 +6,14 @@ buffer pre-filled with 2^18 transitions (episode length 100) and priorities rand
 update pass (SURVEY.md §8d "Synthetic inputs").  One "step" = one `SAC_Base.train()`:
 PER sample of 256 windows + every gradient/optimizer step + Polyak + priority / mu-prob write-back.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak]
 N > 1: one rank per GPU over RCCL — under torch.distributed.run, or spawned by this script itself when it is started
 plainly with --gpus N.  Every rank owns a replay shard (capacity 524288/N); gradients are mean all-reduced.
-  weak   (default)  every rank samples its own batch of 256: `value` = batch-256 steps of all ranks per second
-  strong the GLOBAL batch is 256, 256/N rows per rank: `value` = global-batch steps per second
+  strong (default) the GLOBAL batch stays the BASELINE's 256, 256/N rows per rank: `value` = global-batch
+         train steps per second — the BASELINE metric at every N
+  weak   every rank samples its own batch of 256 (global batch 256 N): `value` = batch-256 steps of all ranks per second
+`value` is always the rate of plain `SAC_Base.train()` calls (one call, one hipGraph launch, one step — the reference's
+loop); `value_runs_of_4` beside it is the same work issued as `SAC_Base.train_steps(4)` (one graph launch per four steps).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline      the dominant KERNEL of the step (launches grouped by kernel name, mean launch time from HIP events on
@@ -97,14 +100,14 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_td_update': 'asac::k_td_update'}
 SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
-ROUND = 'r02'
+ROUND = 'r03'
 
 
 def pmc_traffic(config: str, kernel: str):
     """(HBM bytes per launch, source) of a kernel (all template instances, launch-weighted), or (None, None): the PMC
     passes run under rocprofv3, not inside this process, so the committed summary of the same command is read
     (profiles/<round>_<config>_pmc_traffic.json, tools/summarize_pmc.py: FETCH_SIZE x2 (gfx950) + WRITE_SIZE)."""
-    for rnd in (ROUND, 'r01'):
+    for rnd in (ROUND, 'r02', 'r01'):
         path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_pmc_traffic.json'
         if not path.exists():
             continue
@@ -281,12 +284,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
-                    help='weak: batch 256 per GPU; strong: global batch 256, 256/N rows per GPU (SURVEY 8d)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong',
+                    help='strong (default): global batch 256, 256/N rows per GPU (SURVEY 8d, the BASELINE metric); '
+                         'weak: batch 256 per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--steps-per-launch', type=int, default=4,
-                    help='train steps per call of SAC_Base.train_steps (one hipGraph replay holds that many steps; 1 = train())')
+    ap.add_argument('--run-length', type=int, default=4,
+                    help='the secondary figure `value_runs_of_<k>`: the same steps issued as SAC_Base.train_steps(k) '
+                         '(one hipGraph replay holds k steps); 0 or 1 = skip it.  `value` is always plain train() calls')
     ap.add_argument('--no-extras', action='store_true', help='skip the saturating-size sweep and the cfg3-5 side runs')
     ap.add_argument('--profile-steps', type=int, default=50)
     ap.add_argument('--fill', type=int, default=None, help='transitions resident before timing')
@@ -314,7 +319,6 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    global_batch = CFG['batch_size']
     if args.scaling == 'strong':
         if CFG['batch_size'] % world:
             raise SystemExit(f'strong scaling needs the batch ({CFG["batch_size"]}) divisible by the ranks ({world})')
@@ -352,36 +356,33 @@ def main():
         agent.train()
     for _ in range(args.warmup):
         agent.train()
-    # EXACTLY `steps` train steps, issued as runs of `steps_per_launch` (SAC_Base.train_steps: one graph replay per run;
-    # the first run of that length captures its graph, so one is done before the clock starts) + single steps for the rest
-    spl = max(1, args.steps_per_launch)
-    if spl > 1:
-        agent.train_steps(spl)
+    # EXACTLY `steps` plain train() calls: one call = one step = one graph launch (the reference's loop, the metric)
+    def max_over_ranks(seconds):
+        if dist_ctx is None:
+            return seconds
+        t = torch.tensor([seconds], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps // spl):
-        agent.train_steps(spl)
-    for _ in range(args.steps % spl):
+    for _ in range(args.steps):
         agent.train()
     sync_all()
-    dt = time.perf_counter() - t0
-    if dist_ctx is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    # ... and the same number of steps once more as plain train() calls (one graph launch per step), reported beside it
-    dt_single = None
+    dt = max_over_ranks(time.perf_counter() - t0)
+    # ... and, reported beside it, the same number of steps as runs of k (SAC_Base.train_steps: one graph replay per run;
+    # the first run of that length captures its graph, so one is done before the clock starts)
+    spl, dt_runs = max(1, args.run_length), None
     if spl > 1:
+        agent.train_steps(spl)
         sync_all()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(args.steps // spl):
+            agent.train_steps(spl)
+        for _ in range(args.steps % spl):
             agent.train()
         sync_all()
-        dt_single = time.perf_counter() - t1
-        if dist_ctx is not None:
-            t = torch.tensor([dt_single], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt_single = float(t.item())
+        dt_runs = max_over_ranks(time.perf_counter() - t1)
     graph_used = agent._graph is not None
     agent.replay_buffer.check_health()
 
@@ -496,10 +497,10 @@ def main():
     if rank == 0:
         value = (world if args.scaling == 'weak' else 1) * args.steps / dt
         out = {
-            'metric': f'SAC train steps/sec (PER sample + grad step), batch {global_batch}',
+            'metric': f'SAC train steps/sec (PER sample + grad step), batch {CFG["batch_size"] * world}',
             'value': round(value, 2), 'unit': 'train_steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4),
-            'value_one_step_per_launch': None if dt_single is None else round((world if args.scaling == 'weak' else 1) * args.steps / dt_single, 2),
+            f'value_runs_of_{spl}': None if dt_runs is None else round((world if args.scaling == 'weak' else 1) * args.steps / dt_runs, 2),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{CFG["desc"]}, batch {CFG["batch_size"]} per GPU, {args.fill} transitions resident',
@@ -509,7 +510,7 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'ranks': world, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
                        'hipgraph': bool(graph_used),
-                       'steps_per_graph_launch': spl if (graph_used and agent._graph_runs.get(spl, (None, None, None))[2]) else 1},
+                       'steps_per_graph_launch': 1},
             'roofline': roofline, 'roofline_hbm': roofline_hbm, 'sweep': sweep, 'configs': configs,
             'kernels': kernels, 'cpu_baseline': cpu,
         }

@@ -15,12 +15,12 @@ timeout 900 python bench.py --no-extras --config cfg5 --steps 500 > $O/cfg5_benc
 timeout 600 python tools/kernel_sweep.py > $O/kernel_sweep.txt 2> $O/kernel_sweep.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmc_r /tmp/pmc_w /tmp/spmc_r /tmp/spmc_w
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-extras --no-cpu-baseline --profile-steps 0 --steps-per-launch 1 > /tmp/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-extras --no-cpu-baseline --profile-steps 0 --run-length 0 > /tmp/prof.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 cp $f $O/cfg2_kernel_stats.csv
 python $R/tools/summarize_rocprof.py $f 2100 45 > $O/cfg2_kernel_stats_summary.txt
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --steps-per-launch 1 > /tmp/r.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --steps-per-launch 1 > /tmp/w.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/r.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/w.log 2>&1
 python $R/tools/summarize_pmc.py $(find /tmp/pmc_r -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w -name "*counter_collection.csv" | head -1) $O/cfg2_pmc_traffic.json > $O/cfg2_pmc_traffic_all.txt
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/spmc_r -- python $R/tools/kernel_sweep.py > /tmp/sr.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/spmc_w -- python $R/tools/kernel_sweep.py > /tmp/sw.log 2>&1
@@ -29,15 +29,15 @@ f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_sequence.py $f > $O/cfg2_step_sequence.txt
 for c in cfg3 cfg4 cfg5; do
   rm -rf /tmp/prof_$c
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --profile-steps 0 --steps 200 --warmup 20 --fill 20000 --steps-per-launch 1 > /tmp/prof_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --profile-steps 0 --steps 200 --warmup 20 --fill 20000 --run-length 0 > /tmp/prof_$c.log 2>&1
   python $R/tools/step_sequence.py $(find /tmp/prof_$c -name "*kernel_trace.csv" | head -1) > $O/${c}_step_sequence.txt
   python $R/tools/summarize_rocprof.py $(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1) 220 30 > $O/${c}_kernel_stats_summary.txt
 done
 # HBM traffic of the representation kernels (cfg3 GRU, cfg4 / cfg5 convolution stack and attention): two PMC passes each
 for c in cfg3 cfg4 cfg5; do
   rm -rf /tmp/pmc_r_$c /tmp/pmc_w_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --steps 60 --warmup 10 --fill 20000 --profile-steps 0 --steps-per-launch 1 > /tmp/r_$c.log 2>&1
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --steps 60 --warmup 10 --fill 20000 --profile-steps 0 --steps-per-launch 1 > /tmp/w_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --steps 60 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/r_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --steps 60 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/w_$c.log 2>&1
   python $R/tools/summarize_pmc.py $(find /tmp/pmc_r_$c -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w_$c -name "*counter_collection.csv" | head -1) $O/${c}_pmc_traffic.json > $O/${c}_pmc_traffic_all.txt
 done
 ls -la $O
