@@ -445,7 +445,7 @@ class SAC_Base(AuxHeadsMixin):
         self._cq_buf, self._tq_buf, self._cq_td_buf = (torch.zeros(E, B, 1, **f32) for _ in range(3))
         self._pi_q, self._pi_stats_src = torch.zeros(E, B, 1, **f32), None
         self._pi_a, self._pi_logp, self._pi_sampled = torch.zeros(B, A1, **f32), torch.zeros(B, **f32), False
-        self._graph_exec, self._graph_exec_checked = None, False
+        self._graph_exec, self._graph_exec_checked, self._graph_stats_src = None, False, None
         # online + target representation over the same window: fused GRU layers pair up in one launch
         self._rep_twin = None
         if self._twin_rep and type(self.model_rep) is not ModelSimpleRep:
@@ -1858,6 +1858,9 @@ class SAC_Base(AuxHeadsMixin):
                 self._device_step()
             self._graph = graph
             self._graph_exec, self._graph_exec_checked = None, False
+            # (logp, scale) of the policy step live in THIS graph's private pool: whichever graph ran last is the one
+            # whose tensors `_refresh_policy_stats` must read (a k-step run has its own, `train_steps`)
+            self._graph_stats_src = self._pi_stats_src
             self._logger.info('train step captured into a hipGraph')
         except Exception as e:   # user models with host syncs etc.: stay eager, loudly
             self._graph_failed = True
@@ -1870,6 +1873,7 @@ class SAC_Base(AuxHeadsMixin):
         kernels).  The first replay goes through torch and watches the generator offset: if the
         captured step consumed no torch random numbers (all draws come from `asac_noise_fill`), later
         steps launch the instantiated graph directly."""
+        self._pi_stats_src = self._graph_stats_src
         if self._graph_exec is not None:
             native.graph_launch(self._graph_exec)
             return
@@ -1949,15 +1953,16 @@ class SAC_Base(AuxHeadsMixin):
                     for _ in range(k):
                         self._device_step()
                 torch.cuda.current_stream().wait_stream(side)
-                cached = self._graph_runs[k] = (self._graph, graph, int(graph.raw_cuda_graph_exec()))
+                cached = self._graph_runs[k] = (self._graph, graph, int(graph.raw_cuda_graph_exec()), self._pi_stats_src)
             except Exception as e:
                 torch.cuda.synchronize()
                 self._logger.warning(f'hipGraph capture of a {k}-step run failed, replaying single steps: {e!r}')
-                self._graph_runs[k] = cached = (self._graph, None, None)
+                self._graph_runs[k] = cached = (self._graph, None, None, None)
         if cached[2] is None:
             for _ in range(k):
                 step = self.train()
             return step
+        self._pi_stats_src = cached[3]      # the run's last step left its (logp, scale) in the run graph's pool
         with self._profiler('train', repeat=10):
             native.graph_launch(cached[2])
         self.global_step.add_(k)

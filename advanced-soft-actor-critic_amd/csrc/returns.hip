@@ -317,7 +317,15 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     }
     __syncthreads();
     // what follows has one lane per ROW (B <= blockDim.x): waves without a row leave (a finished wave no longer counts
-    // at the barriers of the climb: 4 waves instead of 16 at each of them for a batch of 256)
+    // at the barriers of the climb: 4 waves instead of 16 at each of them for a batch of 256).  This leans on the CDNA
+    // rule for S_BARRIER — "if some waves of the workgroup have already terminated, the barrier waits for the surviving
+    // waves only" (CDNA3 / CDNA4 ISA guide, S_BARRIER) — not on the HIP programming model, which wants every thread at a
+    // __syncthreads(): the condition is wave-uniform by construction (whole waves leave), and the file refuses to build
+    // for any other target (below).  tests/test_kernels_gpu.py::test_td_error_and_priority_update_in_one_launch covers
+    // batches that are not a multiple of the wave size and checks the tree invariant afterwards.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_td_update retires whole waves ahead of workgroup barriers: valid on gfx950 (CDNA S_BARRIER semantics) only"
+#endif
     if ((int)(threadIdx.x & ~63u) >= B) return;
     float y = 0.f, td = 0.f;
     if (row < B) {

@@ -235,14 +235,23 @@ def test_train_steps_is_the_train_calls_bit_for_bit(case):
         else:
             for _ in range(11):
                 agent.train()
+        # the logged statistics are formed on demand from the LAST step's buffers: after a run they must be the run's
+        # last step's (its graph's pool), after a single step following a run that step's again
+        stats = []
+        for _ in range(2):
+            agent._refresh_policy_stats()
+            stats.append(torch.stack([agent._stats['loss_policy'], agent._stats['c_entropy'], agent._stats['loss_q']]).clone())
+            agent.train()
         torch.cuda.synchronize()
         results.append((agent.get_global_step(), agent.replay_buffer._tree.clone(), agent._params.flat.clone(),
                         agent._target_params.flat.clone(), agent.replay_buffer._columns['mu_prob'].clone(),
-                        agent._opt_steps.clone(), agent.replay_buffer._beta.clone()))
+                        agent._opt_steps.clone(), agent.replay_buffer._beta.clone(), *stats))
         agent.close()
     assert results[0][0] == results[1][0]
-    for name, a, b in zip(('tree', 'weights', 'target weights', 'mu_prob', 'optimizer steps', 'beta'), results[0][1:], results[1][1:]):
+    names = ('tree', 'weights', 'target weights', 'mu_prob', 'optimizer steps', 'beta', 'stats after the run', 'stats one step later')
+    for name, a, b in zip(names, results[0][1:], results[1][1:]):
         assert torch.equal(a, b), name
+    assert not torch.equal(results[0][7], results[0][8])
 
 
 def test_data_parallel_path_single_rank_nccl():
