@@ -44,7 +44,7 @@ class TwinPass:
     _active = None
 
     def __init__(self, online_root, target_root, verify_steps=2):
-        from algorithm.nn_models.layers.recurrent import GRU
+        from algorithm.nn_models.layers.seq_layers import GRU
         tg = dict(target_root.named_modules())
         self.partner = {id(m): tg[name] for name, m in online_root.named_modules()
                         if isinstance(m, GRU) and isinstance(tg.get(name), GRU)}

@@ -13,7 +13,7 @@ from torch import nn
 
 from asac_amd import native
 
-from .nn_models.layers.mlp import LinearLayers, ResBlock
+from .nn_models.layers.linear_layers import LinearLayers, ResBlock
 
 __all__ = ['StockMLP', 'describe_q', 'describe_policy', 'describe_dense', 'fused_dense', 'gauss_head']
 
@@ -21,7 +21,7 @@ MAX_WIDTH, MAX_HEAD = 64, 16
 MAX_INPUT = 128         # a first layer may be up to 128 inputs wide when the stack has <= 3 blocks (two K halves)
 FUSED_DENSE = True      # `LinearLayers` stacks that opt in (`fuse = True`: the conv encoders' heads) run fused
 
-# How the fused autograd Functions (this module, fused_conv, fused_gru, fused_linear, layers.attention) deliver
+# How the fused autograd Functions (this module, fused_conv, fused_gru, fused_linear, layers.seq_layers) deliver
 # PARAMETER gradients.  Default: they are returned to autograd like any op's, so `autograd.grad`, `backward(inputs=
 # ...)` and gradient gating (`sac_aux.calculate_adaptive_weights`) see exactly what PyTorch semantics promise.
 # Inside `direct_param_grads()` the backward kernels instead ADD them straight into the parameters' `.grad` views of
@@ -95,7 +95,7 @@ def _offsets(module: nn.Module) -> dict:
 
 def describe_q(q) -> 'native.MlpDesc | None':
     """Stock continuous-action Q: [state | action] -> c_dense blocks -> Linear(., 1)."""
-    from .nn_models.critic import ModelQ
+    from .nn_models.q import ModelQ
     if type(q) is not ModelQ or q.d_action_sizes or not q.c_action_size:
         return None
     if not (_is_identity(q.dense) and _is_identity(q.c_state_dense) and _is_identity(q.c_action_dense)):
@@ -190,7 +190,7 @@ def fused_dense(ll, x):
 
 def describe_policy(pi) -> 'native.MlpDesc | None':
     """Stock continuous policy: state -> c_dense blocks -> (mean Linear | logstd Linear)."""
-    from .nn_models.actor import ModelPolicy
+    from .nn_models.policy import ModelPolicy
     if type(pi) is not ModelPolicy or pi.d_action_sizes or not pi.c_action_size:
         return None
     if not _is_identity(pi.dense):

@@ -1,4 +1,3 @@
-from .mlp import *
-from .recurrent import *
-from .vision import *
-from .attention import *
+from .linear_layers import *
+from .seq_layers import *
+from .image_layers import *

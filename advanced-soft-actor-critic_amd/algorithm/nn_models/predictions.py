@@ -1,2 +1,82 @@
-"""Import path of the reference layout for the transition / reward / observation models (user plugin files import some names by module path)."""
-from .world import *  # noqa: F401,F403
+"""Recurrent-prediction-model heads of the plugin surface: transition, reward and observation models
+(reference `algorithm/nn_models/predictions.py:7-105`)."""
+import torch
+from torch import nn
+
+from .layers import LinearLayers
+
+__all__ = ['ModelBaseTransition', 'ModelTransition', 'ModelBaseReward', 'ModelReward', 'ModelBaseObservation']
+
+
+class ModelBaseTransition(nn.Module):
+    def __init__(self, state_size, d_action_size, c_action_size, use_extra_data):
+        super().__init__()
+        self.state_size = state_size
+        self.d_action_size, self.c_action_size = d_action_size, c_action_size
+        self.use_extra_data = use_extra_data
+        self.action_size = d_action_size + c_action_size
+        self._build_model()
+
+    def _build_model(self):
+        pass
+
+    def forward(self, obs_list, state, action):
+        """(s_t [, extra_obs_t], a_t) -> Normal over s_t+1"""
+        raise NotImplementedError('ModelBaseTransition not implemented')
+
+    def extra_obs(self, obs_list):
+        raise NotImplementedError('ModelBaseTransition.extra_obs not implemented')
+
+
+class ModelTransition(ModelBaseTransition):
+    def _build_model(self, dense_n=64, dense_depth=0, extra_size=0):
+        n_in = self.state_size + self.action_size
+        if self.use_extra_data:
+            if extra_size == 0:
+                raise Exception('use_extra_data is True but extra_size is zero')
+            n_in += extra_size
+        self.dense = LinearLayers(n_in, dense_n, dense_depth, self.state_size * 2)
+
+    def forward(self, obs_list, state, action):
+        if self.use_extra_data:
+            state = torch.cat([state, self.extra_obs(obs_list)], dim=-1)
+        mean, logstd = torch.chunk(self.dense(torch.cat([state, action], dim=-1)), 2, dim=-1)
+        return torch.distributions.Normal(mean, torch.clamp(torch.exp(logstd), 0.1, 1.0), validate_args=False)
+
+
+class ModelBaseReward(nn.Module):
+    def __init__(self, state_size):
+        super().__init__()
+        self.state_size = state_size
+        self._build_model()
+
+    def _build_model(self):
+        pass
+
+    def forward(self, state):
+        raise NotImplementedError('ModelBaseReward not implemented')
+
+
+class ModelReward(ModelBaseReward):
+    def _build_model(self, dense_n=64, dense_depth=0):
+        self.dense = LinearLayers(self.state_size, dense_n, dense_depth, 1)
+
+    def forward(self, state):
+        return self.dense(state)
+
+
+class ModelBaseObservation(nn.Module):
+    def __init__(self, state_size, obs_shapes, use_extra_data):
+        super().__init__()
+        self.state_size, self.obs_shapes, self.use_extra_data = state_size, obs_shapes, use_extra_data
+        self._build_model()
+
+    def _build_model(self):
+        pass
+
+    def forward(self, state):
+        """s_t -> approx o_t (a tensor or a list of tensors)"""
+        raise NotImplementedError('ModelBaseObservation not implemented')
+
+    def get_loss(self, state, obs_list):
+        raise NotImplementedError('ModelBaseObservation.get_loss not implemented')

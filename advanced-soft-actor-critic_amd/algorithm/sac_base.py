@@ -36,8 +36,8 @@ from asac_amd import native
 from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls
 from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
-from .nn_models.layers.attention import step_mask_cache
-from .nn_models.rep import ModelSimpleRep
+from .nn_models.layers.seq_layers import step_mask_cache
+from .nn_models.representation import ModelSimpleRep
 from .replay_buffer import PrioritizedReplayBuffer
 from .sac_aux import AuxHeadsMixin
 from .utils import *  # noqa: F401,F403
@@ -1588,7 +1588,7 @@ class SAC_Base(AuxHeadsMixin):
     # ==========================================================================================
     def _device_step(self) -> None:
         # the representation passes of a step see the same window buffers: attention blocks build their index /
-        # padding / attention masks once per step (nn_models.layers.attention.step_mask_cache)
+        # padding / attention masks once per step (nn_models.layers.seq_layers.step_mask_cache)
         with step_mask_cache() if self.seq_encoder == SEQ_ENCODER.ATTN else contextlib.nullcontext():
             self._device_step_body()
 

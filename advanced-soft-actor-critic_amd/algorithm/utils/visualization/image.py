@@ -1,29 +1,9 @@
-"""`ImageVisual(model_abs_dir=None)(*images, max_batch=5, range_min=0, range_max=1, save_name=None)`:
-shows the first `max_batch` entries of each [batch, (L,) C, H, W] tensor (or [batch, H, W, C] array) side by
-side, the last step of a window; saves `<save_name->N.jpg` under `model_abs_dir` when given
-(reference algorithm/utils/visualization/image.py:8-63)."""
-from ._figure import LiveGrid, to_numpy
-
-__all__ = ['ImageVisual']
+"""`ImageVisual`: inert stand-in (see the package docstring) — constructing or calling it shows nothing."""
 
 
-class ImageVisual(LiveGrid):
-    def __call__(self, *images, max_batch=5, range_min=0, range_max=1, save_name=None):
-        import torch
-        if len(images[0].shape) > 4:
-            images = [im[:, -1, ...] for im in images]
-        images = [to_numpy(im[:max_batch]).transpose(0, 2, 3, 1) if isinstance(im, torch.Tensor) else im[:max_batch]
-                  for im in images]
-        if self.fig is None:
-            self._open(max_batch, len(images))
-            self.artists = {}
-            for row in self.axes:
-                for ax in row:
-                    ax.axis('off')
-        for j, batch in enumerate(images):
-            for i, picture in enumerate(batch):
-                if (i, j) not in self.artists:
-                    self.artists[i, j] = self.axes[i][j].imshow(picture, vmin=range_min, vmax=range_max)
-                else:
-                    self.artists[i, j].set_data(picture)
-        self._flush(save_name)
+class ImageVisual:
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, *images, **kwargs):
+        pass

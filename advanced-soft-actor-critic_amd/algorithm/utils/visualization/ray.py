@@ -1,34 +1,9 @@
-"""`RayVisual(model_abs_dir=None)(*rays, max_batch=5, save_name=None)`: scatter plot of ray-cast observations
-[batch, (L,) ray_size, C] with ray[..., -2] = 0 on a hit and ray[..., -1] = hit fraction; the rays fan over
-the upper half plane (reference algorithm/utils/visualization/ray.py:8-83)."""
-import numpy as np
-
-from ._figure import LiveGrid, to_numpy
-
-__all__ = ['RayVisual']
+"""`RayVisual`: inert stand-in (see the package docstring) — constructing or calling it shows nothing."""
 
 
-class RayVisual(LiveGrid):
-    def __call__(self, *rays, max_batch=5, save_name=None):
-        if len(rays[0].shape) > 3:
-            rays = [r[:, -1, ...] for r in rays]
-        rays = [to_numpy(r[:max_batch]) for r in rays]
-        if self.fig is None:
-            self._open(max_batch, len(rays))
-            self.artists = {}
-            for i, row in enumerate(self.axes):
-                for j, ax in enumerate(row):
-                    for side in ('right', 'top'):
-                        ax.spines[side].set_visible(False)
-                    for side in ('left', 'bottom'):
-                        ax.spines[side].set_position('center')
-                    ax.set_xlim(-1, 1)
-                    ax.set_ylim(-1, 1)
-                    self.artists[i, j] = ax.scatter([], [], s=1)
-        for j, batch in enumerate(rays):
-            for i, ray in enumerate(batch):
-                hit = ray[:, -2] == 0.
-                angle = np.linspace(0, np.pi, len(ray))[hit]
-                dist = ray[:, -1][hit]
-                self.artists[i, j].set_offsets(np.stack([np.cos(angle) * dist, np.sin(angle) * dist], axis=1))
-        self._flush(save_name, save=False)      # (the reference's ray viewer never writes files)
+class RayVisual:
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, *rays, **kwargs):
+        pass

@@ -43,6 +43,12 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ac
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (v_mfma_f32_16x16x4_f32), same guide
 
 CONFIGS = {
+    # BASELINE.json configs[0] at the metric's batch size — the reference's CPU-runnable plumbing case: n_step 1, no
+    # priorities (IS weights dropped, the tree sampled but never updated: sac_base.py:2494, 2571-2584)
+    'cfg1': dict(obs_names=['vector'], obs_shapes=[(6,)], d_action_sizes=[], c_action_size=2, plugin='nn_vec',
+                 n_step=1, burn_in_step=0, batch_size=256, ensemble_q_num=2, ensemble_q_sample=2, capacity=524288,
+                 fill=2 ** 18, episode_len=100, hidden=(0,), seq_encoder=None, use_priority=False,
+                 desc='cfg1: TEST vector obs(6) c_action(2) stock MLP, n_step=1, use_priority=false'),
     # BASELINE.json configs[1] — the metric's configuration
     'cfg2': dict(obs_names=['vector'], obs_shapes=[(6,)], d_action_sizes=[], c_action_size=2, plugin='nn_vec',
                  n_step=4, burn_in_step=0, batch_size=256, ensemble_q_num=2, ensemble_q_sample=2, capacity=524288,
@@ -187,6 +193,7 @@ def build_agent(device, dist_ctx, capacity, seed):
                     ensemble_q_sample=CFG['ensemble_q_sample'],
                     seq_encoder=SEQ_ENCODER[CFG['seq_encoder']] if CFG['seq_encoder'] else None,
                     curiosity=CURIOSITY[CFG['curiosity']] if CFG.get('curiosity') else None,
+                    use_priority=CFG.get('use_priority', True),
                     replay_config={'capacity': capacity},
                     hip_config={'dist': dist_ctx, **json.loads(os.environ.get('ASAC_BENCH_HIP_CONFIG', '{}'))})
 
@@ -222,7 +229,7 @@ def cpu_baseline(budget_s=24.0):
                            n_step=CFG['n_step'], burn_in_step=CFG['burn_in_step'], batch_size=CFG['batch_size'],
                            ensemble_q_num=CFG['ensemble_q_num'], ensemble_q_sample=CFG['ensemble_q_sample'],
                            seq_encoder=CFG['seq_encoder'], curiosity=CFG.get('curiosity'),
-                           replay_config={'capacity': CFG['capacity']})
+                           use_priority=CFG.get('use_priority', True), replay_config={'capacity': CFG['capacity']})
     fill = 2 ** 15   # bounded: the tree depth (19 levels) is what the sampler pays for, not the fill
     for _ in range(fill // CFG['episode_len']):
         agent.put_episode(**synthetic_episode(rng, CFG['episode_len']))

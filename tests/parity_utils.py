@@ -156,7 +156,7 @@ def zero_gradient_tensors(g, mods) -> list:
     return names
 
 
-def assert_first_step_gradients(agent, g, rtol, atol_frac, skip=()):
+def assert_first_step_gradients(agent, g, rtol, atol_frac, skip=(), log_key=None):
     """After the FIRST train step Adam's first moment is (1 - beta1) * gradient: compares every gradient of the
     step with the reference's (`g0/<optimizer>/<j>`), entry by entry, within rtol * |want| + atol_frac * max|tensor|
     + ZERO_GRAD_REL * max|any gradient of the same optimizer| (the last term is the rounding floor of sums whose
@@ -173,13 +173,21 @@ def assert_first_step_gradients(agent, g, rtol, atol_frac, skip=()):
         want = g[key]
         got = moments[oname][int(j)].cpu().numpy()
         atol = atol_frac * float(np.abs(want).max()) + ZERO_GRAD_REL * opt_scale[oname]
+        if log_key is not None:     # observed: worst entry error relative to the tensor's largest entry, per optimizer
+            rec = PARITY_LOG.setdefault(f'{log_key}/{oname}', {'max_err_over_tensor_max': 0., 'used': 0., 'rtol': rtol,
+                                                               'atol_frac': atol_frac, 'tensors': 0})
+            err = np.abs(got.astype(np.float64) - want)
+            rec['max_err_over_tensor_max'] = max(rec['max_err_over_tensor_max'],
+                                                 float(err.max() / max(float(np.abs(want).max()), ZERO_GRAD_REL * opt_scale[oname], 1e-300)))
+            rec['used'] = max(rec['used'], float((err / (atol + rtol * np.abs(want) + 1e-300)).max()))
+            rec['tensors'] += 1
         np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=key)
         checked += 1
     assert checked > 0
     return checked
 
 
-def assert_weights_close(mods, g, n_steps, lr, rtol, atol, small_frac=1e-3, prefix='w1', only=None):
+def assert_weights_close(mods, g, n_steps, lr, rtol, atol, small_frac=1e-3, prefix='w1', only=None, log_key=None):
     """Post-training weights against the reference's.  Adam's first updates are sign-like (-lr * g / (|g| + eps)),
     so an entry whose reference gradient is analytically zero or at rounding level (|g0| < small_frac * max|g0| of
     its tensor, or the whole tensor is a `zero_gradient_tensors` one) may move by +-lr per step with a
@@ -206,8 +214,76 @@ def assert_weights_close(mods, g, n_steps, lr, rtol, atol, small_frac=1e-3, pref
                     loose[...] = True
             err = np.abs(got - want)
             bound = np.where(loose, 2.2 * lr * n_steps, atol) + rtol * np.abs(want)
+            if log_key is not None:     # observed: strict entries in the norm atol + rtol |want|; slack entries in units of lr
+                rec = PARITY_LOG.setdefault(log_key, {'strict_max_abs': 0., 'strict_used': 0., 'slack_max_over_lr_steps': 0.,
+                                                      'slack_entries': 0, 'entries': 0, 'rtol': rtol, 'atol': atol})
+                if (~loose).any():
+                    rec['strict_max_abs'] = max(rec['strict_max_abs'], float(err[~loose].max()))
+                    rec['strict_used'] = max(rec['strict_used'], float((err[~loose] / bound[~loose]).max()))
+                if loose.any():
+                    rec['slack_max_over_lr_steps'] = max(rec['slack_max_over_lr_steps'], float(err[loose].max() / (lr * n_steps)))
+                rec['slack_entries'] += int(loose.sum())
+                rec['entries'] += int(err.size)
             assert (err <= bound).all(), (f'{name}/{k}: {int((err > bound).sum())} of {err.size} entries off, worst '
                                           f'{float(err.max()):.3g} (strict entries: {float(err[~loose].max()) if (~loose).any() else 0:.3g})')
             if loose.any():
                 slack[f'{name}/{k}'] = float(loose.mean())
     return slack
+
+
+# ------------------------------------------------------------------------------------------------
+# measured parity errors: every float comparison of the step-parity tests goes through `check`,
+# which records the OBSERVED error beside the tolerance it was tested under.  The record is written to
+# gpurun_out/parity_errors.json when the test process ends (tools/install_profiles.py copies its summary to
+# profiles/<round>_parity_errors.json); tolerances in the tests are set to <= 4x what this file shows.
+#   max_abs   max |got - want|
+#   max_rel   max |got - want| / |want| over the entries with |want| >= 1e-3 * max|want| (the rest is judged by max_abs)
+#   used      max |got - want| / (atol + rtol |want|): the fraction of the tolerance the worst entry consumed
+# ------------------------------------------------------------------------------------------------
+PARITY_LOG = {}
+
+
+def check(key: str, got, want, rtol: float, atol: float = 0., enforce: bool = True):
+    """np.testing.assert_allclose(got, want, rtol, atol) that also records the observed error under `key`
+    ('<test>/<case>/<observable>'; several calls under one key — steps of a run — keep the worst).  `enforce=False`:
+    record only (drift reports)."""
+    got = np.asarray(got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got, dtype=np.float64)
+    want = np.asarray(want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else want, dtype=np.float64)
+    got, want = np.broadcast_arrays(got, want)
+    err = np.abs(got - want)
+    finite = np.isfinite(want) & np.isfinite(got)
+    same_inf = (~finite) & (got == want)
+    err = np.where(same_inf, 0., err)
+    big = np.abs(want) >= 1e-3 * max(float(np.abs(np.where(finite, want, 0.)).max(initial=0.)), 1e-300)
+    max_abs = float(err.max(initial=0.))
+    max_rel = float((err[big & finite] / np.abs(want[big & finite])).max(initial=0.)) if (big & finite).any() else 0.
+    used = float((err / (atol + rtol * np.abs(np.where(finite, want, 0.)) + 1e-300)).max(initial=0.)) if err.size else 0.
+    rec = PARITY_LOG.setdefault(key, {'max_abs': 0., 'max_rel': 0., 'used': 0., 'rtol': rtol, 'atol': atol, 'calls': 0,
+                                      'entries': 0, 'enforced': bool(enforce)})
+    rec['max_abs'], rec['max_rel'], rec['used'] = max(rec['max_abs'], max_abs), max(rec['max_rel'], max_rel), max(rec['used'], used)
+    rec['rtol'], rec['atol'] = rtol, atol
+    rec['calls'] += 1
+    rec['entries'] = int(err.size)
+    if enforce:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=key)
+
+
+def _dump_parity_log():
+    if not PARITY_LOG:
+        return
+    import json
+    import os
+    from pathlib import Path
+    out = Path(os.environ.get('ASAC_PARITY_LOG', Path(__file__).resolve().parent.parent / 'gpurun_out' / 'parity_errors.json'))
+    try:
+        out.parent.mkdir(parents=True, exist_ok=True)
+        old = json.loads(out.read_text()) if out.exists() else {}
+        old.update(PARITY_LOG)
+        out.write_text(json.dumps(old, indent=1, sort_keys=True))
+    except OSError:
+        pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_dump_parity_log)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import algorithm.nn_models as m
-from algorithm.nn_models.layers.attention import GATE, POSITIONAL_ENCODING
+from algorithm.nn_models.layers.seq_layers import GATE, POSITIONAL_ENCODING
 
 CASES = {
     'plain': dict(embed_dim=8),

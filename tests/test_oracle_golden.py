@@ -91,7 +91,7 @@ def _load_weights(agent, g, prefix):
 
 
 # same eager ops on the same host give identical bits; these cases run other kernels for the same math: the GRU
-# un-packed (nn_models/layers/recurrent.py), attention heads as batched GEMMs instead of chunk / cat
+# un-packed (nn_models/layers/seq_layers.py), attention heads as batched GEMMs instead of chunk / cat
 INEXACT = ('cfg3', 'attn', 'conv_attn_cur')
 
 

@@ -52,8 +52,31 @@ TRAINED_REP = ('cfg3', 'attn', 'conv', 'conv_attn_cur')
 REFERENCE_ILL_CONDITIONED = {'attn': ('optimizer_policy',)}
 
 
-@pytest.mark.parametrize('case', list(pu.STEP_CASES))
-def test_full_step_vs_reference_golden(golden_dir, case):
+# observable -> (rtol, atol); per-case overrides below.  Set from the OBSERVED errors (profiles/r03_parity_errors.json,
+# written by `parity_utils.check`): each bound is <= 4x the worst error seen on MI355X in the norm atol + rtol |want|.
+TOL = {
+    'is_weights': (2e-6, 0.), 'loss_q': (2e-4, 0.), 'loss_policy': (2e-4, 2e-5), 'c_entropy': (2e-4, 2e-5),
+    'd_entropy': (2e-4, 2e-5), 'loss_curiosity': (2e-4, 0.), 'td_error': (2e-4, 2e-5), 'tree': (2e-4, 1e-6),
+    'mu_prob': (1e-3, 1e-6), 'hidden': (2e-4, 2e-5), 'log_c_alpha': (1e-5, 0.),
+    'grad0': (2e-3, 2e-5),          # (rtol, fraction of the tensor's largest entry)
+    'weights': (5e-4, 2e-5),
+}
+TOL_CASE = {
+    # what the step computes after the policy update inherits the policy's difference where the reference's own
+    # policy gradient is ill-conditioned (see REFERENCE_ILL_CONDITIONED)
+    ('attn', 'td_error'): (3e-3, 2e-5), ('attn', 'tree'): (3e-3, 1e-6), ('attn', 'log_c_alpha'): (5e-5, 0.),
+}
+TOL_LATER_STEPS_ILL = 3e-3      # `attn`, steps after the first: they start from the policy the first one left
+
+
+def tol(case, observable):
+    return TOL_CASE.get((case, observable), TOL[observable])
+
+
+def run_golden_case(golden_dir, case, align: bool, tag: str):
+    """One pass over the recorded steps of `case`.  `align`: trained-representation cases compare the freshly updated
+    representation / critic weights with the reference's and then continue from the reference's (see above);
+    `align=False` runs the product end to end on its own weights (drift report)."""
     from algorithm.fused import RecordedNoise
     g = np.load(golden_dir / f'f6_step_{case}.npz')
     io = pu.STEP_CASES[case][3]
@@ -62,22 +85,27 @@ def test_full_step_vs_reference_golden(golden_dir, case):
     for ep in pu.golden_episodes(g, len(io['obs_shapes'])):
         agent.put_episode(**ep)
     rb = agent.replay_buffer
-    rt = 2e-4
-    # what the step computes after the policy update inherits the policy's difference where the reference's own
-    # policy gradient is ill-conditioned (see REFERENCE_ILL_CONDITIONED)
-    rt_post = 3e-3 if case in REFERENCE_ILL_CONDITIONED else rt
+    ill = case in REFERENCE_ILL_CONDITIONED
     n_steps = int(g['n_steps'])
     step_box, slack_rq = [0], {}
+    K = f'{tag}/{case}'
+
+    def chk(observable, got, want, later=False):
+        rt, at = tol(case, observable) if tag == 'step' else DRIFT_TOL.get((case, observable), DRIFT_TOL.get(observable, tol(case, observable)))
+        if later and ill and tag == 'step':
+            rt = max(rt, TOL_LATER_STEPS_ILL)
+        pu.check(f'{K}/{observable}', got, want, rt, at)
 
     def align_with_reference():
         s_ = step_box[0]
         # one Adam update away from weights that were aligned (or loaded) before it
-        slack_rq.update(pu.assert_weights_close(mods, g, 1, LR, rtol=5e-4, atol=2e-5, prefix=f'step{s_}/w_rq'))
+        slack_rq.update(pu.assert_weights_close(mods, g, 1, LR, *tol(case, 'weights'), prefix=f'step{s_}/w_rq', log_key=f'{K}/w_rq'))
         pu.load_golden_weights(agent, g, prefix=f'step{s_}/w_rq')
 
-    if case in TRAINED_REP:
+    if case in TRAINED_REP and align:
         assert f'step0/w_rq/model_q_0/{next(iter(agent.model_q_list[0].state_dict()))}' in g.files
         agent.after_rep_q_update = align_with_reference
+    ids_equal = True
     for s in range(n_steps):
         step_box[0] = s
         eps = [g[f'step{s}/eps{j}'] for j in range(int(g[f'step{s}/n_eps']))]
@@ -86,48 +114,82 @@ def test_full_step_vs_reference_golden(golden_dir, case):
         alpha_before = agent.log_c_alpha.detach().clone()
         assert agent.train() == s + 1
         assert agent.noise.exhausted(), 'every recorded draw must be consumed, in order'
-        assert np.array_equal(rb._ids.cpu().numpy(), g[f'step{s}/sample_ids']), f'step {s}: PER index selection'
-        np.testing.assert_allclose(rb._w.cpu().numpy()[:, None], g[f'step{s}/is_weights'], rtol=2e-6)
-        rt_s = rt if s == 0 else rt_post       # later steps start from the policy the earlier ones left
-        np.testing.assert_allclose(agent._stats['loss_q'].item(), g[f'step{s}/loss_q'], rtol=rt_s)
+        same = np.array_equal(rb._ids.cpu().numpy(), g[f'step{s}/sample_ids'])
+        if not same and not align and s > 0:
+            # un-aligned run: index selection is a discontinuous function of priorities that now differ at rounding
+            # level — report and stop comparing (everything downstream is a different batch)
+            ids_equal = False
+            pu.PARITY_LOG[f'{K}/ids_differ_from_step'] = {'step': s}
+            break
+        assert same, f'step {s}: PER index selection'
+        later = s > 0
+        chk('is_weights', rb._w.cpu().numpy()[:, None], g[f'step{s}/is_weights'])
+        chk('loss_q', agent._stats['loss_q'].item(), g[f'step{s}/loss_q'], later)
         # the policy objective and the entropy the reference returns from _train_policy (sac_base.py:1903-1911)
         agent._refresh_policy_stats(alpha_before)
-        np.testing.assert_allclose(agent._stats['loss_policy'].item(), g[f'step{s}/loss_policy'], rtol=rt_s, atol=2e-5)
+        chk('loss_policy', agent._stats['loss_policy'].item(), g[f'step{s}/loss_policy'], later)
         if f'step{s}/c_entropy' in g.files:
-            np.testing.assert_allclose(agent._stats['c_entropy'].item(), g[f'step{s}/c_entropy'], rtol=rt_s, atol=2e-5)
+            chk('c_entropy', agent._stats['c_entropy'].item(), g[f'step{s}/c_entropy'], later)
         if f'step{s}/d_entropy' in g.files:
-            np.testing.assert_allclose(agent._stats['d_entropy'].item(), g[f'step{s}/d_entropy'], rtol=rt_s, atol=2e-5)
+            chk('d_entropy', agent._stats['d_entropy'].item(), g[f'step{s}/d_entropy'], later)
         if f'step{s}/loss_curiosity' in g.files:
-            np.testing.assert_allclose(agent._stats['loss_curiosity'].item(), g[f'step{s}/loss_curiosity'], rtol=rt_s)
-        if s == 0:
-            pu.assert_first_step_gradients(agent, g, rtol=2e-3, atol_frac=2e-5, skip=REFERENCE_ILL_CONDITIONED.get(case, ()))
+            chk('loss_curiosity', agent._stats['loss_curiosity'].item(), g[f'step{s}/loss_curiosity'], later)
+        if s == 0 and align:
+            pu.assert_first_step_gradients(agent, g, rtol=tol(case, 'grad0')[0], atol_frac=tol(case, 'grad0')[1],
+                                           skip=REFERENCE_ILL_CONDITIONED.get(case, ()), log_key=f'{K}/grad0')
         if f'step{s}/td_error' in g.files:
-            np.testing.assert_allclose(agent._td_error.cpu().numpy()[:, None], g[f'step{s}/td_error'],
-                                       rtol=rt_post, atol=2e-5)
-            np.testing.assert_allclose(rb._tree.cpu().numpy(), g[f'step{s}/tree'], rtol=rt_post, atol=1e-6)
-        # stored-action probabilities are exp() of a log-density with 1/sigma^2 gain on f32 noise of loc: 1e-3
+            chk('td_error', agent._td_error.cpu().numpy()[:, None], g[f'step{s}/td_error'])
+            chk('tree', rb._tree.cpu().numpy(), g[f'step{s}/tree'])
+        # stored-action probabilities are exp() of a log-density with 1/sigma^2 gain on f32 noise of loc
         mu, mu_want = rb._columns['mu_prob'].cpu().numpy(), g[f'step{s}/mu_prob']
-        if case in REFERENCE_ILL_CONDITIONED:   # ... and sigma = 7e-9 there: a density of 1e8 next to 0
+        if ill:   # ... and sigma = 7e-9 there: a density of 1e8 next to 0
             bad = np.abs(mu - mu_want) > 1e-3 + 5e-2 * np.abs(mu_want)
             assert bad.mean() <= 0.01, f'{bad.sum()} / {bad.size} written-back probabilities differ'
         else:
-            np.testing.assert_allclose(mu, mu_want, rtol=1e-3, atol=1e-6)
+            chk('mu_prob', mu, mu_want)
         if rb._columns['pre_seq_hidden_state'].shape[-1]:
-            np.testing.assert_allclose(rb._columns['pre_seq_hidden_state'].cpu().numpy(), g[f'step{s}/hidden'],
-                                       rtol=rt_s, atol=2e-5)
-        np.testing.assert_allclose(agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'], rtol=5e-5 if case in REFERENCE_ILL_CONDITIONED else 1e-5)
+            chk('hidden', rb._columns['pre_seq_hidden_state'].cpu().numpy(), g[f'step{s}/hidden'], later)
+        chk('log_c_alpha', agent.log_c_alpha.item(), g[f'step{s}/log_c_alpha'])
+    return agent, g, mods, n_steps, slack_rq, ids_equal
+
+
+@pytest.mark.parametrize('case', list(pu.STEP_CASES))
+def test_full_step_vs_reference_golden(golden_dir, case):
+    agent, g, mods, n_steps, slack_rq, _ = run_golden_case(golden_dir, case, align=True, tag='step')
+    rb = agent.replay_buffer
     # the parameters with an analytically zero gradient, by name: the key-projection biases of the attention blocks
     zero = pu.zero_gradient_tensors(g, mods)
     assert all('k_proj' in z and z.endswith('bias') for z in zero), zero
     assert bool(zero) == ('attn' in case)
     ill = [m for m in mods if any('model_' + o.split('_', 1)[1] == m for o in REFERENCE_ILL_CONDITIONED.get(case, ()))]
-    slack = pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5, only=[m for m in mods if m not in ill])
+    wt = tol(case, 'weights')
+    slack = pu.assert_weights_close(mods, g, n_steps, LR, *wt, only=[m for m in mods if m not in ill], log_key=f'step/{case}/weights')
     if ill:     # a gradient the reference itself only knows to 2 %: the sign of entries below 10 % of the largest is open
-        slack.update(pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-4, atol=2e-5, small_frac=0.1, only=ill))
+        slack.update(pu.assert_weights_close(mods, g, n_steps, LR, *wt, small_frac=0.1, only=ill, log_key=f'step/{case}/weights_ill'))
     print(f'{case}: zero-gradient parameters {zero}; entries given +-lr slack after the first update {slack_rq}, '
           f'after {n_steps} steps {slack}')
     rb.check_health()
     assert rb.check_tree_invariant() == 0
+    agent.close()
+
+
+# Un-aligned runs of the trained-representation cases: the product runs the recorded steps END TO END on its own
+# weights (no `after_rep_q_update` hook), so what the policy step, the TD errors and the write-backs inherit from
+# rounding-level differences in the representation / critic update is measured instead of argued.  Bounds: the sign
+# flips of Adam's first update move single weights by 2 lr = 6e-4; observables downstream move accordingly.
+DRIFT_TOL = {
+    'loss_q': (2e-3, 0.), 'loss_policy': (2e-3, 2e-4), 'c_entropy': (2e-3, 2e-4), 'loss_curiosity': (2e-3, 0.),
+    'td_error': (5e-3, 5e-4), 'tree': (5e-3, 1e-5), 'mu_prob': (1e-2, 1e-5), 'hidden': (2e-3, 2e-4), 'log_c_alpha': (1e-4, 0.),
+    'is_weights': (1e-3, 0.),
+}
+
+
+@pytest.mark.parametrize('case', [c for c in TRAINED_REP if c not in REFERENCE_ILL_CONDITIONED])
+def test_full_step_unaligned_drift(golden_dir, case):
+    agent, g, mods, n_steps, _, ids_equal = run_golden_case(golden_dir, case, align=False, tag='drift')
+    if ids_equal:
+        pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-3, atol=2e-4, small_frac=0.05, log_key=f'drift/{case}/weights')
+    agent.replay_buffer.check_health()
     agent.close()
 
 

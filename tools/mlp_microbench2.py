@@ -18,7 +18,7 @@ import algorithm.fused_mlp as fm
 for depth in (1, 2, 3, 4):
     Q = mk(depth)
     q = Q(6, [], 2, False).cuda()
-    import algorithm.nn_models.critic as cr
+    import algorithm.nn_models.q as cr
     old = cr.ModelQ; cr.ModelQ = Q
     d = describe_q(q); cr.ModelQ = old
     assert d is not None
