@@ -2,6 +2,7 @@
 // C ABI in include/asac_hip.h.  Pure streaming kernels: 12 B/param (Polyak), 28 B/param (Adam);
 // 16-byte loads/stores, grid capped at 2048 workgroups with a grid-stride loop.
 #include "asac_common.h"
+#include "asac_gelu.h"
 #include "asac_sidecar.h"
 
 #include <cmath>
@@ -131,7 +132,25 @@ inline int stream_grid(int64_t n_vec) {
 
 using namespace asac;
 
+// The activation of every fused MLP / convolution kernel, element by element (asac_gelu.h), so that its distance from
+// torch.nn.functional.gelu can be measured through the C ABI (tests/test_kernels_gpu.py::test_gelu_against_torch).
+__global__ __launch_bounds__(256) void k_gelu_eval(const float* __restrict__ z, float* __restrict__ value,
+                                                   float* __restrict__ deriv, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v, d;
+        gelu_parts(z[i], v, d);
+        value[i] = v;
+        deriv[i] = d;
+    }
+}
+
 extern "C" {
+
+int asac_gelu_eval(const float* z, float* value, float* deriv, int64_t n, void* stream) {
+    if (n <= 0 || !z || !value || !deriv) return bad_arg("asac_gelu_eval");
+    ASAC_LAUNCH(k_gelu_eval, dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), z, value, deriv, n);
+    return finish_launch("asac_gelu_eval");
+}
 
 int asac_polyak(float* target, const float* source, int64_t n, float tau, void* stream) {
     if (n <= 0) return bad_arg("asac_polyak");

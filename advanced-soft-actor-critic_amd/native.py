@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 48
+ABI_VERSION = 49
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -139,6 +139,7 @@ _SIGNATURES = {
                                C.c_void_p, C.c_void_p]),
     'asac_sumtree_leaf_max': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_sumtree_check': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_gelu_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'asac_window_gather_pad': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_sumtree_descend': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -450,6 +451,10 @@ def sumtree_leaf_max(tree, capacity, out):
 
 def sumtree_check(tree, capacity, out):
     _check(load().asac_sumtree_check(_p(tree), capacity, _p(out), _stream()), 'asac_sumtree_check')
+
+
+def gelu_eval(z, value, deriv):
+    _check(load().asac_gelu_eval(_p(z), _p(value), _p(deriv), z.numel(), _stream()), 'asac_gelu_eval')
 
 
 @_profiled

@@ -64,14 +64,16 @@ CONFIGS = {
                  plugin='nn_conv', n_step=3, burn_in_step=5, batch_size=512, ensemble_q_num=4, ensemble_q_sample=2,
                  capacity=65536, fill=2 ** 15, episode_len=100, hidden=(0,), seq_encoder=None,
                  desc='cfg4: vector(10)+image(3,30,30) conv rep, ensemble 4 (2 sampled), b=5 n=3, PER capacity 65536'),
-    # configs[4] — conv + episodic attention rep, FORWARD curiosity, batch 1024.  `use_prediction` is left out:
-    # the reference itself cannot run it with a trainable representation
+    # configs[4] — conv + episodic attention rep, FORWARD curiosity, recurrent prediction models, batch 1024.  (The
+    # reference itself raises with `use_prediction` and a trainable representation — its `_train_rpm` differentiates a
+    # graph its Q loss has freed; here the graph is kept and the head runs; `_train_rpm` itself is
+    # pinned against the reference's, tests/golden/f11_rpm.npz)
     'cfg5': dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 30, 30)], d_action_sizes=[], c_action_size=4,
                  plugin='nn_conv_attn', n_step=3, burn_in_step=5, batch_size=1024, ensemble_q_num=2,
                  ensemble_q_sample=2, capacity=65536, fill=2 ** 15, episode_len=100, hidden=(8,), seq_encoder='ATTN',
-                 curiosity='FORWARD',
-                 desc='cfg5: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, PER capacity 65536; '
-                      'use_prediction: omitted (the reference itself raises with a trainable representation)'),
+                 curiosity='FORWARD', use_prediction=True,
+                 desc='cfg5: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, use_prediction '
+                      '(transition / reward / observation models), b=5 n=3, PER capacity 65536'),
 }
 CFG = dict(CONFIGS['cfg2'])
 
@@ -193,7 +195,7 @@ def build_agent(device, dist_ctx, capacity, seed):
                     ensemble_q_sample=CFG['ensemble_q_sample'],
                     seq_encoder=SEQ_ENCODER[CFG['seq_encoder']] if CFG['seq_encoder'] else None,
                     curiosity=CURIOSITY[CFG['curiosity']] if CFG.get('curiosity') else None,
-                    use_priority=CFG.get('use_priority', True),
+                    use_priority=CFG.get('use_priority', True), use_prediction=CFG.get('use_prediction', False),
                     replay_config={'capacity': capacity},
                     hip_config={'dist': dist_ctx, **json.loads(os.environ.get('ASAC_BENCH_HIP_CONFIG', '{}'))})
 
@@ -229,7 +231,8 @@ def cpu_baseline(budget_s=24.0):
                            n_step=CFG['n_step'], burn_in_step=CFG['burn_in_step'], batch_size=CFG['batch_size'],
                            ensemble_q_num=CFG['ensemble_q_num'], ensemble_q_sample=CFG['ensemble_q_sample'],
                            seq_encoder=CFG['seq_encoder'], curiosity=CFG.get('curiosity'),
-                           use_priority=CFG.get('use_priority', True), replay_config={'capacity': CFG['capacity']})
+                           use_priority=CFG.get('use_priority', True), use_prediction=CFG.get('use_prediction', False),
+                           replay_config={'capacity': CFG['capacity']})
     fill = 2 ** 15   # bounded: the tree depth (19 levels) is what the sampler pays for, not the fill
     for _ in range(fill // CFG['episode_len']):
         agent.put_episode(**synthetic_episode(rng, CFG['episode_len']))

@@ -13,8 +13,14 @@
  *   - `stream` is a hipStream_t passed as void*
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch / argument check
  *     (asac_last_error() gives text)
- *   - f32 arithmetic follows the reference's evaluation order; the library is built with
- *     -ffp-contract=off so no multiply-add is fused behind the reference's back
+ *   - f32 sums, products and scans follow the reference's evaluation order; the library is built with
+ *     -ffp-contract=off so no multiply-add is fused behind the reference's back.  Transcendentals are the device's
+ *     (`expf`, `logf`, `tanhf`, `powf`: within a few ulp of the host's).  ONE function is an approximation by design:
+ *     GELU inside the fused MLP / convolution kernels is x * Phi(x) with erf from Abramowitz-Stegun 7.1.26 (one
+ *     `__expf`, one `v_rcp_f32`; csrc/asac_gelu.h) instead of ATen's erff.  Bound, against float64 GELU on [-12, 12]:
+ *     |gelu - gelu64| <= 6e-7 + 3e-7 |gelu64|, |gelu' - gelu64'| <= 6e-7 (observed on MI355X: 4.6e-7 and 2.8e-7;
+ *     ATen's own f32 GELU is 4.5e-7 from the same float64 values) — asserted by
+ *     tests/test_kernels_gpu.py::test_gelu_against_torch through asac_gelu_eval() below
  */
 #ifndef ASAC_HIP_H
 #define ASAC_HIP_H
@@ -25,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 48
+#define ASAC_ABI_VERSION 49
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -108,6 +114,11 @@ int asac_sumtree_leaf_max(const float* tree, int capacity, float* out, void* str
 
 /* Debug invariant: counts internal nodes with tree[i] != tree[2i+1]+tree[2i+2] into out[0]. */
 int asac_sumtree_check(const float* tree, int capacity, int32_t* out, void* stream);
+
+/* Measurement: value[i] = gelu(z[i]), deriv[i] = gelu'(z[i]) exactly as the fused MLP / convolution kernels evaluate
+ * them (replaces nothing: the reference's activation is ATen's `nn.GELU()`, linear_layers.py:24-119; this exposes
+ * the library's evaluation so that its distance from ATen's can be bounded by a test). */
+int asac_gelu_eval(const float* z, float* value, float* deriv, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Ring storage: window gather with episode-continuity padding, and predicated row scatter.

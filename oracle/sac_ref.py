@@ -14,7 +14,9 @@ Each function cites the reference lines it restates.  Every random draw (stratif
 Gaussian noise, ensemble permutations) comes from `self.noise`, so recorded draws can be replayed.
 Scope: vector/any observations through user `ModelRep`, continuous and/or discrete (non
 DQN-like) actions, n-step V-trace, ensemble-min, PER, seq_encoder None / RNN / ATTN, optional
-FORWARD/INVERSE curiosity.  Siamese / RND / prediction heads are outside the hot path.
+FORWARD/INVERSE curiosity, and the recurrent prediction models (`use_prediction`: `_train_rpm` with the cosine-sign
+gating of `calculate_adaptive_weights`, pinned by `tests/golden/f11_rpm.npz`).  Siamese / RND heads are compared
+against their own recorded reference steps directly (tests/test_sac_aux_gpu.py).
 """
 import numpy as np
 import torch
@@ -147,7 +149,8 @@ class SacRef:
                  init_log_alpha=-2.3, use_auto_alpha=True, target_d_alpha=0.98, target_c_alpha=1.,
                  d_policy_entropy_penalty=0.5, learning_rate=3e-4, gamma=0.99, v_lambda=1.,
                  v_rho=1., v_c=1., clip_epsilon=0.2, use_n_step_is=True, use_priority=True,
-                 curiosity=None, curiosity_strength=1., replay_config=None, noise=None):
+                 curiosity=None, curiosity_strength=1., use_prediction=False, transition_kl=0.8, use_extra_data=True,
+                 replay_config=None, noise=None):
         self.obs_names, self.obs_shapes = list(obs_names), list(obs_shapes)
         self.d_action_sizes, self.c_action_size = list(d_action_sizes), c_action_size
         self.d_sum, self.d_branches = sum(d_action_sizes), len(d_action_sizes)
@@ -165,6 +168,7 @@ class SacRef:
         self.use_n_step_is, self.use_priority = use_n_step_is, use_priority
         self.curiosity = curiosity if curiosity is None or isinstance(curiosity, str) else curiosity.name
         self.curiosity_strength = curiosity_strength
+        self.use_prediction, self.transition_kl = use_prediction, transition_kl
         self.noise = noise or TorchNoise()
         self.global_step = 0
 
@@ -222,6 +226,12 @@ class SacRef:
             self.model_inverse_dynamic = nn_module.ModelInverseDynamic(self.state_size, self.d_sum + c_action_size)
             self.optimizer_curiosity = adam(list(self.model_inverse_dynamic.parameters()))
 
+        if use_prediction:  # sac_base.py:421-441
+            self.model_transition = nn_module.ModelTransition(self.state_size, self.d_sum, c_action_size, use_extra_data)
+            self.model_reward = nn_module.ModelReward(self.state_size)
+            self.model_observation = nn_module.ModelObservation(self.state_size, obs_shapes, use_extra_data)
+            self.optimizer_prediction = adam(self.prediction_parameters())
+
         self.replay_buffer = PrioritizedReplayRef(batch_size=batch_size, sample_prev_n=burn_in_step,
                                                   sample_post_n=n_step, **(replay_config or {}))
         self.update_target(1.)  # sac_base.py:629
@@ -237,7 +247,13 @@ class SacRef:
             d['model_forward_dynamic'] = self.model_forward_dynamic
         elif self.curiosity == 'INVERSE':
             d['model_inverse_dynamic'] = self.model_inverse_dynamic
+        if self.use_prediction:
+            d.update(model_transition=self.model_transition, model_reward=self.model_reward,
+                     model_observation=self.model_observation)
         return d
+
+    def prediction_parameters(self) -> list:
+        return [*self.model_transition.parameters(), *self.model_reward.parameters(), *self.model_observation.parameters()]
 
     def named_optimizers(self) -> dict:
         """named like the reference's ckpt_dict (sac_base.py:493-566)"""
@@ -248,6 +264,8 @@ class SacRef:
             d['optimizer_alpha'] = self.optimizer_alpha
         if self.curiosity is not None:
             d['optimizer_curiosity'] = self.optimizer_curiosity
+        if self.use_prediction:
+            d['optimizer_prediction'] = self.optimizer_prediction
         return {k: v for k, v in d.items() if v is not None}
 
     # -- sac_base.py:745-764 ---------------------------------------------------------------------
@@ -348,7 +366,7 @@ class SacRef:
 
     # -- sac_base.py:1468-1605 -------------------------------------------------------------------
     def train_rep_q(self, n_last, n_pad, nx_obs, nx_states, n_actions, n_rewards, n_dones,
-                    n_mu_probs, priority_is):
+                    n_mu_probs, priority_is, nx_target_states=None):
         obs0 = [o[:, 0] for o in nx_obs]
         state, action = nx_states[:, 0], n_actions[:, 0]
         d_action, c_action = action[..., :self.d_sum], action[..., self.d_sum:]
@@ -376,12 +394,59 @@ class SacRef:
             self.optimizer_rep.zero_grad()
         for o in self.optimizer_q_list:
             o.zero_grad()
-        torch.stack(losses).sum().backward()
+        # `use_prediction`: the reference's `_train_rpm` differentiates the representation's graph a second time,
+        # which its own `loss.backward()` (1570) has freed — it raises.  The product keeps that graph alive so the head
+        # runs; the oracle restates THAT choice here, everything else is 1570-1603 in order.
+        torch.stack(losses).sum().backward(retain_graph=self.use_prediction)
+        grads_rep_main = [p.grad.detach() for p in self.model_rep.parameters()]
         for o in self.optimizer_q_list:
             o.step()
+        self.last_rpm = None
+        if self.use_prediction:
+            self.last_rpm = self.train_rpm(grads_rep_main, nx_obs, nx_states, nx_target_states, n_actions, n_rewards)
         if self.optimizer_rep:
             self.optimizer_rep.step()
         return losses[0].detach()
+
+    # -- sac_base.py:1607-1631 -------------------------------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def adaptive_weights(grads_main, loss_list, params):
+        """`calculate_adaptive_weights`: every auxiliary loss's gradient w.r.t. `params` is ADDED to their `.grad`
+        iff its cosine with the main gradient (all tensors flattened into one row) is positive — gate =
+        clamp(sign(cos), min=0), so cos == 0 (and NaN-free zero gradients) gate to 0.  -> the gates"""
+        params = list(params)
+        with torch.enable_grad():
+            aux_list = [torch.autograd.grad(loss, params, allow_unused=True, retain_graph=True) for loss in loss_list]
+        aux_list = [[a if a is not None else torch.zeros_like(m) for m, a in zip(grads_main, aux)] for aux in aux_list]
+        flat_main = torch.cat([g.reshape(1, -1) for g in grads_main], dim=1)
+        gates = [torch.sign(nn.functional.cosine_similarity(flat_main, torch.cat([a.reshape(1, -1) for a in aux], dim=1))).clamp(min=0)
+                 for aux in aux_list]
+        for aux, gate in zip(aux_list, gates):
+            for p, a in zip(params, aux):
+                p.grad += gate * a
+        return gates
+
+    # -- sac_base.py:1798-1839 -------------------------------------------------------------------
+    def train_rpm(self, grads_rep_main, nx_obs, nx_states, nx_target_states, n_actions, n_rewards):
+        """transition model: -mean log N(s'_target | s, a) + transition_kl * mean KL(N || N(0, 1)); reward model: MSE / n;
+        observation model: its own `get_loss` / n.  The three losses gate into the REPRESENTATION's gradient
+        (`adaptive_weights`); their sum trains the three models (one Adam).  -> dict of observables"""
+        n_obs = [o[:, :-1] for o in nx_obs]
+        dist = self.model_transition(n_obs, nx_states[:, :-1], n_actions)
+        loss_transition = -torch.mean(dist.log_prob(nx_target_states[:, 1:]))
+        std_normal = torch.distributions.Normal(torch.zeros_like(dist.loc), torch.ones_like(dist.scale), validate_args=False)
+        loss_transition = loss_transition + self.transition_kl * torch.mean(torch.distributions.kl.kl_divergence(dist, std_normal))
+        loss_reward = nn.functional.mse_loss(self.model_reward(nx_states[:, 1:]), torch.unsqueeze(n_rewards, 2)) / self.n
+        loss_obs = self.model_observation.get_loss(nx_states, list(nx_obs)) / self.n
+        gates = None
+        if grads_rep_main:      # (a parameter-free representation: the reference raises in autograd.grad; nothing to gate)
+            gates = self.adaptive_weights(grads_rep_main, [loss_transition, loss_reward, loss_obs], self.model_rep.parameters())
+        self.optimizer_prediction.zero_grad()
+        (loss_transition + loss_reward + loss_obs).backward(inputs=self.prediction_parameters())
+        self.optimizer_prediction.step()
+        return dict(losses=torch.stack([loss_transition, loss_reward, loss_obs]).detach(),
+                    gates=None if gates is None else torch.cat(gates), entropy=torch.mean(dist.entropy()).detach())
 
     # -- sac_base.py:1841-1911 -------------------------------------------------------------------
     def train_policy(self, obs_list, state, action, mu_d_policy_probs):
@@ -520,7 +585,7 @@ class SacRef:
         w = priority_is if self.use_priority else None
         loss_q = self.train_rep_q(bn_last[:, b:], bn_pad[:, b:], [o[:, b:] for o in bnx_obs],
                                   bnx_states[:, b:], bn_act[:, b:], bn_rew[:, b:], bn_done[:, b:],
-                                  bn_mu[:, b:], w)
+                                  bn_mu[:, b:], w, nx_target_states=bnx_target_states[:, b:])
         with torch.no_grad():
             bnx_states, next_hidden = self.l_states(*rep_in)
         obs_b = [o[:, b] for o in bnx_obs]
@@ -534,7 +599,7 @@ class SacRef:
 
         # write-backs, sac_base.py:2558-2605
         out = dict(ids=ids, is_weights=is_w, loss_q=loss_q, d_entropy=d_ent, c_entropy=c_ent,
-                   loss_policy=self.last_loss_policy, loss_curiosity=loss_cur, padding_mask=batch['padding_mask'].numpy().copy(),
+                   loss_policy=self.last_loss_policy, loss_curiosity=loss_cur, rpm=self.last_rpm, padding_mask=batch['padding_mask'].numpy().copy(),
                    index=batch['index'].numpy().copy())
         bn_states = bnx_states[:, :-1]
         pi_probs = None

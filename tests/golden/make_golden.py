@@ -14,6 +14,9 @@ Fixtures:
   f4_get_y.npz     SAC_Base._get_y with table-driven policy / target-Q stubs (ensemble min + V)
   f5_polyak.npz    SAC_Base._update_target_variables
   f6_step_<case>.npz  full train() steps: weights before/after, episodes, draws, observables
+  f11_rpm.npz      SAC_Base._train_rpm + calculate_adaptive_weights on a fresh graph (use_prediction)
+
+    python tests/golden/make_golden.py [fixture function names...]      (default: all)
 """
 import importlib.util
 import random
@@ -745,8 +748,89 @@ def f10_agent():
     np.savez_compressed(HERE / 'f10_agent.npz', **out)
 
 
+def f11_rpm():
+    """`_train_rpm` (sac_base.py:1798-1839) with `calculate_adaptive_weights` (1607-1631) driven DIRECTLY on freshly
+    computed states.  The reference's whole step cannot be recorded with `use_prediction`: `_train_rep_q` has freed
+    the representation's graph when `_train_rpm` differentiates it again ("backward through the graph a second
+    time"; with the parameter-free `ModelSimpleRep`, "grad requires non-empty inputs").  Called on its own graph —
+    the way f4 drives `_get_y` — the function runs.  Two variants per learner: main gradient g and -g, so every
+    auxiliary loss is seen once with gate 1 and once with gate 0."""
+    from torch import autograd
+    from torch.nn import functional
+    nn_mod = load_ref_nn(AUX_PLUGIN)
+    out = {}
+    B, n = 16, 3
+    for tag, flip, kw in [('a', 1., {}), ('b', -1., {}), ('c', 1., dict(transition_kl=0.3, use_extra_data=False))]:
+        seed_all(11)
+        rng = np.random.default_rng(11)
+        sac = SAC_Base(obs_names=['vector'], obs_shapes=[(6,)], d_action_sizes=[], c_action_size=2, model_abs_dir=None,
+                       nn=nn_mod, device='cpu', batch_size=B, n_step=n, use_prediction=True,
+                       replay_config={'capacity': 256}, **kw)
+        heads = {k: getattr(sac, k) for k in ('model_rep', 'model_target_rep', 'model_transition', 'model_reward',
+                                               'model_observation')}
+        for name, m in heads.items():
+            for k, v in m.state_dict().items():
+                out[f'{tag}/w0/{name}/{k}'] = v.numpy().copy()
+        obs = rng.standard_normal((B, n + 1, 6)).astype(np.float32)
+        actions = rng.random((B, n, 2)).astype(np.float32)
+        rewards = rng.standard_normal((B, n)).astype(np.float32)
+        coef = rng.standard_normal((8,)).astype(np.float32)
+        nx_obses_list = [torch.from_numpy(obs.copy())]
+        nx_states, _ = sac.model_rep(nx_obses_list, None, None)
+        with torch.no_grad():
+            nx_target_states, _ = sac.model_target_rep(nx_obses_list, None, None)
+        # the "main" loss whose gradient the gates compare against (the Q loss in a real step)
+        main = flip * torch.mean(torch.square(torch.sum(nx_states * torch.from_numpy(coef), dim=-1)))
+        sac.optimizer_rep.zero_grad()
+        main.backward(retain_graph=True)
+        grads_rep_main = [p.grad.detach() for p in sac.model_rep.parameters()]      # (aliases .grad, as in 1577)
+        for j, g_ in enumerate(grads_rep_main):
+            out[f'{tag}/g_main/{j}'] = g_.numpy().copy()
+        seen = {}
+        orig = sac.calculate_adaptive_weights
+
+        def spy(grads_main, loss_list, model):
+            seen['losses'] = np.array([float(l_) for l_ in loss_list], dtype=np.float32)
+            flat_main = torch.cat([g_.reshape(1, -1) for g_ in grads_main], dim=1)
+            cos = []
+            for l_ in loss_list:
+                ga = autograd.grad(l_, list(model.parameters()), allow_unused=True, retain_graph=True)
+                ga = [a if a is not None else torch.zeros_like(m_) for m_, a in zip(grads_main, ga)]
+                cos.append(float(functional.cosine_similarity(flat_main, torch.cat([a.reshape(1, -1) for a in ga], dim=1))))
+            seen['cos'] = np.array(cos, dtype=np.float32)
+            return orig(grads_main, loss_list, model)
+
+        sac.calculate_adaptive_weights = spy
+        ret = sac._train_rpm(grads_rep_main, nx_obses_list, nx_states, nx_target_states, torch.from_numpy(actions.copy()),
+                             torch.from_numpy(rewards.copy()))
+        out[f'{tag}/obs'], out[f'{tag}/actions'], out[f'{tag}/rewards'], out[f'{tag}/coef'] = obs, actions, rewards, coef
+        out[f'{tag}/flip'] = np.float32(flip)
+        out[f'{tag}/nx_states'] = nx_states.detach().numpy().copy()
+        out[f'{tag}/nx_target_states'] = nx_target_states.numpy().copy()
+        out[f'{tag}/losses'] = seen['losses']            # transition (incl. KL), reward / n_step, observation / n_step
+        out[f'{tag}/cos'] = seen['cos']
+        out[f'{tag}/gate'] = (np.sign(seen['cos']).clip(min=0)).astype(np.float32)
+        out[f'{tag}/ret'] = np.array([float(r_) for r_ in ret], dtype=np.float32)   # mean entropy, loss_reward, loss_obs
+        for j, p_ in enumerate(sac.model_rep.parameters()):
+            out[f'{tag}/g_rep_after/{j}'] = p_.grad.numpy().copy()
+        pred = list(sac.model_transition.parameters()) + list(sac.model_reward.parameters()) + list(sac.model_observation.parameters())
+        for j, p_ in enumerate(pred):
+            out[f'{tag}/g_pred/{j}'] = p_.grad.numpy().copy()
+        for name in ('model_transition', 'model_reward', 'model_observation'):
+            for k, v in heads[name].state_dict().items():
+                out[f'{tag}/w1/{name}/{k}'] = v.numpy().copy()
+        out[f'{tag}/cfg'] = np.array([B, n, kw.get('transition_kl', 0.8), float(kw.get('use_extra_data', True))])
+        sac.close()
+    assert set(out['a/gate'].tolist()) | set(out['b/gate'].tolist()) == {0., 1.}
+    np.savez_compressed(HERE / 'f11_rpm.npz', **out)
+
+
 def main():
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name]()
+        return
     f1_sumtree()
     f2_per()
     f3_vtrace()
@@ -772,6 +856,7 @@ def main():
     f8_interop()
     f9_acting()
     f10_agent()
+    f11_rpm()
     print('golden fixtures written to', HERE)
 
 

@@ -26,7 +26,7 @@ def _agent(plugin, obs_shapes, tmp_path=None, seq_encoder=None, **kw):
 def test_acting_through_fused_encoder_layers_matches_module_path(monkeypatch):
     from asac_amd import native
     from algorithm import fused_conv, fused_mlp
-    from algorithm.nn_models.layers import attention
+    from algorithm.nn_models.layers import seq_layers as attention
     from tests.plugins import nn_conv, nn_conv_attn
     rng = np.random.default_rng(0)
     n_env = 7

@@ -59,7 +59,7 @@ def test_baseline_config_full_size_vs_oracle(name):
     B, n, A, E = cfg['batch_size'], cfg['n_step'], cfg['c_action_size'], cfg['ensemble_q_num']
     common = dict(n_step=n, burn_in_step=cfg['burn_in_step'], batch_size=B, ensemble_q_num=E,
                   ensemble_q_sample=cfg['ensemble_q_sample'], use_priority=cfg.get('use_priority', True),
-                  replay_config={'capacity': cfg['capacity']})
+                  use_prediction=cfg.get('use_prediction', False), replay_config={'capacity': cfg['capacity']})
     torch.manual_seed(0)
     agent = SAC_Base(cfg['obs_names'], cfg['obs_shapes'], [], A, None, plugin, device='cuda:0',
                      seq_encoder=SEQ_ENCODER[cfg['seq_encoder']] if cfg['seq_encoder'] else None,
@@ -68,9 +68,10 @@ def test_baseline_config_full_size_vs_oracle(name):
     oracle = sac_ref.SacRef(cfg['obs_names'], cfg['obs_shapes'], [], A, plugin, seq_encoder=cfg['seq_encoder'],
                             curiosity=cfg.get('curiosity'), **common)
     pu.copy_weights_to_oracle(agent, oracle)
-    if cfg.get('curiosity'):
-        oracle.model_forward_dynamic.load_state_dict(
-            {k: v.detach().cpu().clone() for k, v in agent.model_forward_dynamic.state_dict().items()})
+    extra = (['model_forward_dynamic'] if cfg.get('curiosity') else []) + \
+        (['model_transition', 'model_reward', 'model_observation'] if cfg.get('use_prediction') else [])
+    for mname in extra:
+        getattr(oracle, mname).load_state_dict({k: v.detach().cpu().clone() for k, v in getattr(agent, mname).state_dict().items()})
 
     rng = np.random.default_rng(7)
     T = cfg['episode_len']
@@ -116,6 +117,13 @@ def test_baseline_config_full_size_vs_oracle(name):
         chk('loss_q', agent._stats['loss_q'].item(), float(out['loss_q']))
         if cfg.get('curiosity'):
             chk('loss_curiosity', agent._stats['loss_curiosity'].item(), float(out['loss_curiosity']))
+        if cfg.get('use_prediction'):
+            # the prediction models after their Adam step (sign-like updates: entries move by lr per step, so the weights
+            # themselves are compared) and, through the next steps' losses / td-errors, the gated representation update
+            for mname in ('model_transition', 'model_reward', 'model_observation'):
+                for (k, v), vo in zip(getattr(agent, mname).state_dict().items(), getattr(oracle, mname).state_dict().values()):
+                    pu.check(f'full_size/{name}/prediction_weights', v, vo, rtol=0., atol=2.2 * 3e-4 * (step + 1))
+            assert out['rpm'] is not None and np.isfinite(out['rpm']['losses'].numpy()).all()
         if cfg.get('use_priority', True):
             chk('td_error', agent._td_error.cpu().numpy(), out['td_error'].reshape(-1))
         else:       # the tree is frozen: sampled, never updated (reference sac_base.py:2571-2584)

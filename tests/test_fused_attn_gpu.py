@@ -33,7 +33,7 @@ def test_attention_core_matches_module_path(B, Lq, Lk, E, kind, monkeypatch):
     import asac_amd  # noqa: F401
     from asac_amd import native
     import algorithm.nn_models as m
-    from algorithm.nn_models.layers import attention
+    from algorithm.nn_models.layers import seq_layers as attention
     monkeypatch.setattr(attention, 'FUSED_PROJECTIONS', False)      # the core alone (projections by the modules)
     torch.manual_seed(0)
     ref = m.MultiheadAttention(E, 1, out_dense_depth=1)

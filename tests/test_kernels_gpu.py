@@ -666,3 +666,21 @@ def test_window_aux_matches_get_bnx_data_concatenations(nat):
     got_a = torch.empty(B, L, A, device='cuda')
     nat.window_aux(bn_i, bn_p, bn_a, got_i, got_p, got_a)
     assert torch.equal(got_i, want_i.to(torch.int32)) and torch.equal(got_p, want_p) and torch.equal(got_a, want_a)
+
+
+def test_gelu_against_torch(nat):
+    """The one function of the library that is an approximation by design: GELU of the fused MLP / convolution kernels
+    (Abramowitz-Stegun 7.1.26 erf, `__expf`, `v_rcp_f32`; csrc/asac_gelu.h) against `torch.nn.functional.gelu` and its
+    derivative, evaluated in float64, on [-12, 12] (2^20 points + the neighbourhood of 0).  The bound asserted here is
+    the one include/asac_hip.h states."""
+    from tests import parity_utils as pu
+    z = torch.cat([torch.linspace(-12, 12, 2 ** 20), torch.linspace(-1e-3, 1e-3, 4097), torch.randn(2 ** 16) * 3]).cuda()
+    value, deriv = torch.empty_like(z), torch.empty_like(z)
+    nat.gelu_eval(z, value, deriv)
+    zd = z.double().requires_grad_()
+    want = torch.nn.functional.gelu(zd)
+    want_d, = torch.autograd.grad(want.sum(), zd)
+    pu.check('kernels/gelu/value', value, want.detach(), rtol=3e-7, atol=6e-7)
+    pu.check('kernels/gelu/derivative', deriv, want_d, rtol=0., atol=6e-7)
+    # ... and ATen's own f32 evaluation for scale: how far IT is from the float64 value
+    pu.check('kernels/gelu/aten_f32_value_for_scale', torch.nn.functional.gelu(z), want.detach(), rtol=3e-7, atol=6e-7, enforce=False)

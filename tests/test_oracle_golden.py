@@ -149,3 +149,51 @@ def test_f6_full_step(golden_dir, case):
         for k, v in mod.state_dict().items():
             assert f'w1/{name}/{k}' in g.files
             np.testing.assert_allclose(v.numpy(), g[f'w1/{name}/{k}'], err_msg=f'{name}/{k}', **wtol)
+
+
+# ------------------------------------------------------------------------------------------------
+# recurrent prediction models: `_train_rpm` + `calculate_adaptive_weights` (f11_rpm.npz: the reference's functions
+# called on a fresh graph — its whole step raises with `use_prediction`)
+# ------------------------------------------------------------------------------------------------
+def rpm_oracle(g, tag):
+    """oracle learner with the fixture's weights; -> (oracle, inputs for train_rpm)"""
+    B, n, kl, extra = g[f'{tag}/cfg']
+    oracle = sac_ref.SacRef(['vector'], [(6,)], [], 2, pu.plugin('nn_vec_full'), batch_size=int(B), n_step=int(n),
+                            use_prediction=True, transition_kl=float(kl), use_extra_data=bool(extra),
+                            replay_config={'capacity': 256})
+    for name, mod in oracle.named_modules().items():
+        sd = {k: torch.from_numpy(g[f'{tag}/w0/{name}/{k}'].copy()) for k in mod.state_dict() if f'{tag}/w0/{name}/{k}' in g.files}
+        if sd:
+            mod.load_state_dict(sd)
+    return oracle
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_f11_rpm_bit_exact(golden_dir, tag):
+    g = np.load(golden_dir / 'f11_rpm.npz')
+    torch.set_num_threads(1)
+    oracle = rpm_oracle(g, tag)
+    obs = [torch.from_numpy(g[f'{tag}/obs'].copy())]
+    nx_states, _ = oracle.model_rep(obs, None, None)
+    with torch.no_grad():
+        nx_target_states, _ = oracle.model_target_rep(obs, None, None)
+    assert np.array_equal(nx_states.detach().numpy(), g[f'{tag}/nx_states'])
+    main = float(g[f'{tag}/flip']) * torch.mean(torch.square(torch.sum(nx_states * torch.from_numpy(g[f'{tag}/coef']), dim=-1)))
+    oracle.optimizer_rep.zero_grad()
+    main.backward(retain_graph=True)
+    grads_main = [p.grad.detach() for p in oracle.model_rep.parameters()]
+    for j, gm in enumerate(grads_main):
+        assert np.array_equal(gm.numpy(), g[f'{tag}/g_main/{j}'])
+    out = oracle.train_rpm(grads_main, obs, nx_states, nx_target_states, torch.from_numpy(g[f'{tag}/actions'].copy()),
+                           torch.from_numpy(g[f'{tag}/rewards'].copy()))
+    assert np.array_equal(out['losses'].numpy(), g[f'{tag}/losses'])
+    assert np.array_equal(out['gates'].numpy(), g[f'{tag}/gate'])
+    assert np.array_equal(np.array([float(out['entropy']), float(out['losses'][1]), float(out['losses'][2])], dtype=np.float32),
+                          g[f'{tag}/ret'])
+    for j, p in enumerate(oracle.model_rep.parameters()):
+        assert np.array_equal(p.grad.numpy(), g[f'{tag}/g_rep_after/{j}']), f'representation gradient {j} after gating'
+    for j, p in enumerate(oracle.prediction_parameters()):
+        assert np.array_equal(p.grad.numpy(), g[f'{tag}/g_pred/{j}']), f'prediction gradient {j}'
+    for name in ('model_transition', 'model_reward', 'model_observation'):
+        for k, v in getattr(oracle, name).state_dict().items():
+            assert np.array_equal(v.numpy(), g[f'{tag}/w1/{name}/{k}']), f'{name}/{k} after Adam'
