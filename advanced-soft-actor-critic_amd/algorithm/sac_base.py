@@ -65,6 +65,21 @@ def _masked_mse_backward(pred, target, padding_mask, loss_out):
         pred.backward(d)
 
 
+class _Window:
+    """views of the step's static batch tensors and what the phases of `_device_step_body` hand to each other"""
+
+
+class _AfterPolicy:
+    """what the stock networks' pass of the UPDATED policy over the window leaves for the temperature step, the TD
+    error and the write-backs (all None: the generic path computes each where it is needed)"""
+    ls_win = alpha_logp = probs_win = td_sample = None      # (loc | scale) [B, L, 2A]; log pi of the temperature sample;
+    #                                                           pi(stored actions) [B, L, A]; the TD target's (action, log pi)
+    sc_write = sc_alpha = None                               # sidecar jobs still waiting for a host launch
+    side_cq = td_q_table = ls_td = td_pi = None              # online Q(s_b, a_b); target Q on the TD sample; the TD
+    #                                                           target's own policy pass (over target states) and its pi
+    mu_written = False                                       # the mu-probability write-back is issued / riding
+
+
 class SAC_Base(AuxHeadsMixin):
     _closed = False
 
@@ -204,10 +219,6 @@ class SAC_Base(AuxHeadsMixin):
         self._dist = hip_config.get('dist')     # parallel.DataParallelContext or None
         self._use_fused_mlp = bool(hip_config.get('fused_mlp', True))
         self._graph_collectives = bool(hip_config.get('graph_collectives', True))
-        # independent launches on a second stream (parallel hipGraph branches).  Measured on MI355X /
-        # ROCm 7.0: every cross-branch edge costs more than the ~5 us launch it hides (cfg2: 5.2k -> 4.8k
-        # steps/s), so the step stays one serial chain by default.
-        self._parallel_branches = bool(hip_config.get('parallel_branches', False))
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
@@ -223,6 +234,7 @@ class SAC_Base(AuxHeadsMixin):
         self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
+        self._dist_ready = False        # (collective decision, `_ready_to_train`)
         assert self._dist_sampling in ('throughput', 'parity')
 
         self._set_logger()
@@ -440,8 +452,6 @@ class SAC_Base(AuxHeadsMixin):
         self._grad_q = torch.zeros(E, B, **f32)            # d loss / d q written by the loss kernels
         self._grad_logp = torch.zeros(B, **f32)
         self._ls_y = None
-        self._side = torch.cuda.Stream(device=dev) if self._parallel_branches else None
-        self._side_pending = False
         self._cq_buf, self._tq_buf, self._cq_td_buf = (torch.zeros(E, B, 1, **f32) for _ in range(3))
         self._pi_q, self._pi_stats_src = torch.zeros(E, B, 1, **f32), None
         self._pi_a, self._pi_logp, self._pi_sampled = torch.zeros(B, A1, **f32), torch.zeros(B, **f32), False
@@ -539,9 +549,9 @@ class SAC_Base(AuxHeadsMixin):
             # (global batch = world_size * batch_size, this rank trains on batch_size rows of it)
             from .parallel import ProductShard, ShardedParityReplay
             rb = self.replay_buffer
-            rb.sharded = ShardedParityReplay(self._dist, ProductShard(rb), self.batch_size * self._dist.world_size,
-                                             self.device, beta=rb._init_beta,
-                                             beta_increment=rb.beta_increment_per_sampling)
+            global_batch = self.batch_size * self._dist.world_size
+            rb.sharded = ShardedParityReplay(self._dist, ProductShard(rb, global_batch), global_batch, self.device)
+            rb._u = torch.zeros(global_batch, dtype=torch.float64, device=self.device)    # the GLOBAL batch's uniforms
         elif self._dist is not None:
             self.replay_buffer.min_ratio_reducer = self._dist.all_reduce_min_
 
@@ -1022,7 +1032,6 @@ class SAC_Base(AuxHeadsMixin):
                     n_mu_probs.data_ptr(), n_mu_probs.stride(0), n_mu_probs.stride(1)
                 args.mu_offset, args.A = dsum, self.c_action_size
             if q_online is not None and not self.d_action_sizes:
-                self._join()     # q_online may come from the side stream
                 args.q_online, args.E_online, args.td_error_out = q_online.data_ptr(), q_online.shape[0], td_out.data_ptr()
             sidecars = None
             if q_online is not None and self._vtrace_sidecars:     # the TD error's launch hosts the pending write-backs
@@ -1043,22 +1052,6 @@ class SAC_Base(AuxHeadsMixin):
     # ==========================================================================================
     # losses / updates (reference _train_rep_q 1468-1605, _train_policy 1841-1911, _train_alpha 1913-1949)
     # ==========================================================================================
-    # -- a second stream for launches that do not depend on each other: captured as parallel branches
-    #    of the step's hipGraph (and really concurrent in eager mode); results land in static buffers
-    def _fork(self):
-        """`with self._fork(): ...` issues the block on the side stream, ordered after everything
-        already on the current stream."""
-        if not self._parallel_branches:
-            return contextlib.nullcontext()
-        self._side.wait_stream(torch.cuda.current_stream())
-        self._side_pending = True
-        return torch.cuda.stream(self._side)
-
-    def _join(self) -> None:
-        if self._side_pending:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side_pending = False
-
     @torch.no_grad()
     def _train_rep_q_stock(self, n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
                            n_dones, n_mu_probs, priority_is, policy_sample):
@@ -1595,9 +1588,32 @@ class SAC_Base(AuxHeadsMixin):
     def _device_step_body(self) -> None:
         """Everything one `train()` does on the device, without a single host synchronisation
         (reference `_sample_from_replay_buffer` 2398-2494, `_train` 2027-2126, write-backs 2558-2605).
-        Reads / writes only static buffers, so it can be captured and replayed as a hipGraph."""
-        rb, b, n = self.replay_buffer, self.burn_in_step, self.n_step
+        Reads / writes only static buffers, so it can be captured and replayed as a hipGraph.  Phases:
+          _step_sample            prologue (Polyak, draws) + PER sample + window gather -> views of the static batch
+          _step_rep_and_q         representation passes (online, target), Q step, states under the updated representation
+          _step_policy            policy step
+          _step_after_policy_*    stock networks: the UPDATED policy over the window -> new behaviour probabilities, the
+                                  TD target's sample, the temperature step's sample (one launch, or the chain it replaces)
+          _step_temperature_and_aux  temperature step (unless a sidecar took it), curiosity / RND
+          _step_write_backs       TD error -> priorities, mu-probability and hidden-state rows"""
         self._counter_advanced = False
+        w = self._step_sample()
+        self._step_rep_and_q(w)
+        self._step_policy(w)
+        post = _AfterPolicy()
+        self._vtrace_sidecars = self._pending_alpha = None
+        if w.stock and self.use_n_step_is:
+            with torch.no_grad():
+                if not self._step_after_policy_one_launch(w, post):
+                    self._step_after_policy_chain(w, post)
+        self._step_temperature_and_aux(w, post)
+        self._step_write_backs(w, post)
+        if not self._counter_advanced:
+            self._opt_steps.add_(1)
+
+    def _step_sample(self):
+        """-> the step's window views (`_Window`): [B, L] tensors are `bnx_*`, their first L - 1 rows `bn_*`"""
+        rb, b = self.replay_buffer, self.burn_in_step
         # Polyak of every step rides in the step's first launch, together with every uniform / Gaussian draw and
         # ensemble subset of the step (recorded test noise: a plain Polyak launch, draws injected by the test)
         polyak = None
@@ -1610,227 +1626,235 @@ class SAC_Base(AuxHeadsMixin):
             self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
                                   self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
         rb.sample_into_static(sampled=sampled)
-        batch, ids = rb._batch, rb._ids
-        priority_is = rb._w.unsqueeze(-1) if self.use_priority else None
-
-        bnx_obses_list = [batch[f'obs_{name}'] for name in self.obs_names]
-        bnx_actions, bnx_pad = batch['action'], batch['padding_mask']
-        bn_indexes, bn_last, bn_pad = batch['index'][:, :-1], batch['last_mask'][:, :-1], bnx_pad[:, :-1]
-        bn_actions, bn_rewards, bn_dones = bnx_actions[:, :-1], batch['reward'][:, :-1], batch['done'][:, :-1]
-        bn_mu_probs = batch['mu_prob'][:, :-1]
-        bnx_hidden = batch['pre_seq_hidden_state']
-
+        batch = rb._batch
+        w = _Window()
+        w.ids = rb._ids
+        w.priority_is = rb._w.unsqueeze(-1) if self.use_priority else None
+        w.bnx_obses_list = [batch[f'obs_{name}'] for name in self.obs_names]
+        w.bnx_actions, w.bnx_pad = batch['action'], batch['padding_mask']
+        w.bn_indexes, w.bn_last, w.bn_pad = batch['index'][:, :-1], batch['last_mask'][:, :-1], w.bnx_pad[:, :-1]
+        w.bn_actions, w.bn_rewards, w.bn_dones = w.bnx_actions[:, :-1], batch['reward'][:, :-1], batch['done'][:, :-1]
+        w.bn_mu_probs = batch['mu_prob'][:, :-1]
+        w.bnx_hidden = batch['pre_seq_hidden_state']
+        w.nx_obs = [o[:, b:] for o in w.bnx_obses_list]
+        w.obs_b = [o[:, b] for o in w.bnx_obses_list]
+        w.stock = self._stock_c_only()
+        w.rep_trainable = self.optimizer_rep is not None
         self.noise.prefill(self._eps_all)          # (torch fallback: one launch for all Gaussian draws)
         if type(self.model_rep) is ModelSimpleRep:
             # the stock concatenation rep ignores index / mask / previous actions: do not build them
-            rep_in = (None, None, bnx_obses_list, None, bnx_hidden)
+            w.rep_in = (None, None, w.bnx_obses_list, None, w.bnx_hidden)
         else:
-            bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(bn_indexes, bn_pad, bn_actions)
-            rep_in = (bnx_indexes, bnx_padding_masks, bnx_obses_list, bnx_pre_actions, bnx_hidden)
-        rep_trainable = self.optimizer_rep is not None
+            bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(w.bn_indexes, w.bn_pad, w.bn_actions)
+            w.rep_in = (bnx_indexes, bnx_padding_masks, w.bnx_obses_list, bnx_pre_actions, w.bnx_hidden)
+        return w
 
+    def _step_rep_and_q(self, w) -> None:
+        """reference `_train` 2066-2103: online and target representation over the window, `_train_rep_q`, the states
+        again under the updated representation -> w.bnx_states, w.bnx_target_states, w.next_hidden"""
+        b = self.burn_in_step
         with self._rep_twin if self._rep_twin else contextlib.nullcontext():
-            bnx_states, next_hidden = self.get_l_states(*rep_in, is_target=False)
+            bnx_states, next_hidden = self.get_l_states(*w.rep_in, is_target=False)
             with torch.no_grad():
-                bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
-
-        nx_obs = [o[:, b:] for o in bnx_obses_list]
+                w.bnx_target_states, _ = self.get_l_states(*w.rep_in, is_target=True)
         aux = None
         if self.siamese is not None or self.use_prediction:
-            aux = dict(n_indexes=bn_indexes[:, b:], n_pre_actions=bn_actions[:, b - 1:-1] if b > 0 else bn_actions[:, 0:0],
-                       n_pre_seq_hidden_states=bnx_hidden[:, b:-1], nx_target_states=bnx_target_states[:, b:])
-        self._train_rep_q(bn_last[:, b:], bn_pad[:, b:], nx_obs, bnx_states[:, b:], bnx_actions[:, b:],
-                          bn_rewards[:, b:], bn_dones[:, b:], bn_mu_probs[:, b:], priority_is, aux,
-                          policy_sample=self._stock_c_only() and not rep_trainable,
+            aux = dict(n_indexes=w.bn_indexes[:, b:],
+                       n_pre_actions=w.bn_actions[:, b - 1:-1] if b > 0 else w.bn_actions[:, 0:0],
+                       n_pre_seq_hidden_states=w.bnx_hidden[:, b:-1], nx_target_states=w.bnx_target_states[:, b:])
+        self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bnx_states[:, b:], w.bnx_actions[:, b:],
+                          w.bn_rewards[:, b:], w.bn_dones[:, b:], w.bn_mu_probs[:, b:], w.priority_is, aux,
+                          policy_sample=w.stock and not w.rep_trainable,
                           state_base=(bnx_states, b))
         if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
             self.after_rep_q_update()
-
-        if rep_trainable:   # states under the updated representation (reference 2097-2103)
+        if w.rep_trainable:   # states under the updated representation (reference 2097-2103)
             with torch.no_grad():
-                bnx_states, next_hidden = self.get_l_states(*rep_in, is_target=False)
+                w.bnx_states, w.next_hidden = self.get_l_states(*w.rep_in, is_target=False)
         else:
-            bnx_states, next_hidden = bnx_states.detach(), next_hidden.detach()
+            w.bnx_states, w.next_hidden = bnx_states.detach(), next_hidden.detach()
 
-        obs_b = [o[:, b] for o in bnx_obses_list]
-        state_b = bnx_states[:, b]
-        stock = self._stock_c_only()
+    def _step_policy(self, w) -> None:
+        b = self.burn_in_step
+        w.state_b = w.bnx_states[:, b]
         # the target computation already ran the (still unchanged) policy on this state: reuse its output
-        ls_b = self._ls_y[:, 0] if (stock and not rep_trainable and self._ls_y is not None) else None
-        self._train_policy(obs_b, state_b, bn_actions[:, b], bn_mu_probs[:, b, :self.d_action_summed_size], ls=ls_b)
+        ls_b = self._ls_y[:, 0] if (w.stock and not w.rep_trainable and self._ls_y is not None) else None
+        self._train_policy(w.obs_b, w.state_b, w.bn_actions[:, b], w.bn_mu_probs[:, b, :self.d_action_summed_size], ls=ls_b)
 
-        # one forward of the UPDATED stock policy over the whole window serves the temperature step
-        # (row b), the new mu-probabilities (rows < L-1) and, where the target representation is the
-        # online one (parameter-free rep), the TD-error target (rows >= b)
-        ls_win = alpha_logp = probs_win = td_sample = None
-        auto_alpha = self.use_auto_alpha and ((self.d_action_sizes and not self.discrete_dqn_like) or self.c_action_size)
-        # Launches off the step's critical path ride as sidecar workgroups of launches that are on it (csrc/
-        # asac_sidecar.h): the mu-probability write-back elects in the sampling launch and writes in the TD error's
-        # forward launch, which also carries the temperature step
-        sc_elect = sc_write = sc_alpha = None
-        side_cq = td_q_table = ls_td = td_pi = td_rows = None
-        fused_b = False
-        self._vtrace_sidecars = self._pending_alpha = None
-        if stock and self.use_n_step_is:
-            with torch.no_grad():
-                B_, L_, A = *bnx_states.shape[:2], self.c_action_size
-                f32 = dict(dtype=torch.float32, device=self.device)
-                same_states = (b == 0 and bnx_target_states.data_ptr() == bnx_states.data_ptr()
-                               and bnx_target_states.stride() == bnx_states.stride())
-                rows_win = StockMLP._rows(bnx_states, self.state_size)
-                job_b = None
-                if (self._fused_td_chain and self.use_priority and same_states and self._use_sidecars
-                        and not self._parallel_branches and rb.sharded is None
-                        and self.curiosity is None and not self.use_rnd):
-                    # the UPDATED policy over the window -> [pi(stored actions) = the new mu, the TD target's sample,
-                    # the temperature step's sample at row b] -> target critics on the TD sample, with the TD error's
-                    # online Q of (s_b, a_b) riding along and the mu-probability write-back electing beside it: ONE launch
-                    # (bit-identical to the three it replaces).  The write-back's second pass rides in the TD error's
-                    # return launch; the temperature step (it needs every tile's sample) rides in the priority update,
-                    # the step's last launch, and the TD error's return, which must already see the new temperature,
-                    # evaluates the value that step will write (`pending_alpha`)
-                    job_pi, ls_out = self._fpi.job(rows_win, None)
-                    probs_win = torch.empty((B_, L_, A), **f32)
-                    td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
-                    job_tq, td_q_table = self._ftq.job(rows_win, td_sample[0].view(-1, A))
-                    if auto_alpha:
-                        alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
-                    job_b = native.pi_q_job(job_pi, job_tq, self._eps_td, td_sample[0], td_sample[1], L_,
-                                            action=bnx_actions, prob_out=probs_win,
-                                            eps2=self._eps_alpha if auto_alpha else None, t2=b,
-                                            a2_out=scratch if auto_alpha else None,
-                                            logp2_out=alpha_logp if auto_alpha else None)
-                    if not native.policy_sample_q_forward_ok(job_b):
-                        job_b = probs_win = td_sample = td_q_table = alpha_logp = None
-                if job_b is not None:
-                    if auto_alpha:
-                        self.noise.normal_(self._eps_alpha)
-                    self.noise.normal_(self._eps_td)
-                    xb = StockMLP._rows(bnx_states[:, b], self.state_size)
-                    ab = StockMLP._rows(bnx_actions[:, b], self.c_action_size)
-                    job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                    sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
-                    if auto_alpha:
-                        sc_alpha = self._alpha_sidecar(alpha_logp)
-                    native.policy_sample_q_forward(job_b, [job_q], sidecars=[sc_elect])
-                    if sc_alpha is not None:
-                        self._alpha_logp_over_ranks(alpha_logp)
-                    self._pending_alpha = sc_alpha      # (None: a wider optimizer -> `_train_alpha` below)
-                    ls_win = ls_out[0].view(B_, L_, 2 * A)
-                    td_q_table = td_q_table.view(self.ensemble_q_num, B_, L_)
-                    side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
-                    self._vtrace_sidecars = [sc_write]
-                    fused_b = True
-                else:
-                    # the TD target's policy forward (over the TARGET states, where they are not the online ones) rides
-                    # beside the window's, its sample beside the window's elementwise jobs
-                    td_own = self.use_priority and not same_states
-                    if td_own:
-                        states_td = bnx_target_states[:, b:]
-                        td_rows = StockMLP._rows_in_place(states_td, self.state_size)
-                        job_win, ls_out = self._fpi.job(rows_win, None)
-                        job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
-                        native.mlp_forward_multi([job_win, job_pi_td])
-                        ls_win = ls_out[0].view(B_, L_, 2 * A)
-                        ls_td = ls_td_out[0].view(B_, n + 1, 2 * A)
-                    else:
-                        ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
-                    # ... and ONE elementwise launch on it: the temperature step's sample, pi(stored actions)
-                    # over the window, the TD target's sample
-                    probs_win = torch.empty((B_, L_, A), **f32)
-                    jobs = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=bnx_actions, prob_out=probs_win)]
-                    if auto_alpha:
-                        self.noise.normal_(self._eps_alpha)
-                        alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
-                        jobs.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, alpha_logp))
-                    if self.use_priority and same_states:
-                        self.noise.normal_(self._eps_td)
-                        td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
-                        jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *td_sample))
-                    elif td_own:
-                        self.noise.normal_(self._eps_td)
-                        td_sample = (torch.empty((B_, n + 1, A), **f32), torch.empty((B_, n + 1), **f32))
-                        td_pi = torch.empty((B_, n + 1, A), **f32)
-                        jobs.append(native.squash_job(ls_td[..., :A], ls_td[..., A:], self._eps_td, *td_sample,
-                                                      action=bnx_actions[:, b:], prob_out=td_pi))
-                    # (with priorities the TD error's online-Q launch follows and hosts the second pass + the temperature step)
-                    if self.use_priority and self._use_sidecars and not self._parallel_branches and rb.sharded is None:
-                        sc_elect, sc_write = rb.window_scatter_sidecars(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1])
-                        if auto_alpha:
-                            sc_alpha = self._alpha_sidecar(alpha_logp)
-                    native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
-                    if sc_alpha is not None:
-                        self._alpha_logp_over_ranks(alpha_logp)
-        # side stream from here to the end of the step: the TD error's online Q and the mu-probability
-        # write-back (its own election scratch) beside the temperature step / TD target / tree update
-        if probs_win is not None and not fused_b:
-            with torch.no_grad(), self._fork():
-                if self.use_priority:
-                    xb = StockMLP._rows(bnx_states[:, b], self.state_size)
-                    ab = StockMLP._rows(bnx_actions[:, b], self.c_action_size)
-                    if td_sample is not None:
-                        # the TD error's online Q of (s_b, a_b) and its target ensemble on the sampled
-                        # window actions: two networks, one launch
-                        job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                        job_tq, td_q_table = self._ftq.job(
-                            td_rows if td_rows is not None else StockMLP._rows(bnx_target_states, self.state_size),
-                            StockMLP._rows(td_sample[0], self.c_action_size))
-                        native.mlp_forward_multi([job_q, job_tq],
-                                                 sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None] or None)
-                        td_q_table = td_q_table.view(self.ensemble_q_num, *td_sample[1].shape)
-                    elif sc_write is not None or sc_alpha is not None:
-                        job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
-                        native.mlp_forward_multi([job_q], sidecars=[sc for sc in (sc_write, sc_alpha) if sc is not None])
-                    else:
-                        self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
-                    side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
-                if sc_write is None:
-                    rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', probs_win[:, :-1],
-                                                 side=self._parallel_branches)
-        if sc_alpha is not None:
-            auto_alpha = False      # done by the sidecar
+    def _auto_alpha(self) -> bool:
+        return bool(self.use_auto_alpha and ((self.d_action_sizes and not self.discrete_dqn_like) or self.c_action_size))
+
+    def _same_states(self, w) -> bool:
+        """the target representation's states ARE the online ones (parameter-free representation, no burn-in)"""
+        return (self.burn_in_step == 0 and w.bnx_target_states.data_ptr() == w.bnx_states.data_ptr()
+                and w.bnx_target_states.stride() == w.bnx_states.stride())
+
+    def _step_after_policy_one_launch(self, w, post) -> bool:
+        """One forward of the UPDATED stock policy over the whole window serves the new mu-probabilities (rows < L - 1),
+        the temperature step (row b) and, where the target representation is the online one, the TD-error target
+        (rows >= b): policy -> [pi(stored actions) = the new mu, the TD target's sample, the temperature step's sample] ->
+        target critics on the TD sample, with the TD error's online Q of (s_b, a_b) riding along and the mu-probability
+        write-back electing beside it — ONE launch (bit-identical to the chain `_step_after_policy_chain` issues).  The
+        write-back's second pass rides in the TD error's return launch; the temperature step (it needs every tile's
+        sample) rides in the priority update, the step's last launch, and the TD error's return, which must already see
+        the new temperature, evaluates the value that step will write (`pending_alpha`).  -> False: not applicable."""
+        rb, b, n = self.replay_buffer, self.burn_in_step, self.n_step
+        if not (self._fused_td_chain and self.use_priority and self._same_states(w) and self._use_sidecars
+                and rb.sharded is None and self.curiosity is None and not self.use_rnd):
+            return False
+        B_, L_, A = *w.bnx_states.shape[:2], self.c_action_size
+        f32 = dict(dtype=torch.float32, device=self.device)
+        auto_alpha = self._auto_alpha()
+        rows_win = StockMLP._rows(w.bnx_states, self.state_size)
+        job_pi, ls_out = self._fpi.job(rows_win, None)
+        probs_win = torch.empty((B_, L_, A), **f32)
+        td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
+        job_tq, td_q_table = self._ftq.job(rows_win, td_sample[0].view(-1, A))
+        alpha_logp = scratch = None
         if auto_alpha:
-            self._train_alpha(obs_b, state_b, ls=None if ls_win is None else ls_win[:, b], logp=alpha_logp)
-        if self.curiosity is not None:
-            self._train_curiosity(bn_pad[:, b:], bnx_states[:, b:], bn_actions[:, b:])
-        if self.use_rnd:
-            self._train_rnd(bn_pad[:, b:], bnx_states[:, b:-1], bn_actions[:, b:])
+            alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
+        job = native.pi_q_job(job_pi, job_tq, self._eps_td, td_sample[0], td_sample[1], L_,
+                              action=w.bnx_actions, prob_out=probs_win,
+                              eps2=self._eps_alpha if auto_alpha else None, t2=b,
+                              a2_out=scratch, logp2_out=alpha_logp)
+        if not native.policy_sample_q_forward_ok(job):
+            return False
+        if auto_alpha:
+            self.noise.normal_(self._eps_alpha)
+        self.noise.normal_(self._eps_td)
+        xb = StockMLP._rows(w.bnx_states[:, b], self.state_size)
+        ab = StockMLP._rows(w.bnx_actions[:, b], self.c_action_size)
+        job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
+        # launches off the step's critical path ride as sidecar workgroups of launches that are on it (csrc/asac_sidecar.h)
+        sc_elect, post.sc_write = rb.window_scatter_sidecars(w.ids, -b, b + n, w.bnx_pad, 'mu_prob', probs_win[:, :-1])
+        if auto_alpha:
+            post.sc_alpha = self._alpha_sidecar(alpha_logp)
+        native.policy_sample_q_forward(job, [job_q], sidecars=[sc_elect])
+        if post.sc_alpha is not None:
+            self._alpha_logp_over_ranks(alpha_logp)
+        self._pending_alpha = post.sc_alpha      # (None: a wider optimizer -> `_train_alpha`)
+        post.ls_win = ls_out[0].view(B_, L_, 2 * A)
+        post.probs_win, post.td_sample, post.alpha_logp = probs_win, td_sample, alpha_logp
+        post.td_q_table = td_q_table.view(self.ensemble_q_num, B_, L_)
+        post.side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
+        self._vtrace_sidecars = [post.sc_write]
+        post.mu_written = True
+        return True
 
-        # ---- write-backs --------------------------------------------------------------------------
-        bn_states = bnx_states[:, :-1]
+    def _step_after_policy_chain(self, w, post) -> None:
+        """The chain form: policy forward over the window (the TD target's policy forward over the TARGET states, where
+        they are not the online ones, beside it) -> ONE elementwise launch [temperature sample, pi(stored actions), TD
+        target's sample] -> the TD error's online Q of (s_b, a_b) with its target ensemble on the sampled window actions
+        (two networks, one launch; hosts the write-back's second pass and the temperature step as sidecars)."""
+        rb, b, n = self.replay_buffer, self.burn_in_step, self.n_step
+        B_, L_, A = *w.bnx_states.shape[:2], self.c_action_size
+        f32 = dict(dtype=torch.float32, device=self.device)
+        auto_alpha, same_states = self._auto_alpha(), self._same_states(w)
+        rows_win = StockMLP._rows(w.bnx_states, self.state_size)
+        td_own = self.use_priority and not same_states
+        td_rows = sc_elect = None
+        if td_own:
+            td_rows = StockMLP._rows_in_place(w.bnx_target_states[:, b:], self.state_size)
+            job_win, ls_out = self._fpi.job(rows_win, None)
+            job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
+            native.mlp_forward_multi([job_win, job_pi_td])
+            ls_win = ls_out[0].view(B_, L_, 2 * A)
+            post.ls_td = ls_td_out[0].view(B_, n + 1, 2 * A)
+        else:
+            ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
+        probs_win = torch.empty((B_, L_, A), **f32)
+        jobs = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=w.bnx_actions, prob_out=probs_win)]
+        if auto_alpha:
+            self.noise.normal_(self._eps_alpha)
+            post.alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
+            jobs.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, post.alpha_logp))
+        if self.use_priority and same_states:
+            self.noise.normal_(self._eps_td)
+            post.td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
+            jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *post.td_sample))
+        elif td_own:
+            self.noise.normal_(self._eps_td)
+            post.td_sample = (torch.empty((B_, n + 1, A), **f32), torch.empty((B_, n + 1), **f32))
+            post.td_pi = torch.empty((B_, n + 1, A), **f32)
+            jobs.append(native.squash_job(post.ls_td[..., :A], post.ls_td[..., A:], self._eps_td, *post.td_sample,
+                                          action=w.bnx_actions[:, b:], prob_out=post.td_pi))
+        # (with priorities the TD error's online-Q launch follows and hosts the second pass + the temperature step)
+        if self.use_priority and self._use_sidecars and rb.sharded is None:
+            sc_elect, post.sc_write = rb.window_scatter_sidecars(w.ids, -b, b + n, w.bnx_pad, 'mu_prob', probs_win[:, :-1])
+            if auto_alpha:
+                post.sc_alpha = self._alpha_sidecar(post.alpha_logp)
+        native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
+        if post.sc_alpha is not None:
+            self._alpha_logp_over_ranks(post.alpha_logp)
+        post.ls_win, post.probs_win = ls_win, probs_win
+        if self.use_priority:
+            xb = StockMLP._rows(w.bnx_states[:, b], self.state_size)
+            ab = StockMLP._rows(w.bnx_actions[:, b], self.c_action_size)
+            riders = [sc for sc in (post.sc_write, post.sc_alpha) if sc is not None]
+            if post.td_sample is not None:
+                job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
+                job_tq, td_q_table = self._ftq.job(
+                    td_rows if td_rows is not None else StockMLP._rows(w.bnx_target_states, self.state_size),
+                    StockMLP._rows(post.td_sample[0], self.c_action_size))
+                native.mlp_forward_multi([job_q, job_tq], sidecars=riders or None)
+                post.td_q_table = td_q_table.view(self.ensemble_q_num, *post.td_sample[1].shape)
+            elif riders:
+                job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
+                native.mlp_forward_multi([job_q], sidecars=riders)
+            else:
+                self._fq._launch_forward(xb, ab, out=self._cq_td_buf)
+            post.side_cq = self._cq_td_buf.view(self.ensemble_q_num, -1)
+        if post.sc_write is None:
+            rb.update_window_transitions(w.ids, -b, b + n, w.bnx_pad, 'mu_prob', probs_win[:, :-1])
+        post.mu_written = True
+
+    def _step_temperature_and_aux(self, w, post) -> None:
+        b = self.burn_in_step
+        if self._auto_alpha() and post.sc_alpha is None:      # (a sidecar: done by the launch that carries it)
+            self._train_alpha(w.obs_b, w.state_b, ls=None if post.ls_win is None else post.ls_win[:, b], logp=post.alpha_logp)
+        if self.curiosity is not None:
+            self._train_curiosity(w.bn_pad[:, b:], w.bnx_states[:, b:], w.bn_actions[:, b:])
+        if self.use_rnd:
+            self._train_rnd(w.bn_pad[:, b:], w.bnx_states[:, b:-1], w.bn_actions[:, b:])
+
+    def _step_write_backs(self, w, post) -> None:
+        """reference 2558-2605: TD error -> priorities; new behaviour probabilities and hidden states -> the ring"""
+        rb, b, n, ids = self.replay_buffer, self.burn_in_step, self.n_step, w.ids
+        bn_states = w.bnx_states[:, :-1]
         pi_probs = None
         if self.use_n_step_is:
-            if probs_win is not None:
-                pi_probs = probs_win[:, :-1]          # the last row's probability is not stored (1159-1189)
+            if post.probs_win is not None:
+                pi_probs = post.probs_win[:, :-1]          # the last row's probability is not stored (1159-1189)
             else:
-                pi_probs = self.get_l_probs([o[:, :-1] for o in bnx_obses_list], bn_states, bn_actions)
+                pi_probs = self.get_l_probs([o[:, :-1] for o in w.bnx_obses_list], bn_states, w.bn_actions)
         # the hidden-state write-back rides along too: its election beside the TD error's return, its write pass beside the
         # priority update (the step's last two launches; its own election scratch: the mu-probability write pass may
         # share the return launch)
-        hidden_rows = hidden_write = None
-        if (self.seq_hidden_state_shape[-1] != 0 and self.use_priority and self._use_sidecars and not self._parallel_branches
+        hidden_write = None
+        if (self.seq_hidden_state_shape[-1] != 0 and self.use_priority and self._use_sidecars
                 and rb.sharded is None and bool(self.c_action_size) and not self.d_action_sizes
                 and len(self._vtrace_sidecars or ()) < native.MAX_SIDECARS):
-            hidden_rows = next_hidden.detach().contiguous()
-            h_elect, hidden_write = rb.window_scatter_sidecars(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
+            hidden_rows = w.next_hidden.detach().contiguous()
+            h_elect, hidden_write = rb.window_scatter_sidecars(ids, 1 - b, b + n, w.bnx_pad, 'pre_seq_hidden_state',
                                                                hidden_rows, side=True)
             self._vtrace_sidecars = list(self._vtrace_sidecars or ()) + [h_elect]
         if self.use_priority:
             # no write pass waiting for the update's launch: the TD error's return and the priority update are one launch
             # (one workgroup forms every return: it pays while each of its threads has at most one step of one window —
             # measured: B 256 n 4 +2.5 %, B 512 n 3 -0.8 %, B 1024 n 3 -0.3 %)
-            merged = (self._fused_td_update and hidden_write is None and self._use_sidecars and not self._parallel_branches
+            merged = (self._fused_td_update and hidden_write is None and self._use_sidecars
                       and bool(self.c_action_size) and not self.d_action_sizes and ids.numel() * n <= 1024
                       and rb.td_update_ok(ids, n))
             self._td_update_with = (rb, ids) if merged else None
-            td = self._get_td_error(bn_last[:, b:], bn_pad[:, b:], nx_obs, bn_states[:, b],
-                                    bnx_target_states[:, b:], bnx_actions[:, b:], bn_rewards[:, b:],
-                                    bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
-                                    ls=None if td_sample is None else (ls_td if td_pi is not None else ls_win),
-                                    sample=td_sample,
-                                    stored_pi=None if td_sample is None else (td_pi if td_pi is not None else probs_win),
-                                    c_q=side_cq,
-                                    q_table=td_q_table)
+            own_td_policy = post.td_pi is not None     # the TD target's policy ran over the target states
+            td = self._get_td_error(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bn_states[:, b],
+                                    w.bnx_target_states[:, b:], w.bnx_actions[:, b:], w.bn_rewards[:, b:],
+                                    w.bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
+                                    ls=None if post.td_sample is None else (post.ls_td if own_td_policy else post.ls_win),
+                                    sample=post.td_sample,
+                                    stored_pi=None if post.td_sample is None else (post.td_pi if own_td_policy else post.probs_win),
+                                    c_q=post.side_cq,
+                                    q_table=post.td_q_table)
             assert not self._vtrace_sidecars, 'the TD error\'s return launch did not take its sidecars'
             if merged and self._td_update_with is None:
                 assert self._pending_alpha is None      # the return's launch ran the temperature step and the update
@@ -1839,13 +1863,10 @@ class SAC_Base(AuxHeadsMixin):
                 rb.update(ids, td, sidecars=[sc for sc in (self._pending_alpha, hidden_write) if sc is not None] or None)
                 self._pending_alpha = None
         if self.seq_hidden_state_shape[-1] != 0 and hidden_write is None:
-            rb.update_window_transitions(ids, 1 - b, b + n, bnx_pad, 'pre_seq_hidden_state',
-                                         next_hidden.detach().contiguous())
-        if self.use_n_step_is and probs_win is None:
-            rb.update_window_transitions(ids, -b, b + n, bnx_pad, 'mu_prob', pi_probs)
-        self._join()
-        if not self._counter_advanced:
-            self._opt_steps.add_(1)
+            rb.update_window_transitions(ids, 1 - b, b + n, w.bnx_pad, 'pre_seq_hidden_state',
+                                         w.next_hidden.detach().contiguous())
+        if self.use_n_step_is and not post.mu_written:
+            rb.update_window_transitions(ids, -b, b + n, w.bnx_pad, 'mu_prob', pi_probs)
 
     def _try_capture(self) -> None:
         """Warm up on a side stream, then capture `_device_step` into one hipGraph."""
@@ -1891,11 +1912,29 @@ class SAC_Base(AuxHeadsMixin):
             except Exception as e:   # older torch: keep torch's replay
                 self._logger.warning(f'raw graph handle unavailable, using CUDAGraph.replay(): {e!r}')
 
+    def _ready_to_train(self) -> bool:
+        """Reference `train` 2503-2506: no step until the buffer holds more than a batch.  A data-parallel step holds
+        collectives, so the ranks decide TOGETHER (one small all-reduce per call until it turns true, none afterwards):
+        throughput mode needs every rank's shard above its own batch; parity mode needs the UNION above the global batch
+        (and every rank to know the transition layout: it allocates its batch from it) — a rank with a short shard
+        takes part from the first step."""
+        rb = self.replay_buffer
+        if self._dist is None:
+            return rb.is_lg_batch_size
+        if self._dist_ready:
+            return True
+        if rb.sharded is not None:
+            all_have_keys, union = self._dist.all_ready(rb._columns is not None and bool(rb._columns), rb.size, self.device)
+            self._dist_ready = all_have_keys and union > rb.sharded.B
+        else:
+            self._dist_ready, _ = self._dist.all_ready(rb.is_lg_batch_size, rb.size, self.device)
+        return self._dist_ready
+
     @unified_elapsed_timer('train a step', 10)
     def train(self) -> int:
         step = self.get_global_step()
         rb = self.replay_buffer
-        if not rb.is_lg_batch_size:
+        if not self._ready_to_train():
             self._profiler('train a step').ignore()
             return step
         if rb._gather_keys is None:
@@ -1906,7 +1945,7 @@ class SAC_Base(AuxHeadsMixin):
             if self.update_target_per_step != 1 and step % self.update_target_per_step == 0:
                 self._update_target_variables(tau=self.tau)
             graph_ok = (self._use_graph and not self._graph_failed and isinstance(self.noise, DeviceNoise)
-                        and (self._dist is None or self._graph_collectives) and rb.sharded is None)
+                        and (self._dist is None or self._graph_collectives))
             if graph_ok and self._graph is None and self._eager_steps >= self._graph_warmup:
                 self._try_capture()
             if graph_ok and self._graph is not None:

@@ -107,4 +107,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Kernel arguments read WHERE THEY ARE USED.  A by-value struct parameter is loaded whole in the kernel's entry block:
+// with argument blocks of 0.5 - 2 KB the kernel starts with dozens of scalar loads in several dependent wait groups and
+// parks what does not fit the 102 SGPRs in VGPR lanes (`v_writelane`), all before its first vector load is issued.  A
+// reference into the kernarg segment (address space 4) makes every field an ordinary scalar load at its use: the staging
+// phase fetches what it needs in one batch, everything else arrives while the kernel is busy.  Usage:
+//     __global__ void k(const Args by_value) { const ASAC_KARG Args& a = *static_cast<const ASAC_KARG Args*>(kernarg_base()); ...
+// (`by_value` must be the FIRST parameter: offset 0 of the segment; it is never named again.)
+#define ASAC_KARG __attribute__((address_space(4)))
+__device__ __forceinline__ const ASAC_KARG void* kernarg_base() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const ASAC_KARG void*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;
+#endif
+}
+
 }  // namespace asac

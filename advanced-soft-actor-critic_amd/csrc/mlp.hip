@@ -37,7 +37,6 @@ constexpr int kP = 66;           // LDS pitch (floats)
 constexpr int kMaxW = 64;        // max layer width / input width
 constexpr int kMaxB = ASAC_MLP_MAX_BLOCKS;
 constexpr int kHeadPad = 16;     // head output columns are padded to one MFMA tile
-constexpr int kMaxThreads = 512;
 template <int TM> constexpr int threads_of() { return TM * 16; }    // one thread per (row, 4-column group)
 
 // 16-row tiles while they still fit one resident round of workgroups
@@ -307,12 +306,14 @@ __device__ __forceinline__ f32x4 gemm_tile_nt(const float* __restrict__ A, const
 
 // Gaussian policy head (reference nn_models/policy.py:170-172): columns of head 0 are means ->
 // 5*tanh(x/5), columns of head 1 are log-stds -> exp(clamp(x, -20, 0.5)).
-__device__ __forceinline__ float head_value(const asac_mlp_desc_t& d, int col, float raw) {
+template <typename DESC>
+__device__ __forceinline__ float head_value(const DESC& d, int col, float raw) {
     if (d.head_transform != 1) return raw;
     if (col < d.head_cols[0]) return tanhf(raw / 5.f) * 5.f;
     return expf(fminf(fmaxf(raw, -20.f), 0.5f));
 }
-__device__ __forceinline__ float head_deriv(const asac_mlp_desc_t& d, int col, float raw) {
+template <typename DESC>
+__device__ __forceinline__ float head_deriv(const DESC& d, int col, float raw) {
     if (d.head_transform != 1) return 1.f;
     if (col < d.head_cols[0]) {
         const float t = tanhf(raw / 5.f);
@@ -421,8 +422,8 @@ struct StageScalars {
 };
 #define ASAC_PIN(x) asm volatile("" : "+s"(x))
 
-template <int NB>
-__device__ __forceinline__ StageScalars stage_scalars(const MlpFwdArgs& a, int e) {
+template <int NB, typename ARGS>
+__device__ __forceinline__ StageScalars stage_scalars(const ARGS& a, int e) {
     StageScalars q;
     q.P = a.params + e * a.member_stride;
     q.x0 = a.x0, q.x1 = a.d.in1 > 0 ? a.x1 : a.x0;
@@ -1270,8 +1271,9 @@ __device__ __forceinline__ void ps_put_tile(const float (&v)[2], float* xs) {
     }
 }
 
-__global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs a) {
+__global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs a_by_value) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const ASAC_KARG PolicyStepArgs& a = *static_cast<const ASAC_KARG PolicyStepArgs*>(kernarg_base());   // (asac_common.h)
     PsLds& L = *reinterpret_cast<PsLds*>(smem_raw);
     PsPiLds& P = *reinterpret_cast<PsPiLds*>(smem_raw);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1560,6 +1562,45 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
 // two launches' worth), (loc | scale) and the sampled actions never travel through L2 between launches.  The policy
 // part is repeated by the E workgroups of a tile (they run side by side on different CUs); member 0's workgroup
 // writes the shared outputs.  Same MFMA chains and the very device functions of the separate launches: bit-identical.
+// Kernel-argument form of a forward job on a STOCK network (three 64-wide blocks on <= 64 inputs: what the
+// fixed-shape instantiations read): 32-bit offsets and strides, none of asac_mlp_desc_t's tables — 128 bytes instead of
+// MlpFwdArgs' 272.  A launch's argument block is fetched on its critical path and every field that stays live costs a
+// scalar register: with four MlpFwdArgs (1.9 KB with the sidecar list) k_pi_sample_q spilled 258 SGPRs and kept nine
+// dwords of scratch per lane; in this form it does neither.  The kernel expands a job back into the MlpFwdArgs view the
+// device functions are written against (the constants — three blocks, width 64 — fold at compile time).
+struct StockJobArg {
+    const float *P, *x0, *x1;
+    float* out;
+    int32_t member_stride, N, x0_rs, x0_ms, x1_rs, x1_ms, x0_sb, x0_T;
+    int32_t in0, in1, h0, h1, hw0, hw1, hb0, hb1;
+    int32_t w_off[3], b_off[3];
+    int32_t residual_bits, head_transform;
+};
+static_assert(sizeof(StockJobArg) == 128, "StockJobArg");
+
+template <typename JOB>
+__device__ __forceinline__ MlpFwdArgs expand_stock(const JOB& j) {
+    MlpFwdArgs a;
+    a.d.in0 = j.in0, a.d.in1 = j.in1, a.d.n_blocks = 3;
+#pragma unroll
+    for (int l = 0; l < kMaxB; ++l) {
+        a.d.width[l] = l < 3 ? kMaxW : 0;
+        a.d.residual[l] = l < 3 ? (j.residual_bits >> l) & 1 : 0;
+        a.d.w_off[l] = l < 3 ? j.w_off[l] : 0;
+        a.d.b_off[l] = l < 3 ? j.b_off[l] : 0;
+    }
+    a.d.head_cols[0] = j.h0, a.d.head_cols[1] = j.h1;
+    a.d.head_w_off[0] = j.hw0, a.d.head_w_off[1] = j.hw1;
+    a.d.head_b_off[0] = j.hb0, a.d.head_b_off[1] = j.hb1;
+    a.d.head_transform = j.head_transform, a.d.reserved_ = 0;
+    a.params = j.P, a.member_stride = j.member_stride;
+    a.x0 = j.x0, a.x0_rs = j.x0_rs, a.x0_ms = j.x0_ms;
+    a.x1 = j.x1, a.x1_rs = j.x1_rs, a.x1_ms = j.x1_ms;
+    a.x0_sb = j.x0_sb, a.x0_T = j.x0_T, a.pad_ = 0;
+    a.N = j.N, a.out = j.out;
+    return a;
+}
+
 struct PiQLds {
     float head[kHeadPad * kP];            // --- the layout of MlpLds<16> up to `w`: the extra plain forward jobs of the
     float bias[kMaxB][kMaxW];             //     launch run mlp_fwd_tiles<16> on the same memory
@@ -1582,22 +1623,72 @@ struct PiQCritic {       // a view with the member names net_put_fixed expects
     float (&head_bias)[kHeadPad];
 };
 
-struct PiQArgs {
-    MlpFwdArgs pi, q;            // pi.out: [N][2A] (loc | scale) or NULL; q.out: [E][N]
-    int32_t E, tile_groups;   // critics; workgroups along the tile axis (they loop over the tiles)
-    int32_t blocks;           // workgroups of the fused job = tile_groups * E
-    // sampling (asac_squash_job_t): main sample over every row, optional stored-action probabilities, optional second
-    // sample at window position t2
-    const float* eps;
-    float *a_out, *logp_out;
-    StoredProb sp;
-    const float* eps2;
-    int32_t T, t2;
-    float *a2_out, *logp2_out;
+// (32-bit strides: pi_q_job_ok bounds every offset of the launch below 2^29 floats)
+struct StoredProbArg {
+    const float* action;
+    float* out;
+    int32_t T, a_sb, a_st, a_off, p_sb, p_st, p_off, pad_;
+};
+struct PiQLaunch {
+    StockJobArg pi, q;                      // the fused job: pi.out [N][2A] or NULL, q.out [E][N]
+    const float *eps, *eps2;
+    float *a_out, *logp_out, *a2_out, *logp2_out;
+    StoredProbArg sp;
+    int32_t E, tile_groups, blocks, T, t2;
+    // plain forward jobs riding in the same launch (their workgroups follow the fused job's)
+    int32_t x_n, x_blocks;
+    int32_t x_E[ASAC_MLP_MAX_JOBS], x_first_block[ASAC_MLP_MAX_JOBS], x_tile_stride[ASAC_MLP_MAX_JOBS];
+    StockJobArg x_job[ASAC_MLP_MAX_JOBS];
 };
 
+
+// Kernel arguments are read WHERE THEY ARE USED, through the kernarg segment's own address space: a by-value struct
+// parameter is loaded whole in the kernel's entry block (k_pi_sample_q: ~130 scalar registers parked in VGPR lanes by
+// `v_writelane` before the first weight load was issued); a reference into the segment makes each field an ordinary
+// scalar load at its use — the staging phase fetches what it needs in one batch (stage_scalars_stock), the sampling
+// pointers arrive while the policy runs.
+__device__ __forceinline__ StageScalars stage_scalars_stock(const ASAC_KARG StockJobArg& j, int e) {
+    StageScalars q;
+    q.P = j.P + e * j.member_stride;
+    q.x0 = j.x0, q.x1 = j.in1 > 0 ? j.x1 : j.x0;
+    q.N = j.N, q.x0_rs = j.x0_rs, q.x0_ms = j.x0_ms, q.x1_rs = j.x1_rs, q.x1_ms = j.x1_ms, q.x0_sb = j.x0_sb;
+    q.in0 = j.in0, q.in1 = j.in1, q.x0_T = j.x0_T;
+    q.h0 = j.h0, q.h1 = j.h1;
+    q.hw0 = j.hw0, q.hw1 = j.hw1, q.hb0 = j.hb0, q.hb1 = j.hb1;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) q.w_off[l] = j.w_off[l], q.b_off[l] = j.b_off[l];
+    ASAC_PIN(q.P); ASAC_PIN(q.x0); ASAC_PIN(q.x1);
+    ASAC_PIN(q.N); ASAC_PIN(q.x0_rs); ASAC_PIN(q.x0_ms); ASAC_PIN(q.x1_rs); ASAC_PIN(q.x1_ms); ASAC_PIN(q.x0_sb);
+    ASAC_PIN(q.in0); ASAC_PIN(q.in1); ASAC_PIN(q.x0_T); ASAC_PIN(q.h0); ASAC_PIN(q.h1);
+    ASAC_PIN(q.hw0); ASAC_PIN(q.hw1); ASAC_PIN(q.hb0); ASAC_PIN(q.hb1);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { ASAC_PIN(q.w_off[l]); ASAC_PIN(q.b_off[l]); }
+    return q;
+}
+
+// ... of a second network on the SAME rows as `rows` (x0 addressing shared; x1 is never fetched: it is formed on chip)
+__device__ __forceinline__ StageScalars stage_scalars_stock_like(const ASAC_KARG StockJobArg& j, int e, const StageScalars& rows) {
+    StageScalars q = rows;
+    q.P = j.P + e * j.member_stride;
+    q.in1 = j.in1;
+    q.h0 = j.h0, q.h1 = j.h1;
+    q.hw0 = j.hw0, q.hw1 = j.hw1, q.hb0 = j.hb0, q.hb1 = j.hb1;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) q.w_off[l] = j.w_off[l], q.b_off[l] = j.b_off[l];
+    ASAC_PIN(q.P); ASAC_PIN(q.in1); ASAC_PIN(q.h0); ASAC_PIN(q.h1);
+    ASAC_PIN(q.hw0); ASAC_PIN(q.hw1); ASAC_PIN(q.hb0); ASAC_PIN(q.hb1);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { ASAC_PIN(q.w_off[l]); ASAC_PIN(q.b_off[l]); }
+    return q;
+}
+
+// the Gaussian policy head (policy.py:170-172): location columns 5 tanh(x / 5), scale columns exp(clamp(x, -20, 0.5))
+__device__ __forceinline__ float gauss_head_value(bool location, float raw) {
+    return location ? tanhf(raw / 5.f) * 5.f : expf(fminf(fmaxf(raw, -20.f), 0.5f));
+}
+
 template <bool WINDOW>
-__device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
+__device__ __forceinline__ void pi_q_tiles(const ASAC_KARG PiQLaunch& a, PiQLds& L) {
     // eight waves: the staging (loads and LDS writes of two networks and the input tile) is dealt over 512 threads —
     // 1.5 us instead of 2.5; the forward chains have four column tiles: waves 4..7 only keep the barriers company there
     constexpr int THREADS = 512;
@@ -1606,15 +1697,17 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
     const int e = (int)blockIdx.x % a.E, group = (int)blockIdx.x / a.E;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = wave * 16 + (lane & 15);
-    const int A = a.pi.d.head_cols[0], S = a.q.d.in0;
-    const int K0p = a.pi.d.in0, K0q = a.q.d.in0 + a.q.d.in1;
-    const int64_t N = a.pi.N;
+    const int A = a.pi.h0, S = a.q.in0;
+    const int K0p = a.pi.in0, K0q = a.q.in0 + a.q.in1;
+    const int N = a.pi.N;                 // (rows, strides and offsets of this launch are below 2^29: 32-bit index arithmetic)
     const int n_tiles = (int)((N + 15) / 16);
     const bool writer = e == 0;
     MLP_STAMP(0);
 
     // ---- staging: the policy and critic e, one round trip ----------------------------------------------------------
-    const StageScalars sp = stage_scalars<3>(a.pi, 0), sq = stage_scalars<3>(a.q, e);
+    // (the critics read the policy's rows — pi_q_job_ok: their row addressing shares the policy's registers)
+    const StageScalars sp = stage_scalars_stock(a.pi, 0);
+    const StageScalars sq = stage_scalars_stock_like(a.q, e, sp);
     float in_lo[SLOTS];
     fetch_input_tile_fixed<THREADS, WINDOW, SLOTS>(sp, 0, (int64_t)group * 16, in_lo);
     StagedNet<THREADS> rp, rq;
@@ -1629,7 +1722,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
     MLP_STAMP(1);
 
     for (int tile = group; tile < n_tiles; tile += a.tile_groups) {
-        const int64_t row0 = (int64_t)tile * 16;
+        const int row0 = tile * 16;
         if (tile != group) {       // (later tiles of a looping workgroup: the first one arrived with the weights)
             fetch_input_tile_fixed<THREADS, WINDOW, SLOTS>(sp, 0, row0, in_lo);
             __syncthreads();
@@ -1645,7 +1738,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
                 float* xout = L.xs[cur ^ 1];
                 const f32x4 acc = l > 0 ? gemm_tile(xin, L.w[l], kMaxW, 0, wave) : gemm_tile(xin, L.w[l], round4(K0p), 0, wave);
                 const float bias = L.bias[l][col];
-                const bool res = a.pi.d.residual[l] != 0;
+                const bool res = (a.pi.residual_bits >> l) & 1;
                 f32x2_g ya, yb, unused;
                 gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
                 gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
@@ -1670,7 +1763,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
             const int hc = lane & 15;
             const float mine = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
             const int lrow = 4 * (lane >> 4) + wave;
-            const float v = head_value(a.pi.d, hc, mine + L.head_bias[hc]);
+            const float v = gauss_head_value(hc < A, mine + L.head_bias[hc]);
             L.ls[lrow * 2 * kHeadPad + hc] = v;
             if (writer && a.pi.out && row0 + lrow < N && hc < 2 * A) a.pi.out[(row0 + lrow) * (2 * A) + hc] = v;
         }
@@ -1690,18 +1783,19 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
             if (job < 3 && job_on) {
                 for (int it = lane; it < 16 * A; it += 64) {
                     const int lrow = it / A, d = it - lrow * A;
-                    const int64_t r = row0 + lrow;
+                    const int r = row0 + lrow;
                     if (r >= N) continue;
                     const float l = L.ls[lrow * 2 * kHeadPad + d], sc = L.ls[lrow * 2 * kHeadPad + A + d];
                     if (job == 1) {
-                        const int64_t sb = r / a.sp.T, st = r - sb * a.sp.T;
+                        const int spT = a.sp.T;
+                        const int sb = (int)((unsigned)r / (unsigned)spT), st = r - sb * spT;
                         const float av = a.sp.action[sb * a.sp.a_sb + st * a.sp.a_st + a.sp.a_off + d];
                         const float x = atanhf(fminf(fmaxf(av, -0.999f), 0.999f));
                         s0[lrow * 8 + d] = squash_jac(x);
                         s1[lrow * 8 + d] = expf(normal_log_prob(x, l, sc));
                     } else {
                         float ev;
-                        const int64_t smp = r / a.T;
+                        const int smp = (int)((unsigned)r / (unsigned)a.T);
                         if (job == 0) {
                             ev = a.eps[r * A + d];
                         } else {
@@ -1725,16 +1819,17 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (lane < 16) {
                     const int lrow = lane;
-                    const int64_t r = row0 + lrow;
+                    const int r = row0 + lrow;
                     if (r < N) {
                         if (job == 1) {
                             float jac = 1.f;
                             for (int d = 0; d < A; ++d) jac *= s0[lrow * 8 + d];
-                            const int64_t sb = r / a.sp.T, st = r - sb * a.sp.T;
-                            float* out = a.sp.out + sb * a.sp.p_sb + st * a.sp.p_st + a.sp.p_off;
+                            const int spT = a.sp.T;
+                            const int sb = (int)((unsigned)r / (unsigned)spT), st = r - sb * spT;
+                            float* out = a.sp.out + (sb * a.sp.p_sb + st * a.sp.p_st + a.sp.p_off);
                             for (int d = 0; d < A; ++d) out[d] = s1[lrow * 8 + d] / jac;
                         } else {
-                            const int64_t smp = r / a.T;
+                            const int smp = (int)((unsigned)r / (unsigned)a.T);
                             if (job == 0 || r - smp * a.T == a.t2) {
                                 float corr = 0.f;
                                 for (int d = 0; d < A; ++d) corr += s0[lrow * 8 + d];
@@ -1773,7 +1868,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
                 float* xout = L.xs[cur ^ 1];
                 const f32x4 acc = l > 0 ? gemm_tile(xin, L.qw[l], kMaxW, 0, wave) : gemm_tile(xin, L.qw[l], round4(K0q), 0, wave);
                 const float bias = L.qbias[l][col];
-                const bool res = a.q.d.residual[l] != 0;
+                const bool res = (a.q.residual_bits >> l) & 1;
                 f32x2_g ya, yb, unused;
                 gelu_parts2((f32x2_g){acc[0] + bias, acc[1] + bias}, ya, unused);
                 gelu_parts2((f32x2_g){acc[2] + bias, acc[3] + bias}, yb, unused);
@@ -1795,7 +1890,7 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
             if ((lane & 15) == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t row = row0 + 4 * (lane >> 4) + r;
+                    const int row = row0 + 4 * (lane >> 4) + r;
                     if (row < N) a.q.out[(int64_t)e * N + row] = acc[r] + L.qhead_bias[0];
                 }
             }
@@ -1804,42 +1899,42 @@ __device__ __forceinline__ void pi_q_tiles(const PiQArgs& a, PiQLds& L) {
     }
 }
 
-struct PiQLaunch {
-    PiQArgs f;
-    MlpMultiArgs extra;       // plain forward jobs riding in the same launch (their workgroups follow the fused job's)
-};
-
+static_assert(sizeof(PiQLaunch) <= 672, "kernel arguments of k_pi_sample_q (was 1 240 bytes as four MlpFwdArgs)");
 static_assert(sizeof(PiQLaunch) + sizeof(SidecarsDev) <= 4096, "kernel arguments of k_pi_sample_q");
 
 template <int NSC>
-__global__ __launch_bounds__(512) void k_pi_sample_q(const PiQLaunch m, const SidecarsT<NSC> sc) {
+__global__ __launch_bounds__(512) void k_pi_sample_q(const PiQLaunch m_by_value, const SidecarsT<NSC> sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (`m_by_value` sits at offset 0 of the kernarg segment; it is read through `m`, field by field, where used)
+    const ASAC_KARG PiQLaunch& m = *static_cast<const ASAC_KARG PiQLaunch*>(kernarg_base());
     const int blk = (int)blockIdx.x;
+    const int fused_blocks = m.blocks;
     // (the fused job's workgroups run eight waves; the plain forward jobs and the sidecars riding along are written
     // for four: their workgroups let the other four go — a finished wave no longer counts at the barriers)
-    if (blk >= m.f.blocks && threadIdx.x >= 256) return;
-    if (blk < m.f.blocks) {
+    if (blk >= fused_blocks && threadIdx.x >= 256) return;
+    if (blk < fused_blocks) {
         PiQLds& L = *reinterpret_cast<PiQLds*>(smem_raw);
-        if (m.f.pi.x0_T > 0) pi_q_tiles<true>(m.f, L);
-        else pi_q_tiles<false>(m.f, L);
+        if (m.pi.x0_T > 0) pi_q_tiles<true>(m, L);
+        else pi_q_tiles<false>(m, L);
         return;
     }
-    const int xb = blk - m.f.blocks;
-    if (xb >= m.extra.blocks) {
-        sidecar_run(sc, xb - m.extra.blocks, reinterpret_cast<float*>(smem_raw));
+    const int xb = blk - fused_blocks;
+    if (xb >= m.x_blocks) {
+        sidecar_run(sc, xb - m.x_blocks, reinterpret_cast<float*>(smem_raw));
         return;
     }
     int k = 0;
 #pragma unroll
     for (int q = 1; q < ASAC_MLP_MAX_JOBS; ++q)
-        if (q < m.extra.n && xb >= m.extra.first_block[q]) k = q;
-    const int local = xb - m.extra.first_block[k];
-    const int E = m.extra.E[k];
+        if (q < m.x_n && xb >= m.x_first_block[q]) k = q;
+    const int local = xb - m.x_first_block[k];
+    const int E = m.x_E[k];
     MlpLds<16>& L = *reinterpret_cast<MlpLds<16>*>(smem_raw);
-    if (m.extra.job[k].x0_T > 0)
-        mlp_fwd_tiles<16, true, false, 3>(m.extra.job[k], local % E, local / E, m.extra.tile_stride[k], L);
+    const MlpFwdArgs job = expand_stock(m.x_job[k]);
+    if (job.x0_T > 0)
+        mlp_fwd_tiles<16, true, false, 3>(job, local % E, local / E, m.x_tile_stride[k], L);
     else
-        mlp_fwd_tiles<16, false, false, 3>(m.extra.job[k], local % E, local / E, m.extra.tile_stride[k], L);
+        mlp_fwd_tiles<16, false, false, 3>(job, local % E, local / E, m.x_tile_stride[k], L);
 }
 
 // grad[e*stride + i] (+)= sum_tiles partial[tile][e][i]   (fixed order: deterministic)
@@ -2271,6 +2366,28 @@ int asac_policy_step_fused(const asac_mlp_desc_t* q_desc, const float* q_params,
     return finish_launch("asac_policy_step_fused");
 }
 
+static bool fits32(int64_t v) { return v >= 0 && v < 0x1fffffffLL; }
+
+// asac_mlp_desc_t + addressing -> the compact kernel-argument form (callers have checked stock3 and the 32-bit ranges)
+static StockJobArg stock_job_arg(const asac_mlp_desc_t* d, const float* params, int64_t member_stride, const float* x0,
+                                 int64_t x0_rs, int64_t x0_ms, const float* x1, int64_t x1_rs, int64_t x1_ms, int64_t N,
+                                 int64_t x0_T, int64_t x0_sb, float* out) {
+    StockJobArg j{};
+    j.P = params, j.x0 = x0, j.x1 = x1, j.out = out;
+    j.member_stride = (int32_t)member_stride, j.N = (int32_t)N;
+    j.x0_rs = (int32_t)x0_rs, j.x0_ms = (int32_t)x0_ms, j.x1_rs = (int32_t)x1_rs, j.x1_ms = (int32_t)x1_ms;
+    j.x0_sb = (int32_t)x0_sb, j.x0_T = (int32_t)x0_T;
+    j.in0 = d->in0, j.in1 = d->in1, j.h0 = d->head_cols[0], j.h1 = d->head_cols[1];
+    j.hw0 = (int32_t)d->head_w_off[0], j.hw1 = (int32_t)d->head_w_off[1];
+    j.hb0 = (int32_t)d->head_b_off[0], j.hb1 = (int32_t)d->head_b_off[1];
+    for (int l = 0; l < 3; ++l) {
+        j.w_off[l] = (int32_t)d->w_off[l], j.b_off[l] = (int32_t)d->b_off[l];
+        j.residual_bits |= (d->residual[l] ? 1 : 0) << l;
+    }
+    j.head_transform = d->head_transform;
+    return j;
+}
+
 static bool pi_q_job_ok(const asac_pi_q_job_t& j) {
     const asac_mlp_job_t &p = j.pi, &q = j.q;
     if (!p.desc || !q.desc || !desc_ok(*p.desc) || !desc_ok(*q.desc) || p.N <= 0 || q.N != p.N || p.E != 1 || q.E < 1) return false;
@@ -2286,6 +2403,10 @@ static bool pi_q_job_ok(const asac_pi_q_job_t& j) {
     if (!s.eps || !s.a_tanh_out || !s.logp_out || s.A != A || s.rows != p.N) return false;
     if (s.action && (!s.prob_out || s.T <= 0)) return false;
     if (j.eps2 && (!j.a2_out || !j.logp2_out || s.T <= 0 || j.t2 < 0 || j.t2 >= s.T)) return false;
+    if (!fits32(p.member_stride) || !fits32(q.member_stride * q.E)) return false;
+    if (s.action && (!fits32((p.N / s.T + 1) * s.action_stride_b) || !fits32((p.N / s.T + 1) * s.prob_stride_b) ||
+                     !fits32(s.T * s.action_stride_t) || !fits32(s.T * s.prob_stride_t)))
+        return false;
     return p.N * (p.x0_row_stride + 1) < 0x1fffffffLL &&
            (p.x0_window_T == 0 || (p.N / p.x0_window_T + 1) * p.x0_sample_stride < 0x1fffffffLL);
 }
@@ -2300,52 +2421,44 @@ int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_
     if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_policy_sample_q_forward: sidecar");
     PiQLaunch m{};
     const asac_mlp_job_t &p = job->pi, &q = job->q;
-    PiQArgs& f = m.f;
-    f.pi = make_args(p.desc, p.params, p.member_stride, p.x0, p.x0_row_stride, 0, nullptr, 0, 0, p.N);
-    f.pi.x0_T = p.x0_window_T;
-    f.pi.x0_sb = p.x0_sample_stride;
-    f.pi.out = p.out;
-    f.q = make_args(q.desc, q.params, q.member_stride, p.x0, p.x0_row_stride, 0, p.x0, 0, 0, p.N);   // (x1: the sampled actions, on chip)
-    f.q.x0_T = p.x0_window_T;
-    f.q.x0_sb = p.x0_sample_stride;
-    f.q.out = q.out;
-    f.E = q.E;
+    m.pi = stock_job_arg(p.desc, p.params, p.member_stride, p.x0, p.x0_row_stride, 0, nullptr, 0, 0, p.N, p.x0_window_T,
+                         p.x0_sample_stride, p.out);
+    m.q = stock_job_arg(q.desc, q.params, q.member_stride, p.x0, p.x0_row_stride, 0, p.x0, 0, 0, p.N, p.x0_window_T,
+                        p.x0_sample_stride, q.out);            // (x1: the sampled actions, on chip)
+    m.E = q.E;
     const int tiles = (int)((p.N + 15) / 16);
     const int cap = 256 / q.E > 0 ? 256 / q.E : 1;
-    f.tile_groups = tiles <= cap ? tiles : cap;
-    f.blocks = f.tile_groups * q.E;
+    m.tile_groups = tiles <= cap ? tiles : cap;
+    m.blocks = m.tile_groups * q.E;
     const asac_squash_job_t& sj = job->sample;
-    f.eps = sj.eps;
-    f.a_out = sj.a_tanh_out;
-    f.logp_out = sj.logp_out;
-    f.sp = StoredProb{sj.action, sj.T, sj.action_stride_b, sj.action_stride_t, sj.action_offset,
-                      sj.prob_out, sj.prob_stride_b, sj.prob_stride_t, sj.prob_offset};
-    f.eps2 = job->eps2;
-    f.T = sj.T > 0 ? sj.T : 1;
-    f.t2 = job->t2;
-    f.a2_out = job->a2_out;
-    f.logp2_out = job->logp2_out;
-    MlpMultiArgs& x = m.extra;
-    x.n = n_extra;
+    m.eps = sj.eps;
+    m.a_out = sj.a_tanh_out;
+    m.logp_out = sj.logp_out;
+    m.sp = StoredProbArg{sj.action, sj.prob_out, sj.T, (int32_t)sj.action_stride_b, (int32_t)sj.action_stride_t, sj.action_offset,
+                         (int32_t)sj.prob_stride_b, (int32_t)sj.prob_stride_t, sj.prob_offset, 0};
+    m.eps2 = job->eps2;
+    m.T = sj.T > 0 ? sj.T : 1;
+    m.t2 = job->t2;
+    m.a2_out = job->a2_out;
+    m.logp2_out = job->logp2_out;
+    m.x_n = n_extra;
     int blocks = 0;
     for (int k = 0; k < n_extra; ++k) {
         const asac_mlp_job_t& j = extra_jobs[k];
         if (!j.desc || !desc_ok(*j.desc) || !stock3(*j.desc, j.params, j.member_stride) || j.E <= 0 || j.N <= 0 || !j.x0 ||
             (j.desc->in1 > 0 && !j.x1) || !j.out || j.x0_window_T < 0 ||
             j.N * (j.x0_row_stride + j.x1_row_stride + 1) >= 0x1fffffffLL ||
-            (j.x0_window_T > 0 && (j.N / j.x0_window_T + 1) * j.x0_sample_stride >= 0x1fffffffLL))
+            (j.x0_window_T > 0 && (j.N / j.x0_window_T + 1) * j.x0_sample_stride >= 0x1fffffffLL) ||
+            !fits32(j.member_stride) || !fits32(j.x0_member_stride) || !fits32(j.x1_member_stride))
             return bad_arg("asac_policy_sample_q_forward: extra job");
-        x.job[k] = make_args(j.desc, j.params, j.member_stride, j.x0, j.x0_row_stride, j.x0_member_stride, j.x1,
-                             j.x1_row_stride, j.x1_member_stride, j.N);
-        x.job[k].x0_T = j.x0_window_T;
-        x.job[k].x0_sb = j.x0_sample_stride;
-        x.job[k].out = j.out;
-        x.E[k] = j.E;
-        x.first_block[k] = blocks;
-        x.tile_stride[k] = mlp_tile_groups(j.N, j.E, 1, 16);
-        blocks += x.tile_stride[k] * j.E;
+        m.x_job[k] = stock_job_arg(j.desc, j.params, j.member_stride, j.x0, j.x0_row_stride, j.x0_member_stride, j.x1,
+                                   j.x1_row_stride, j.x1_member_stride, j.N, j.x0_window_T, j.x0_sample_stride, j.out);
+        m.x_E[k] = j.E;
+        m.x_first_block[k] = blocks;
+        m.x_tile_stride[k] = mlp_tile_groups(j.N, j.E, 1, 16);
+        blocks += m.x_tile_stride[k] * j.E;
     }
-    x.blocks = blocks;
+    m.x_blocks = blocks;
     static bool attr_done = false;
     static bool attr_done1 = false;
     if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_pi_sample_q<ASAC_MAX_SIDECARS>), sizeof(PiQLds), attr_done,
@@ -2357,7 +2470,7 @@ int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_
     const SidecarsDev none{};
     for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
         const bool last = rep == g_launch_repeat - 1;
-        const dim3 grid((unsigned)(f.blocks + blocks + (last ? sc.blocks : 0)));
+        const dim3 grid((unsigned)(m.blocks + blocks + (last ? sc.blocks : 0)));
         if (sc.n <= 1)
             hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(512), sizeof(PiQLds), as_stream(stream), m,
                                sidecars_first<1>(last ? sc : none));

@@ -60,7 +60,8 @@ __device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
     double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
     double beta_increment, int32_t* __restrict__ leaf_out, float* __restrict__ p_out,
-    int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out, const SampleDraw draw = SampleDraw{}) {
+    int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out, const SampleDraw draw = SampleDraw{},
+    const int32_t* __restrict__ owner = nullptr, int rank = 0) {
     __shared__ float top[kLdsNodes + 1];
     __shared__ float red[kSampleBlock / kWave];
     __shared__ double s_beta;
@@ -95,6 +96,10 @@ __device__ __forceinline__ void sumtree_sample_body(
         }
         double v = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
         if (EXPLICIT) v = u[i];                                // the caller's own values (asac_sumtree_descend)
+        if (EXPLICIT && owner && owner[i] != rank) {           // another shard's sample: nothing of it lives here
+            leaf_out[i] = -1, p_out[i] = 0.f, ids_out[i] = -1;
+            continue;
+        }
         int node = 0, l = 0;
         float p = root;
         // one level of the reference's descent: left/right sums a, b of the current node's children
@@ -212,6 +217,74 @@ __global__ __launch_bounds__(kSampleBlock) void k_sumtree_descend(
     int64_t* __restrict__ ids_out, float* scratch_min) {
     sumtree_sample_body<false, false, false, true>(tree, capacity, levels, n, const_cast<double*>(v), slot_ids, nullptr, 0.0,
                                                    leaf_out, p_out, ids_out, nullptr, scratch_min);
+}
+
+// ... of the samples this shard owns only (the others get leaf -1, priority 0, id -1)
+__global__ __launch_bounds__(kSampleBlock) void k_sumtree_descend_owned(
+    const float* __restrict__ tree, int capacity, int levels, int n, const double* __restrict__ v,
+    const int32_t* __restrict__ owner, int rank, const int64_t* __restrict__ slot_ids, int32_t* __restrict__ leaf_out,
+    float* __restrict__ p_out, int64_t* __restrict__ ids_out, float* scratch_min) {
+    sumtree_sample_body<false, false, false, true>(tree, capacity, levels, n, const_cast<double*>(v), slot_ids, nullptr, 0.0,
+                                                   leaf_out, p_out, ids_out, nullptr, scratch_min, SampleDraw{}, owner, rank);
+}
+
+// The TOP of a sharded sum tree (SURVEY.md section 8e "parity"): the G = 2^k shard roots are the leaves of a heap whose
+// parents are formed like the reference's (left + right in f32, replay_buffer.py:172-183); every sample of the GLOBAL
+// batch draws its stratified value over the global root and walks these k levels with the reference's comparisons
+// (f64 value against f32 sums, 196-205) -> the owning shard and the residual value its own tree continues with.
+// Every rank runs this on the same roots and uniforms and gets the same plan.
+constexpr int kMaxShards = 64;
+__global__ __launch_bounds__(kSampleBlock) void k_sumtree_plan_top(const float* __restrict__ roots, int G, int levels_top,
+                                                                   int batch, const double* __restrict__ u,
+                                                                   int32_t* __restrict__ owner_out, double* __restrict__ v_out,
+                                                                   float* __restrict__ total_out) {
+    __shared__ float heap[2 * kMaxShards];
+    if ((int)threadIdx.x < G) heap[G - 1 + threadIdx.x] = roots[threadIdx.x];
+    __syncthreads();
+    for (int l = levels_top - 1; l >= 0; --l) {          // parents of level l, bottom up
+        const int first = (1 << l) - 1, count = 1 << l;
+        if ((int)threadIdx.x < count) {
+            const int node = first + threadIdx.x;
+            heap[node] = heap[2 * node + 1] + heap[2 * node + 2];
+        }
+        __syncthreads();
+    }
+    const float root = heap[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = root;
+    const int i = blockIdx.x * kSampleBlock + threadIdx.x;
+    if (i >= batch) return;
+    const float seg = root / (float)batch;                 // np.float32(root / B)
+    const double lo = (double)i * (double)seg, hi = (double)(i + 1) * (double)seg;
+    double v = lo + (hi - lo) * u[i];
+    int node = 0;
+    for (int l = 0; l < levels_top; ++l) {
+        const int left = 2 * node + 1;
+        const float a = heap[left], b = heap[left + 1];
+        const bool go_left = (v <= (double)a) || (b == 0.0f);
+        if (!go_left) v -= (double)a;
+        node = go_left ? left : left + 1;
+    }
+    owner_out[i] = node - (G - 1);
+    v_out[i] = v;
+}
+
+// IS weights of the rows [lo, lo + per) of a GLOBAL batch whose leaf priorities p_all[n_all] and total are at hand (the
+// sharded parity sampling after its all-reduce): the minimum runs over the whole batch, beta advances first
+// (replay_buffer.py:352-354).  One workgroup.
+__global__ __launch_bounds__(256) void k_is_weights_slice(const float* __restrict__ p_all, int n_all, int lo, int per,
+                                                          const float* __restrict__ total, double* beta_state,
+                                                          double beta_increment, float* __restrict__ w_out) {
+    __shared__ float red[4];
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < n_all; i += blockDim.x) m = fminf(m, p_all[i]);
+    m = wave_min(m);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+    const double b = fmin(1.0, *beta_state + beta_increment);
+    const float tot = *total;
+    __syncthreads();
+    const float min_ratio = fminf(fminf(red[0], red[1]), fminf(red[2], red[3])) / tot;
+    if (threadIdx.x == 0) *beta_state = b;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) w_out[i] = is_weight(p_all[lo + i], tot, min_ratio, b);
 }
 
 __global__ void k_fill_u32(unsigned int* p, unsigned int v) { *p = v; }
@@ -425,6 +498,42 @@ int asac_sumtree_descend(const float* tree, int capacity, int n, const double* v
     ASAC_LAUNCH(k_sumtree_descend, dim3((n + kSampleBlock - 1) / kSampleBlock), dim3(kSampleBlock), 0, as_stream(stream),
                 tree, capacity, ilog2(capacity), n, values, slot_ids, leaf_out, p_out, ids_out, scratch);
     return finish_launch("asac_sumtree_descend");
+}
+
+int asac_sumtree_descend_owned(const float* tree, int capacity, int n, const double* values, const int32_t* owner,
+                               int rank, const int64_t* slot_ids, int32_t* leaf_out, float* p_out, int64_t* ids_out,
+                               void* stream) {
+    if (capacity <= 0 || (capacity & (capacity - 1)) || n <= 0 || !tree || !values || !owner || !slot_ids || !leaf_out ||
+        !p_out || !ids_out)
+        return bad_arg("asac_sumtree_descend_owned");
+    static float* scratch = nullptr;      // the body's per-launch minimum lands here (unused)
+    if (!scratch && hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(float)) != hipSuccess)
+        return bad_arg("asac_sumtree_descend_owned: scratch");
+    ASAC_LAUNCH(k_sumtree_descend_owned, dim3((n + kSampleBlock - 1) / kSampleBlock), dim3(kSampleBlock), 0,
+                as_stream(stream), tree, capacity, ilog2(capacity), n, values, owner, rank, slot_ids, leaf_out, p_out,
+                ids_out, scratch);
+    return finish_launch("asac_sumtree_descend_owned");
+}
+
+int asac_sumtree_plan_top(const float* shard_roots, int n_shards, int batch, const double* u, int32_t* owner_out,
+                          double* value_out, float* total_out, void* stream) {
+    if (n_shards <= 0 || n_shards > kMaxShards || (n_shards & (n_shards - 1)) || batch <= 0 || !shard_roots || !u ||
+        !owner_out || !value_out || !total_out)
+        return bad_arg("asac_sumtree_plan_top");
+    ASAC_LAUNCH(k_sumtree_plan_top, dim3((batch + kSampleBlock - 1) / kSampleBlock), dim3(kSampleBlock), 0,
+                as_stream(stream), shard_roots, n_shards, ilog2(n_shards), batch, u, owner_out, value_out, total_out);
+    return finish_launch("asac_sumtree_plan_top");
+}
+
+int asac_per_is_weights_slice(const float* p_all, int n_all, int first, int count, const float* total, double* beta_state,
+                              double beta_increment, float* is_weights_out, void* stream) {
+    if (n_all <= 0 || first < 0 || count <= 0 || first + count > n_all || !p_all || !total || !beta_state || !is_weights_out)
+        return bad_arg("asac_per_is_weights_slice");
+    // (not idempotent: under the measurement repeat knob beta advances in the first repetition only)
+    for (int rep = 0; rep < g_launch_repeat; ++rep)
+        hipLaunchKernelGGL(k_is_weights_slice, dim3(1), dim3(256), 0, as_stream(stream), p_all, n_all, first, count, total,
+                           beta_state, rep == 0 ? beta_increment : 0.0, is_weights_out);
+    return finish_launch("asac_per_is_weights_slice");
 }
 
 int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,

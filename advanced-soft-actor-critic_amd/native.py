@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 49
+ABI_VERSION = 50
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -140,6 +140,11 @@ _SIGNATURES = {
     'asac_sumtree_leaf_max': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_sumtree_check': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_gelu_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'asac_sumtree_plan_top': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_sumtree_descend_owned': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_per_is_weights_slice': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
+                                            C.c_void_p, C.c_void_p]),
     'asac_window_gather_pad': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_sumtree_descend': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -451,6 +456,25 @@ def sumtree_leaf_max(tree, capacity, out):
 
 def sumtree_check(tree, capacity, out):
     _check(load().asac_sumtree_check(_p(tree), capacity, _p(out), _stream()), 'asac_sumtree_check')
+
+
+def sumtree_plan_top(shard_roots, batch, u, owner_out, value_out, total_out):
+    assert shard_roots.dtype == torch.float32 and u.dtype == torch.float64 and owner_out.dtype == torch.int32
+    assert value_out.dtype == torch.float64 and u.numel() >= batch
+    _check(load().asac_sumtree_plan_top(_p(shard_roots), shard_roots.numel(), batch, _p(u), _p(owner_out), _p(value_out),
+                                        _p(total_out), _stream()), 'asac_sumtree_plan_top')
+
+
+def sumtree_descend_owned(tree, capacity, values, owner, rank, slot_ids, leaf_out, p_out, ids_out):
+    assert values.dtype == torch.float64 and owner.dtype == torch.int32 and ids_out.dtype == torch.int64
+    _check(load().asac_sumtree_descend_owned(_p(tree), capacity, values.numel(), _p(values), _p(owner), int(rank),
+                                             _p(slot_ids), _p(leaf_out), _p(p_out), _p(ids_out), _stream()),
+           'asac_sumtree_descend_owned')
+
+
+def per_is_weights_slice(p_all, first, count, total, beta_state, beta_increment, w_out):
+    _check(load().asac_per_is_weights_slice(_p(p_all), p_all.numel(), first, count, _p(total), _p(beta_state),
+                                            float(beta_increment), _p(w_out), _stream()), 'asac_per_is_weights_slice')
 
 
 def gelu_eval(z, value, deriv):

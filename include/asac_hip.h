@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 49
+#define ASAC_ABI_VERSION 50
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -80,6 +80,27 @@ int asac_sumtree_sample(const float* tree, int capacity, int batch, const double
  * top levels every rank walks on the host; the owner finishes the walk here with the residual values. */
 int asac_sumtree_descend(const float* tree, int capacity, int n, const double* values, const int64_t* slot_ids,
                          int32_t* leaf_out, float* p_out, int64_t* ids_out, void* stream);
+
+/* Sharded replay, "parity" sampling (no reference counterpart beyond the single tree it
+ * reproduces, replay_buffer.py:172-205): the G = 2^k shard trees are the subtrees of ONE sum tree.
+ *   asac_sumtree_plan_top       the k top levels: parents = left + right (f32) over the G shard roots; every sample of the
+ *                               GLOBAL batch draws v = lo + (hi - lo) u over the global root and walks them with the
+ *                               reference's comparisons -> owner_out i32[batch] (the shard that holds the sample),
+ *                               value_out f64[batch] (the residual value its tree continues with), total_out f32[1]
+ *   asac_sumtree_descend_owned  asac_sumtree_descend for the samples with owner[i] == rank; the others get leaf -1,
+ *                               priority 0, id -1 (so that a SUM all-reduce of p_out over the ranks is the batch's
+ *                               priorities, and update / scatter launches on ids_out skip them as stale)
+ *   asac_per_is_weights_slice   IS weights of rows [first, first + count) of the global batch: minimum over all n_all
+ *                               priorities, beta advanced first (352-354)
+ * Everything stays on the device: with the roots all-gathered and the windows exchanged by fixed-size collectives the
+ * sharded step has no host synchronisation and is captured like the plain one. */
+int asac_sumtree_plan_top(const float* shard_roots, int n_shards, int batch, const double* u, int32_t* owner_out,
+                          double* value_out, float* total_out, void* stream);
+int asac_sumtree_descend_owned(const float* tree, int capacity, int n, const double* values, const int32_t* owner,
+                               int rank, const int64_t* slot_ids, int32_t* leaf_out, float* p_out, int64_t* ids_out,
+                               void* stream);
+int asac_per_is_weights_slice(const float* p_all, int n_all, int first, int count, const float* total, double* beta_state,
+                              double beta_increment, float* is_weights_out, void* stream);
 
 /* K2 stand-alone: w_i = ((p_i/total)/(min_ratio))^-beta, beta_state advanced first.
  * total / min_ratio are device scalars so a cross-rank all-reduce can produce them without a

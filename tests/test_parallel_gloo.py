@@ -38,6 +38,11 @@ def _worker(rank, world, port, out_dir):
     ctx.broadcast_(w)
     assert torch.all(w == 7)
 
+    # (2b) whether a step runs is decided by all ranks together (a step holds collectives: a rank with a short shard
+    # must not return early while the others wait inside an all-reduce)
+    assert ctx.all_ready(rank == 0, size=10 + rank) == (False, 21)
+    assert ctx.all_ready(True, size=3) == (True, 6)
+
     # (3) sharded replay: episodes round-robin over shards; IS weights normalised by the GLOBAL min ratio
     rng = np.random.default_rng(0)                 # same stream on both ranks
     shard = PrioritizedReplayRef(batch_size=8, capacity=64)
@@ -78,32 +83,46 @@ def test_data_parallel_context_world2(tmp_path):
 # ONE reference tree whose leaves are [shard 0 | shard 1]
 # ------------------------------------------------------------------------------------------------
 class _OracleShard:
-    """`ShardedParityReplay` backend over the NumPy oracle buffer"""
+    """`ShardedParityReplay` backend over the NumPy oracle buffer: the plan is the host statement
+    (`parallel.plan_global_sample`) of what the product's backend does with three launches"""
 
-    def __init__(self, rb):
-        self.rb = rb
+    def __init__(self, rb, beta=0.4, beta_increment=0.001):
+        self.rb, self.beta, self.beta_increment = rb, beta, beta_increment
 
-    def root(self):
-        return float(self.rb.tree.total)
+    def root_tensor(self):
+        return torch.tensor([self.rb.tree.total], dtype=torch.float32)
 
-    def descend(self, v):
-        leaf, p = self.rb.tree.descend(v)
-        ids = self.rb.storage.ids_at(leaf - (self.rb.capacity - 1))
-        return torch.from_numpy(np.asarray(p, np.float32)), torch.from_numpy(np.asarray(ids, np.int64))
+    def plan_and_descend(self, roots, u, rank):
+        from algorithm.parallel import plan_global_sample
+        owner, v, total = plan_global_sample(roots.numpy(), len(u), u.numpy())
+        mine = owner == rank
+        p, ids = np.zeros(len(u), np.float32), np.full(len(u), -1, np.int64)
+        leaf, p[mine] = self.rb.tree.descend(v[mine])
+        ids[mine] = self.rb.storage.ids_at(leaf - (self.rb.capacity - 1))
+        return (torch.from_numpy(owner.astype(np.int64)), torch.from_numpy(p), torch.from_numpy(ids),
+                torch.tensor([total], dtype=torch.float32))
+
+    def is_weights(self, p_all, total, first, count):
+        self.beta = min(1., self.beta + self.beta_increment)
+        ratio = p_all.numpy() / np.float32(total.item())
+        w = np.power(ratio / np.min(ratio), -np.float64(self.beta)).astype(np.float32)
+        return torch.from_numpy(w[first:first + count])
 
     def windows(self, ids):
-        ids = ids.numpy()
+        ids = np.where(ids.numpy() < 0, 0, ids.numpy())          # (rows of other shards' samples: anything)
         off = np.arange(-self.rb.prev_n, self.rb.post_n + 1)
         rows = self.rb.storage.rows_at((ids[:, None] + off[None, :]).reshape(-1))
         L = len(off)
         return {k: torch.from_numpy(v.reshape(len(ids), L, *v.shape[1:])) for k, v in rows.items()}
 
     def update(self, ids, td):
-        if len(ids):
-            self.rb.update(ids.numpy(), td.numpy())
+        mine = ids.numpy() >= 0
+        if mine.any():
+            self.rb.update(ids.numpy()[mine], td.numpy()[mine])
 
     def update_windows(self, ids, first_off, count, mask, key, rows):
-        ids, mask, rows = ids.numpy(), mask.numpy(), rows.numpy()
+        mine = ids.numpy() >= 0
+        ids, mask, rows = ids.numpy()[mine], mask.numpy()[mine], rows.numpy()[mine]
         tgt = (ids[:, None] + first_off + np.arange(count)[None, :]).reshape(-1)
         keep = ~mask[:, :count].reshape(-1)
         self.rb.update_transitions(tgt[keep], key, rows[:, :count].reshape(len(tgt), *rows.shape[2:])[keep])
@@ -135,12 +154,15 @@ def _parity_worker(rank, world, port, out_dir):
     union.update(np.arange(world * Cs), np.concatenate([s.tree.tree[Cs - 1:] for s in shards]))
     for it in range(3):
         u = rng.random(B)
-        windows, w, gidx = sharded.sample(u)
+        windows, w, plan_owner = sharded.sample(torch.from_numpy(u))
+        gidx = np.arange(rank * (B // world), (rank + 1) * (B // world))
         leaf, p = union.sample(B, u)
         owner, slot = (leaf - (world * Cs - 1)) // Cs, (leaf - (world * Cs - 1)) % Cs
+        assert np.array_equal(plan_owner.numpy(), owner), 'every sample is owned by the shard that holds the union tree\'s leaf'
         ratio = p / union.total
         w_ref = np.power(ratio / np.min(ratio), -np.float64(0.4 + 0.001 * (it + 1))).astype(np.float32)
         assert np.array_equal(w.numpy(), w_ref[gidx]), 'IS weights of the global batch (bit-exact)'
+        assert len(windows['x']) == B // world
         for j, i in enumerate(gidx):                # my rows are the owner's windows around the union tree's leaf
             src = shards[owner[i]]
             sid = src.storage.ids_at(np.array([slot[i]]))[0]
@@ -152,7 +174,7 @@ def _parity_worker(rank, world, port, out_dir):
         before = mine.tree.tree.copy()
         sharded.update(td)
         new_mu = torch.full((len(gidx), 3, 2), float(100 + it)) + torch.from_numpy(gidx.astype(np.float32))[:, None, None]
-        mask = torch.zeros((len(gidx), 4), dtype=torch.bool)
+        mask = torch.zeros((len(gidx), 3), dtype=torch.bool)
         sharded.update_windows(-1, 3, mask, 'mu_prob', new_mu)
         # every rank replays ALL updates on its copy of the shards it does not own... through the union oracle instead:
         td_full = torch.zeros(B)

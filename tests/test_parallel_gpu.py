@@ -45,6 +45,65 @@ def test_sumtree_descend_matches_oracle(C, n):
     assert np.array_equal(ids.cpu().numpy(), (leaf_ref - (C - 1)) * 3 + 1)
 
 
+@pytest.mark.parametrize('G', [1, 2, 4, 8])
+def test_sharded_plan_kernels_equal_single_tree(G):
+    """asac_sumtree_plan_top + asac_sumtree_descend_owned + asac_per_is_weights_slice, run once per shard the way G ranks
+    would, against ONE reference tree over the union of the shards: owners, leaves, priorities bit-exact; the IS weights
+    of every rank's slice equal the single buffer's (replay_buffer.py:185-205, 352-354) bit for bit; and against the
+    host statement of the plan (`parallel.plan_global_sample`)."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm.parallel import plan_global_sample
+    native.load()
+    rng = np.random.default_rng(17 + G)
+    Cs, B = 1024, 96 * G if G < 8 else 1024
+    leaves = (rng.random(G * Cs) * (rng.random(G * Cs) < 0.7)).astype(np.float32)
+    union = SumTreeRef(G * Cs)
+    union.update(np.arange(G * Cs), leaves)
+    shards = []
+    for g in range(G):
+        t = SumTreeRef(Cs)
+        t.update(np.arange(Cs), leaves[g * Cs:(g + 1) * Cs])
+        shards.append(t)
+    u = rng.random(B)
+    u[0], u[-1] = 0.0, np.nextafter(1.0, 0.0)
+    leaf_ref, p_ref = union.sample(B, u)
+    owner_ref, v_ref, total_ref = plan_global_sample(np.array([t.total for t in shards], np.float32), B, u)
+    f = dict(device='cuda')
+    roots = torch.tensor([t.total for t in shards], dtype=torch.float32, **f)
+    u_d = torch.from_numpy(u).cuda()
+    p_sum = torch.zeros(B, **f)
+    per = B // G
+    for g in range(G):
+        owner, v, total = torch.zeros(B, dtype=torch.int32, **f), torch.zeros(B, dtype=torch.float64, **f), torch.zeros(1, **f)
+        native.sumtree_plan_top(roots, B, u_d, owner, v, total)
+        assert np.array_equal(owner.cpu().numpy(), owner_ref) and float(total) == float(total_ref) == float(union.total)
+        assert np.array_equal(v.cpu().numpy(), v_ref), 'residual values (f64, bit-exact)'
+        assert np.array_equal(owner.cpu().numpy(), (leaf_ref - (G * Cs - 1)) // Cs)
+        tree = torch.from_numpy(shards[g].tree).cuda()
+        slot_ids = (torch.arange(Cs, dtype=torch.int64) * 5 + 2).cuda()
+        leaf, p, ids = torch.zeros(B, dtype=torch.int32, **f), torch.zeros(B, **f), torch.zeros(B, dtype=torch.int64, **f)
+        native.sumtree_descend_owned(tree, Cs, v, owner, g, slot_ids, leaf, p, ids)
+        mine = owner_ref == g
+        leaf, p, ids = leaf.cpu().numpy(), p.cpu().numpy(), ids.cpu().numpy()
+        assert np.array_equal(leaf[mine] - (Cs - 1) + g * Cs, leaf_ref[mine] - (G * Cs - 1))
+        assert np.array_equal(p[mine].view(np.uint32), p_ref[mine].view(np.uint32))
+        assert np.array_equal(ids[mine], (leaf[mine] - (Cs - 1)) * 5 + 2)
+        assert (leaf[~mine] == -1).all() and (p[~mine] == 0).all() and (ids[~mine] == -1).all()
+        p_sum += torch.from_numpy(p).cuda()
+    assert np.array_equal(p_sum.cpu().numpy().view(np.uint32), p_ref.view(np.uint32)), 'the all-reduce\'s sum'
+    ratio = p_ref / union.total
+    w_ref = np.power(ratio / np.min(ratio), -np.float64(0.401)).astype(np.float32)
+    total_d = torch.tensor([float(union.total)], **f)
+    for g in range(G):
+        beta = torch.tensor([0.4], dtype=torch.float64, **f)
+        w = torch.zeros(per, **f)
+        native.per_is_weights_slice(p_sum, g * per, per, total_d, beta, 0.001, w)
+        assert float(beta) == 0.401
+        ok = np.isfinite(w_ref[g * per:(g + 1) * per])
+        np.testing.assert_allclose(w.cpu().numpy()[ok], w_ref[g * per:(g + 1) * per][ok], rtol=2e-6)
+
+
 def _agent(dist_ctx=None, sampling='throughput', device='cuda:0', graph=False, seed=3):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
@@ -56,9 +115,10 @@ def _agent(dist_ctx=None, sampling='throughput', device='cuda:0', graph=False, s
 
 
 def test_parity_sampling_single_rank_equals_plain_sampler():
-    """world size 1: the sharded protocol (top-level walk on the host, asac_sumtree_descend, exchange plan, windows by
-    gather_windows, write-backs through the plan) must be the plain step — same ids drawn, same weights, same batch,
-    same priorities / mu-probabilities / hidden states written back, same weights after the steps."""
+    """world size 1: the sharded protocol (asac_sumtree_plan_top, asac_sumtree_descend_owned, asac_per_is_weights_slice,
+    windows by gather_windows, write-backs through the plan — all on the device) must be the plain step — same ids
+    drawn, same weights, same batch, same priorities / mu-probabilities / hidden states written back, same weights
+    after the steps."""
     import torch.distributed as dist
     from algorithm.fused import RecordedNoise
     from algorithm.parallel import DataParallelContext
@@ -98,11 +158,14 @@ def test_parity_sampling_single_rank_equals_plain_sampler():
 @pytest.mark.parametrize('plugin,kw', [('nn_vec', dict(n_step=4, burn_in_step=0)),
                                        ('nn_rnn', dict(n_step=3, burn_in_step=2, seq_encoder='RNN'))])
 @pytest.mark.parametrize('graph', [False, True])
-def test_throughput_mode_single_rank_equals_plain_step(plugin, kw, graph):
+@pytest.mark.parametrize('sampling', ['throughput', 'parity'])
+def test_data_parallel_single_rank_equals_plain_step(plugin, kw, graph, sampling):
     """world size 1 with the collectives forced on (`always=True`: every RCCL call of the data-parallel step is
-    issued, each an identity): the data-parallel step — sampler with deferred IS weights + MIN all-reduce, gradient
-    all-reduces in front of every Adam, the temperature step on the rank-averaged log-probabilities — must leave
-    bit-identical weights, priorities and write-backs to the plain step's, eagerly and as a captured graph."""
+    issued, each an identity): the data-parallel step — throughput mode: sampler with deferred IS weights + MIN
+    all-reduce; parity mode: roots all-gather, plan / owned descent / weight-slice launches, priority all-reduce,
+    one all-to-all per key, all-gathers for the write-backs; both: gradient all-reduces in front of every Adam, the
+    temperature step on the rank-averaged log-probabilities — must leave bit-identical weights, priorities and
+    write-backs to the plain step's, eagerly AND as a captured graph (no host synchronisation in either mode)."""
     import torch.distributed as dist
     import asac_amd  # noqa: F401
     from algorithm.parallel import DataParallelContext
@@ -120,9 +183,10 @@ def test_throughput_mode_single_rank_equals_plain_step(plugin, kw, graph):
             torch.manual_seed(5)
             return SAC_Base(['vector'], [(6,)], [], 2, None, pu.plugin(plugin), device='cuda:0', batch_size=32, seed=11,
                             replay_config={'capacity': 512},
-                            hip_config={'use_graph': graph, 'graph_warmup': 2, 'dist': ctx}, **kw)
+                            hip_config={'use_graph': graph, 'graph_warmup': 2, 'dist': ctx, 'dist_sampling': sampling}, **kw)
         plain, dp = make(None), make(DataParallelContext(always=True))
-        assert dp.replay_buffer.min_ratio_reducer is not None
+        assert (dp.replay_buffer.min_ratio_reducer is not None) == (sampling == 'throughput')
+        assert (dp.replay_buffer.sharded is not None) == (sampling == 'parity')
         dp._params.flat.copy_(plain._params.flat)
         dp._target_params.flat.copy_(plain._target_params.flat)
         rng = np.random.default_rng(0)
@@ -134,8 +198,13 @@ def test_throughput_mode_single_rank_equals_plain_step(plugin, kw, graph):
             plain.train()
             dp.train()
             a, b = plain.replay_buffer, dp.replay_buffer
-            assert torch.equal(a._ids, b._ids), f'step {step}: ids'
+            if sampling == 'throughput':       # (parity mode: the ids live in the owners' exchange plan)
+                assert torch.equal(a._ids, b._ids), f'step {step}: ids'
+            else:
+                assert torch.equal(a._ids, b.sharded._plan[1]), f'step {step}: ids'
             assert torch.equal(a._w, b._w), f'step {step}: IS weights'
+            for k in a._batch:
+                assert torch.equal(a._batch[k], b._batch[k]), f'step {step}: window {k}'
             assert float(a._beta) == float(b._beta)
             assert torch.equal(a._tree, b._tree), f'step {step}: priorities written back'
             assert torch.equal(a._columns['mu_prob'], b._columns['mu_prob'])

@@ -14,7 +14,7 @@ from tests.plugins import nn_vec  # noqa: E402
 LR = 3e-4
 
 
-def make_agent(case, use_graph=False):
+def make_agent(case, use_graph=False, hip=None):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
     from algorithm.utils.enums import convert_config_to_enum
@@ -23,7 +23,7 @@ def make_agent(case, use_graph=False):
     convert_config_to_enum(kw)
     return SAC_Base(io['obs_names'], io['obs_shapes'], list(d_sizes), io['c_action_size'], None, pu.plugin(plugin_name),
                     device='cuda:0', batch_size=io['batch_size'], replay_config={'capacity': io['capacity']},
-                    hip_config={'use_graph': use_graph}, **kw)
+                    hip_config={'use_graph': use_graph, **(hip or {})}, **kw)
 
 
 # Tolerances (fp32; device GEMM / MFMA accumulation order and device libm against the host):
@@ -73,14 +73,14 @@ def tol(case, observable):
     return TOL_CASE.get((case, observable), TOL[observable])
 
 
-def run_golden_case(golden_dir, case, align: bool, tag: str):
+def run_golden_case(golden_dir, case, align: bool, tag: str, hip=None):
     """One pass over the recorded steps of `case`.  `align`: trained-representation cases compare the freshly updated
     representation / critic weights with the reference's and then continue from the reference's (see above);
     `align=False` runs the product end to end on its own weights (drift report)."""
     from algorithm.fused import RecordedNoise
     g = np.load(golden_dir / f'f6_step_{case}.npz')
     io = pu.STEP_CASES[case][3]
-    agent = make_agent(case)
+    agent = make_agent(case, hip=hip)
     mods = pu.load_golden_weights(agent, g)
     for ep in pu.golden_episodes(g, len(io['obs_shapes'])):
         agent.put_episode(**ep)
@@ -91,8 +91,8 @@ def run_golden_case(golden_dir, case, align: bool, tag: str):
     K = f'{tag}/{case}'
 
     def chk(observable, got, want, later=False):
-        rt, at = tol(case, observable) if tag == 'step' else DRIFT_TOL.get((case, observable), DRIFT_TOL.get(observable, tol(case, observable)))
-        if later and ill and tag == 'step':
+        rt, at = tol(case, observable) if tag != 'drift' else DRIFT_TOL.get((case, observable), DRIFT_TOL.get(observable, tol(case, observable)))
+        if later and ill and tag != 'drift':
             rt = max(rt, TOL_LATER_STEPS_ILL)
         pu.check(f'{K}/{observable}', got, want, rt, at)
 
@@ -190,6 +190,24 @@ def test_full_step_unaligned_drift(golden_dir, case):
     if ids_equal:
         pu.assert_weights_close(mods, g, n_steps, LR, rtol=5e-3, atol=2e-4, small_frac=0.05, log_key=f'drift/{case}/weights')
     agent.replay_buffer.check_health()
+    agent.close()
+
+
+# `hip_config` switches that choose between a one-launch form and the launch chain it replaces (the chains stay: other
+# shapes take them).  Each switch, turned off, runs the recorded reference steps of a stock-network case and of a
+# trained-representation case under the same bounds — the chain forms are compared against the reference, not only
+# against the fused forms ("cover each surviving switch with one step-parity run").
+SWITCHES = ('sidecars', 'fused_policy_step', 'fused_forward_chain', 'fused_td_chain', 'fused_td_update', 'fused_q_return',
+            'fused_q_state_grads', 'twin_rep', 'fused_linear_tanh')
+
+
+@pytest.mark.parametrize('switch', SWITCHES)
+@pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'conv'])
+def test_step_parity_with_each_switch_off(golden_dir, case, switch):
+    agent, g, mods, n_steps, _, _ = run_golden_case(golden_dir, case, align=True, tag=f'switch_off/{switch}', hip={switch: False})
+    pu.assert_weights_close(mods, g, n_steps, LR, *tol(case, 'weights'), log_key=f'switch_off/{switch}/{case}/weights')
+    agent.replay_buffer.check_health()
+    assert agent.replay_buffer.check_tree_invariant() == 0
     agent.close()
 
 
