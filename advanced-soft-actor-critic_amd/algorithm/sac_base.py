@@ -2043,7 +2043,12 @@ class SAC_Base(AuxHeadsMixin):
 
     def close(self):
         self._closed = True
-        self._graph = None
+        # captured graphs go first (they hold the collectives' kernels of a data-parallel step: a process group must
+        # not be torn down under them)
+        self._graph = self._graph_exec = None
+        self._graph_runs.clear()
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize(self.device)
         if hasattr(self, 'replay_buffer'):
             self.replay_buffer.close()
 

@@ -75,6 +75,14 @@ CONFIGS = {
                  desc='cfg5: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, use_prediction '
                       '(transition / reward / observation models), b=5 n=3, PER capacity 65536'),
 }
+# ... and the same without the prediction heads (the round-1 / round-2 workload of this name: their decoder and losses are
+# the plugin's own PyTorch modules — MIOpen transposed convolutions and ~300 elementwise launches per step — and
+# dominate the step; kept beside `cfg5` so that the representation / attention / curiosity path can be followed
+# across rounds)
+CONFIGS['cfg5_without_prediction'] = dict(
+    CONFIGS['cfg5'], use_prediction=False,
+    desc='cfg5 without use_prediction: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, '
+         'PER capacity 65536')
 CFG = dict(CONFIGS['cfg2'])
 
 
@@ -270,7 +278,7 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg3', 'cfg4', 'cfg5'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg3', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess

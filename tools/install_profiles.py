@@ -5,7 +5,7 @@ import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r02'
+R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r03'
 
 for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
     shutil.copy(R / f'{c}_bench.json', P / f'{TAG}_{c}_bench.json')
