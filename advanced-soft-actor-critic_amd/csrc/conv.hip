@@ -198,28 +198,18 @@ __device__ __forceinline__ f32x4 conv1_tile(const float* base, const int* ktq, c
     const int4* kt = reinterpret_cast<const int4*>(ktq) + lk;
     const float4* wt = reinterpret_cast<const float4*>(w1q) + lane;
     if (q0 >= q1) return acc0;
-    // two LDS round trips feed a quad: its offsets (ktq), then the patch elements they point at.  Both run one quad
-    // AHEAD of the MFMAs: quad q's four MFMAs are issued on operands that were requested while quad q - 1 computed, the
-    // offsets of quad q + 2 and the elements of quad q + 1 travel under them (the elements used to be requested at the
-    // top of their own iteration: every quad waited one LDS latency in front of its MFMAs)
     int4 ko = kt[q0 * 4];
     float4 w = wt[q0 * 64];
-    float a0 = base[ko.x], a1v = base[ko.y], a2 = base[ko.z], a3 = base[ko.w];
-    ko = kt[min(q0 + 1, q1 - 1) * 4];
     for (int q = q0; q < q1; ++q) {
-        const float c0 = a0, c1 = a1v, c2 = a2, c3 = a3;
+        const float a0 = base[ko.x], a1v = base[ko.y], a2 = base[ko.z], a3 = base[ko.w];
         const float4 wc = w;
-        const int qn = min(q + 1, q1 - 1), qnn = min(q + 2, q1 - 1);
-        a0 = base[ko.x], a1v = base[ko.y], a2 = base[ko.z], a3 = base[ko.w];     // quad q + 1's elements
+        const int qn = min(q + 1, q1 - 1);         // the next quad's constants travel under this quad's MFMAs
+        ko = kt[qn * 4];
         w = wt[qn * 64];
-        ko = kt[qnn * 4];                                                         // quad q + 2's offsets
-        __builtin_amdgcn_sched_barrier(0);     // (left alone the scheduler sinks every read to its use: no read in flight
-        //                                         under an MFMA, four LDS latencies per quad)
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0, wc.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1, wc.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c2, wc.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c3, wc.w, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, wc.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, wc.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, wc.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, wc.w, acc1, 0, 0, 0);
     }
     return acc0 + acc1;
 }
@@ -321,15 +311,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         e_out[q] = oc < d.O2 ? oc * d.M2 + (row - e_im[q] * d.M2) : -1;
     }
     float b1s = b1v;
-    int ko2[S2H];                                // layer 2: patch offsets of this lane's reduction indices (invariant)
-#pragma unroll
-    for (int s = 0; s < S2H; ++s) ko2[s] = koff2[4 * (kh * S2H + s) + lk];
     const int qa = (Q1 * wave) / 4, qb = (Q1 * (wave + 1)) / 4;    // this wave's share of a split tail tile
 #pragma unroll
     for (int s = 0; s < S2H; ++s) settle(w2r[s]);
     settle(e_bias[0]); settle(e_bias[1]); settle(b1e); settle(b1s);
-#pragma unroll
-    for (int s = 0; s < S2H; ++s) settle(ko2[s]);
 
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
@@ -383,10 +368,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             float av[S2H];
 #pragma unroll
-            for (int s = 0; s < S2H; ++s) av[s] = base[ko2[s]];
-            // every operand read in flight before the first MFMA (the offsets are loop-invariant registers: with the
-            // table read inside the loop each of eight chunks waited for two dependent LDS round trips)
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < S2H; ++s) av[s] = base[koff2[4 * (kh * S2H + s) + lk]];
 #pragma unroll
             for (int s = 0; s < S2H; s += 2) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w2r[s], acc0, 0, 0, 0);
