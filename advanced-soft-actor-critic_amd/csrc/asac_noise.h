@@ -49,8 +49,10 @@ __device__ __forceinline__ double prologue_uniform(uint64_t seed, uint64_t s, in
     const int64_t i = (n_normal + 3) / 4 + (t >> 1);
     const Philox x = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)s, (uint32_t)(s >> 32),
                                    (uint32_t)seed, (uint32_t)(seed >> 32));
-    const int h = (int)(t & 1);
-    const uint64_t bits = ((uint64_t)x.c[2 * h] << 32) | x.c[2 * h + 1];
+    // (selects, not x.c[2 * h]: a run-time index sends the four words through scratch memory — a store / load round trip
+    // in front of the sampler's descent, the first thing the step's first launch does)
+    const bool h = (t & 1) != 0;
+    const uint64_t bits = ((uint64_t)(h ? x.c[2] : x.c[0]) << 32) | (h ? x.c[3] : x.c[1]);
     return (double)(bits >> 11) * 1.1102230246251565e-16;   // 2^-53: [0, 1)
 }
 

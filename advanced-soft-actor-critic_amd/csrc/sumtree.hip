@@ -55,7 +55,7 @@ struct SampleDraw {
     int64_t n_normal;
 };
 
-template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false, bool EXPLICIT = false>
+template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false, bool EXPLICIT = false, int TRIPS = kFusedSampleMax / kSampleBlock>
 __device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
     double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
@@ -73,17 +73,26 @@ __device__ __forceinline__ void sumtree_sample_body(
     }
 
     const float root = STAGE_TOP ? top[0] : tree[0];
-    // the fused single-workgroup form strides over the batch (up to kFusedSampleMax samples), the
-    // multi-workgroup form handles one sample per lane
+    // the fused single-workgroup form strides over the batch (up to kFusedSampleMax samples: TRIPS samples per lane), the
+    // multi-workgroup form handles one sample per lane.  A lane's samples descend IN LOCKSTEP, level by level: their
+    // chains of dependent reads are independent of each other, so the loads of all of them travel together and a batch
+    // of 512 / 1024 costs the round trips of a batch of 256 (walked one after the other, each sample's `s_waitcnt` also
+    // drained its neighbours' loads).  Per sample the comparisons and their order are unchanged.
     const int first = blockIdx.x * kSampleBlock + threadIdx.x;
-    constexpr int kTrips = FUSE_WEIGHTS ? kFusedSampleMax / kSampleBlock : 1;
+    constexpr int kTrips = FUSE_WEIGHTS ? TRIPS : 1;
     float pmin = INFINITY;
     float p_reg[kTrips];
+    double v_[kTrips];
+    int node_[kTrips];
+    bool live_[kTrips];
 #pragma unroll
     for (int trip = 0; trip < kTrips; ++trip) {
         const int i = first + trip * kSampleBlock;
-        p_reg[trip] = 0.f;
-        if (i >= batch) continue;
+        p_reg[trip] = root;
+        node_[trip] = 0;
+        v_[trip] = 0.0;
+        live_[trip] = i < batch;
+        if (!live_[trip]) continue;
         const float seg = root / (float)batch;                 // np.float32(root / B)
         const double lo = (double)i * (double)seg;             // int64 * float32 -> float64
         const double hi = (double)(i + 1) * (double)seg;
@@ -94,55 +103,82 @@ __device__ __forceinline__ void sumtree_sample_body(
         } else {
             ui = u[i];
         }
-        double v = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
-        if (EXPLICIT) v = u[i];                                // the caller's own values (asac_sumtree_descend)
+        v_[trip] = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
+        if (EXPLICIT) v_[trip] = u[i];                         // the caller's own values (asac_sumtree_descend)
         if (EXPLICIT && owner && owner[i] != rank) {           // another shard's sample: nothing of it lives here
             leaf_out[i] = -1, p_out[i] = 0.f, ids_out[i] = -1;
+            live_[trip] = false;
+        }
+    }
+    // one level of the reference's descent: left/right sums a, b of the current node's children
+    auto step = [&](int t, float a, float b) -> int {
+        const bool go_left = (v_[t] <= (double)a) || (b == 0.0f);
+        if (!go_left) v_[t] -= (double)a;
+        p_reg[t] = go_left ? a : b;
+        return go_left ? 0 : 1;
+    };
+    int l = 0;
+    // levels held in LDS (whole levels are staged: the test is the same for every node of a level)
+    for (; l < levels; ++l) {
+        if (!(STAGE_TOP && (4 << l) - 2 < n_lds)) break;      // the largest right child of level l is 2^(l+2) - 2
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int left = 2 * node_[t] + 1;
+            node_[t] = left + step(t, top[left], top[left + 1]);
+        }
+    }
+    // levels in memory, three per round trip: in the array heap the children (2), grandchildren (4) and
+    // great-grandchildren (8) of a node are each contiguous, so all 14 loads are issued together and the
+    // three decisions run on registers — same comparisons, a third of the dependent latencies
+    for (; l + 3 <= levels; l += 3) {
+        // (named vector registers, not arrays: a select chain over an array element is turned back into an indexed load
+        // of a scratch copy)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v2f a1[kTrips];
+        v4f a2[kTrips], a3l[kTrips], a3h[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int64_t node = live_[t] ? node_[t] : 0;      // (a lane without a sample re-reads the top: in range)
+            const float* c1 = tree + 2 * node + 1;
+            const float* c2 = tree + 4 * node + 3;
+            const float* c3 = tree + 8 * node + 7;
+            a1[t] = v2f{c1[0], c1[1]};
+            a2[t] = v4f{c2[0], c2[1], c2[2], c2[3]};
+            a3l[t] = v4f{c3[0], c3[1], c3[2], c3[3]};
+            a3h[t] = v4f{c3[4], c3[5], c3[6], c3[7]};
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int i1 = step(t, a1[t].x, a1[t].y);
+            const int i2 = 2 * i1 + step(t, i1 ? a2[t].z : a2[t].x, i1 ? a2[t].w : a2[t].y);
+            const v4f q4 = (i2 & 2) ? a3h[t] : a3l[t];
+            const float l3 = (i2 & 1) ? q4.z : q4.x;
+            const float r3 = (i2 & 1) ? q4.w : q4.y;
+            node_[t] = 8 * node_[t] + 7 + 2 * i2 + step(t, l3, r3);
+        }
+    }
+    for (; l < levels; ++l) {
+        float ab[kTrips][2];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int left = live_[t] ? 2 * node_[t] + 1 : 1;
+            ab[t][0] = tree[left], ab[t][1] = tree[left + 1];
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) node_[t] = 2 * node_[t] + 1 + step(t, ab[t][0], ab[t][1]);
+    }
+#pragma unroll
+    for (int trip = 0; trip < kTrips; ++trip) {
+        const int i = first + trip * kSampleBlock;
+        if (!live_[trip]) {
+            p_reg[trip] = 0.f;
             continue;
         }
-        int node = 0, l = 0;
-        float p = root;
-        // one level of the reference's descent: left/right sums a, b of the current node's children
-        auto step = [&](float a, float b) -> int {
-            const bool go_left = (v <= (double)a) || (b == 0.0f);
-            if (!go_left) v -= (double)a;
-            p = go_left ? a : b;
-            return go_left ? 0 : 1;
-        };
-        // levels held in LDS
-        for (; l < levels; ++l) {
-            const int left = 2 * node + 1;
-            if (!(STAGE_TOP && left + 1 < n_lds)) break;
-            node = left + step(top[left], top[left + 1]);
-        }
-        // levels in memory, three per round trip: in the array heap the children (2), grandchildren (4) and
-        // great-grandchildren (8) of a node are each contiguous, so all 14 loads are issued together and the
-        // three decisions run on registers — same comparisons, a third of the dependent latencies
-        for (; l + 3 <= levels; l += 3) {
-            const float* c1 = tree + 2 * (int64_t)node + 1;
-            const float* c2 = tree + 4 * (int64_t)node + 3;
-            const float* c3 = tree + 8 * (int64_t)node + 7;
-            float a1[2], a2[4], a3[8];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) a1[q] = c1[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a2[q] = c2[q];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a3[q] = c3[q];
-            const int i1 = step(a1[0], a1[1]);
-            const int i2 = 2 * i1 + step(i1 ? a2[2] : a2[0], i1 ? a2[3] : a2[1]);
-            const float l3 = (i2 & 2) ? ((i2 & 1) ? a3[6] : a3[4]) : ((i2 & 1) ? a3[2] : a3[0]);
-            const float r3 = (i2 & 2) ? ((i2 & 1) ? a3[7] : a3[5]) : ((i2 & 1) ? a3[3] : a3[1]);
-            node = 8 * node + 7 + 2 * i2 + step(l3, r3);
-        }
-        for (; l < levels; ++l) {
-            const int left = 2 * node + 1;
-            node = left + step(tree[left], tree[left + 1]);
-        }
-        if (levels == 0) p = tree[0];
-        leaf_out[i] = node;
+        const float p = levels == 0 ? tree[0] : p_reg[trip];
+        leaf_out[i] = node_[trip];
         p_out[i] = p;
-        ids_out[i] = slot_ids[node - (capacity - 1)];
+        ids_out[i] = slot_ids[node_[trip] - (capacity - 1)];
         pmin = fminf(pmin, p);
         p_reg[trip] = p;
     }
@@ -202,12 +238,21 @@ __global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
     const PrologueArgs pa, const float* __restrict__ tree, int capacity, int levels, int batch,
     const int64_t* __restrict__ slot_ids, double* beta_state, double beta_increment, int32_t* __restrict__ leaf_out,
     float* __restrict__ p_out, int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out) {
-    if (blockIdx.x == 0)
-        sumtree_sample_body<true, true, true>(tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment,
-                                              leaf_out, p_out, ids_out, w_out, min_p_out,
-                                              SampleDraw{pa.seed, pa.step, pa.n_normal});
-    else
+    if (blockIdx.x == 0) {
+        const SampleDraw dr{pa.seed, pa.step, pa.n_normal};
+        // (samples per lane: a compile-time count, so that the lockstep state stays in registers)
+        if (batch <= kSampleBlock)
+            sumtree_sample_body<true, true, true, false, 1>(tree, capacity, levels, batch, pa.u, slot_ids, beta_state,
+                                                            beta_increment, leaf_out, p_out, ids_out, w_out, min_p_out, dr);
+        else if (batch <= 2 * kSampleBlock)
+            sumtree_sample_body<true, true, true, false, 2>(tree, capacity, levels, batch, pa.u, slot_ids, beta_state,
+                                                            beta_increment, leaf_out, p_out, ids_out, w_out, min_p_out, dr);
+        else
+            sumtree_sample_body<true, true, true, false, 4>(tree, capacity, levels, batch, pa.u, slot_ids, beta_state,
+                                                            beta_increment, leaf_out, p_out, ids_out, w_out, min_p_out, dr);
+    } else {
         prologue_block(pa, (int)blockIdx.x - 1, true);
+    }
 }
 
 // the descent alone for explicit f64 values (sharded "parity" sampling: the residual values of the top-level walk)
