@@ -62,13 +62,45 @@ __device__ __forceinline__ void sumtree_sample_body(
     double beta_increment, int32_t* __restrict__ leaf_out, float* __restrict__ p_out,
     int64_t* __restrict__ ids_out, float* __restrict__ w_out, float* min_p_out, const SampleDraw draw = SampleDraw{},
     const int32_t* __restrict__ owner = nullptr, int rank = 0) {
-    __shared__ float top[kLdsNodes + 1];
+    __shared__ __attribute__((aligned(16))) float top[kLdsNodes + 1];
     __shared__ float red[kSampleBlock / kWave];
     __shared__ double s_beta;
+    constexpr int kTrips = FUSE_WEIGHTS ? TRIPS : 1;
+    const int first = blockIdx.x * kSampleBlock + threadIdx.x;
 
     const int n_lds = STAGE_TOP ? min(kLdsNodes, 2 * capacity - 1) : 0;
+    // the tree's top travels to LDS as four 16-byte loads per thread; the lane's uniforms (ten Philox rounds each) are
+    // drawn while they are in flight
+    const bool top_vec = STAGE_TOP && n_lds == kLdsNodes && 2 * capacity - 1 > kLdsNodes &&
+                         (reinterpret_cast<uintptr_t>(tree) & 15) == 0;
+    typedef float st4 __attribute__((ext_vector_type(4)));
+    constexpr int kStage = (kLdsNodes + 1) / 4 / kSampleBlock;
+    st4 st[kStage];
+#pragma unroll
+    for (int k = 0; k < kStage; ++k) {
+        st[k] = st4{0.f, 0.f, 0.f, 0.f};
+        if (top_vec) st[k] = reinterpret_cast<const st4*>(tree)[threadIdx.x + k * kSampleBlock];
+    }
+    double ui_[kTrips];
+#pragma unroll
+    for (int trip = 0; trip < kTrips; ++trip) {
+        const int i = first + trip * kSampleBlock;
+        ui_[trip] = 0.0;
+        if (i >= batch) continue;
+        if (DRAW) {
+            ui_[trip] = prologue_uniform(draw.seed, (uint64_t)*draw.step, draw.n_normal, i);
+            u[i] = ui_[trip];
+        } else {
+            ui_[trip] = u[i];
+        }
+    }
     if (STAGE_TOP) {
-        for (int i = threadIdx.x; i < n_lds; i += kSampleBlock) top[i] = tree[i];
+        if (top_vec) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) reinterpret_cast<st4*>(top)[threadIdx.x + k * kSampleBlock] = st[k];
+        } else {
+            for (int i = threadIdx.x; i < n_lds; i += kSampleBlock) top[i] = tree[i];
+        }
         __syncthreads();
     }
 
@@ -78,8 +110,6 @@ __device__ __forceinline__ void sumtree_sample_body(
     // chains of dependent reads are independent of each other, so the loads of all of them travel together and a batch
     // of 512 / 1024 costs the round trips of a batch of 256 (walked one after the other, each sample's `s_waitcnt` also
     // drained its neighbours' loads).  Per sample the comparisons and their order are unchanged.
-    const int first = blockIdx.x * kSampleBlock + threadIdx.x;
-    constexpr int kTrips = FUSE_WEIGHTS ? TRIPS : 1;
     float pmin = INFINITY;
     float p_reg[kTrips];
     double v_[kTrips];
@@ -96,15 +126,8 @@ __device__ __forceinline__ void sumtree_sample_body(
         const float seg = root / (float)batch;                 // np.float32(root / B)
         const double lo = (double)i * (double)seg;             // int64 * float32 -> float64
         const double hi = (double)(i + 1) * (double)seg;
-        double ui;
-        if (DRAW) {
-            ui = prologue_uniform(draw.seed, (uint64_t)*draw.step, draw.n_normal, i);
-            u[i] = ui;
-        } else {
-            ui = u[i];
-        }
-        v_[trip] = lo + (hi - lo) * ui;                        // np.random.uniform(lo, hi)
-        if (EXPLICIT) v_[trip] = u[i];                         // the caller's own values (asac_sumtree_descend)
+        v_[trip] = lo + (hi - lo) * ui_[trip];                 // np.random.uniform(lo, hi)
+        if (EXPLICIT) v_[trip] = ui_[trip];                    // the caller's own values (asac_sumtree_descend)
         if (EXPLICIT && owner && owner[i] != rank) {           // another shard's sample: nothing of it lives here
             leaf_out[i] = -1, p_out[i] = 0.f, ids_out[i] = -1;
             live_[trip] = false;
@@ -156,6 +179,26 @@ __device__ __forceinline__ void sumtree_sample_body(
             const float l3 = (i2 & 1) ? q4.z : q4.x;
             const float r3 = (i2 & 1) ? q4.w : q4.y;
             node_[t] = 8 * node_[t] + 7 + 2 * i2 + step(t, l3, r3);
+        }
+    }
+    // two levels left: children and grandchildren in one round trip
+    for (; l + 2 <= levels; l += 2) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v2f a1[kTrips];
+        v4f a2[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int64_t node = live_[t] ? node_[t] : 0;
+            const float* c1 = tree + 2 * node + 1;
+            const float* c2 = tree + 4 * node + 3;
+            a1[t] = v2f{c1[0], c1[1]};
+            a2[t] = v4f{c2[0], c2[1], c2[2], c2[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) {
+            const int i1 = step(t, a1[t].x, a1[t].y);
+            node_[t] = 4 * node_[t] + 3 + 2 * i1 + step(t, i1 ? a2[t].z : a2[t].x, i1 ? a2[t].w : a2[t].y);
         }
     }
     for (; l < levels; ++l) {
