@@ -64,7 +64,6 @@ __device__ __forceinline__ void sumtree_sample_body(
     const int32_t* __restrict__ owner = nullptr, int rank = 0) {
     __shared__ __attribute__((aligned(16))) float top[kLdsNodes + 1];
     __shared__ float red[kSampleBlock / kWave];
-    __shared__ double s_beta;
     constexpr int kTrips = FUSE_WEIGHTS ? TRIPS : 1;
     const int first = blockIdx.x * kSampleBlock + threadIdx.x;
 
@@ -81,6 +80,8 @@ __device__ __forceinline__ void sumtree_sample_body(
         st[k] = st4{0.f, 0.f, 0.f, 0.f};
         if (top_vec) st[k] = reinterpret_cast<const st4*>(tree)[threadIdx.x + k * kSampleBlock];
     }
+    // (requested at entry: read after the batch-minimum barrier it was a dependent round trip in front of the weights)
+    const double beta_old = (FUSE_WEIGHTS && w_out) ? *beta_state : 0.0;
     double ui_[kTrips];
 #pragma unroll
     for (int trip = 0; trip < kTrips; ++trip) {
@@ -211,9 +212,11 @@ __device__ __forceinline__ void sumtree_sample_body(
 #pragma unroll
         for (int t = 0; t < kTrips; ++t) node_[t] = 2 * node_[t] + 1 + step(t, ab[t][0], ab[t][1]);
     }
+    int64_t id_reg[kTrips];
 #pragma unroll
     for (int trip = 0; trip < kTrips; ++trip) {
         const int i = first + trip * kSampleBlock;
+        id_reg[trip] = -1;
         if (!live_[trip]) {
             p_reg[trip] = 0.f;
             continue;
@@ -221,8 +224,8 @@ __device__ __forceinline__ void sumtree_sample_body(
         const float p = levels == 0 ? tree[0] : p_reg[trip];
         leaf_out[i] = node_[trip];
         p_out[i] = p;
-        ids_out[i] = slot_ids[node_[trip] - (capacity - 1)];
-        pmin = fminf(pmin, p);
+        id_reg[trip] = slot_ids[node_[trip] - (capacity - 1)];     // (stored at the end: the lookup travels under the
+        pmin = fminf(pmin, p);                                     //  reduction and the weights)
         p_reg[trip] = p;
     }
 
@@ -240,9 +243,7 @@ __device__ __forceinline__ void sumtree_sample_body(
             min_p_out[0] = bm;
             min_p_out[1] = bm / root;
         } else if (FUSE_WEIGHTS) {
-            const double b = fmin(1.0, *beta_state + beta_increment);
-            *beta_state = b;
-            s_beta = b;
+            *beta_state = fmin(1.0, beta_old + beta_increment);
             *min_p_out = bm;
         } else if (w_out) {
             // two-pass weights: the weight buffer doubles as the per-workgroup minimum scratch until the weight
@@ -256,11 +257,17 @@ __device__ __forceinline__ void sumtree_sample_body(
     if (FUSE_WEIGHTS && w_out) {
         __syncthreads();
         const float min_ratio = red[0] / root;                 // min(p/total) == min(p)/total
+        const double b = fmin(1.0, beta_old + beta_increment);
 #pragma unroll
         for (int trip = 0; trip < kTrips; ++trip) {
             const int i = first + trip * kSampleBlock;
-            if (i < batch) w_out[i] = is_weight(p_reg[trip], root, min_ratio, s_beta);
+            if (i < batch) w_out[i] = is_weight(p_reg[trip], root, min_ratio, b);
         }
+    }
+#pragma unroll
+    for (int trip = 0; trip < kTrips; ++trip) {
+        const int i = first + trip * kSampleBlock;
+        if (live_[trip]) ids_out[i] = id_reg[trip];
     }
 }
 
