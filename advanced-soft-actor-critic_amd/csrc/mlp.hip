@@ -37,6 +37,11 @@ constexpr int kP = 66;           // LDS pitch (floats)
 constexpr int kMaxW = 64;        // max layer width / input width
 constexpr int kMaxB = ASAC_MLP_MAX_BLOCKS;
 constexpr int kHeadPad = 16;     // head output columns are padded to one MFMA tile
+// waves of k_policy_step (A/B builds: -DASAC_PS_WAVES=8): the compute phases have work for eight (critics: 2 members x 4
+// column tiles) resp. four waves; the others share the staging of the three networks and the weight-gradient tiles
+#ifndef ASAC_PS_WAVES
+#define ASAC_PS_WAVES 16
+#endif
 template <int TM> constexpr int threads_of() { return TM * 16; }    // one thread per (row, 4-column group)
 
 // 16-row tiles while they still fit one resident round of workgroups
@@ -833,7 +838,7 @@ __device__ __forceinline__ void grad_weight_tiles(const float* __restrict__ delt
         }
     }
 }
-template <int NW = 8>
+template <int NW = ASAC_PS_WAVES>
 __device__ __forceinline__ void ps_grad_weight(const float* __restrict__ delta, int jbase, const float* __restrict__ xprev,
                                                int J, int K, float* __restrict__ out, int first_wave = 0) {
     grad_weight_tiles(delta, jbase, xprev, J, K, out, ((threadIdx.x >> 6) + NW - first_wave) & (NW - 1), NW);
@@ -1208,7 +1213,9 @@ __global__ __launch_bounds__(W8 ? 64 * W8 : TM * 16) void k_mlp_bwd(const MlpArg
 // weights travel in registers meanwhile and take over the critics' LDS once they are done with it; in the policy
 // phase the 16 (heads: 8) independent weight-gradient tiles of a layer are dealt over all 8 waves.  Every MFMA
 // chain has the operand order of the three separate kernels: results are bit-identical to theirs.
-constexpr int kPsThreads = 512;
+constexpr int kPsWaves = ASAC_PS_WAVES;
+constexpr int kPsThreads = 64 * kPsWaves;
+constexpr int kPsSlots = 1024 / kPsThreads;         // of the 16 x 64 input tile per thread
 constexpr int kPsRows = 16;
 
 struct PsQLds {       // one critic: weights, scalar head, bias, two activation tiles (forward ping-pong; then delta)
@@ -1247,13 +1254,13 @@ struct PolicyStepArgs {
     float* ls_out;          // [N][2A] (loc | scale) or NULL
 };
 
-// a 16-row input tile with 512 threads: 2 of the 16 x 64 slots per thread
-__device__ __forceinline__ void ps_fetch_tile(const StageScalars& q, int64_t row0, float (&v)[2]) {
+// a 16-row input tile: kPsSlots of the 16 x 64 slots per thread
+__device__ __forceinline__ void ps_fetch_tile(const StageScalars& q, int64_t row0, float (&v)[kPsSlots]) {
     const int in0 = q.in0, in1 = q.in1;
     const rsrc_t r0 = make_rsrc(q.x0);
     const rsrc_t r1 = make_rsrc(q.x1, in1 > 0 ? 0x7fffffffu : 0u);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kPsSlots; ++u) {
         const int i = threadIdx.x + u * kPsThreads;
         const int r = i >> 6, c = i & 63;
         const uint32_t row = (uint32_t)row0 + (uint32_t)r;
@@ -1263,9 +1270,9 @@ __device__ __forceinline__ void ps_fetch_tile(const StageScalars& q, int64_t row
         v[u] = __builtin_bit_cast(float, buf_ld(r0, o0) | buf_ld(r1, o1));
     }
 }
-__device__ __forceinline__ void ps_put_tile(const float (&v)[2], float* xs) {
+__device__ __forceinline__ void ps_put_tile(const float (&v)[kPsSlots], float* xs) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < kPsSlots; ++u) {
         const int i = threadIdx.x + u * kPsThreads;
         xs[(i >> 6) * kP + (i & 63)] = v[u];
     }
@@ -1291,7 +1298,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     const int e0 = a.q.subset ? a.q.subset[0] : 0, e1 = a.q.subset ? a.q.subset[1] : 1;
     const StageScalars s0 = stage_scalars<3>(a.q, e0), s1 = stage_scalars<3>(a.q, e1), sp = stage_scalars<3>(a.pi, 0);
     const bool sample_here = a.q.x1 == nullptr;
-    float in_q[2] = {0.f, 0.f}, in_pi[2];
+    float in_q[kPsSlots] = {}, in_pi[kPsSlots];
     if (!sample_here) ps_fetch_tile(s0, row0, in_q);
     ps_fetch_tile(sp, row0, in_pi);
     StagedNet<kPsThreads> r0, r1, rp;
@@ -1377,11 +1384,13 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     MLP_STAMP(1);
 
     // ---- critics forward (derivatives of the activations stay in registers) ------------------------------------
-    PsQLds& Q = L.q[m];
+    const bool qwave = wave < 8;                 // (waves beyond the eight of the critic phase keep the barriers company)
+    PsQLds& Q = L.q[qwave ? m : 0];
     f32x4 z[3];
     int cur = 0;
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
+        if (qwave) {
         const float* xin = Q.xs[cur];
         float* xout = Q.xs[cur ^ 1];
         const f32x4 acc = l > 0 ? gemm_tile(xin, Q.w[l], kMaxW, 0, ct) : gemm_tile(xin, Q.w[l], round4(K0q), 0, ct);
@@ -1399,11 +1408,12 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
             if (res) y += xin[row * kP + col];
             xout[row * kP + col] = y;
         }
+        }
         __syncthreads();
         cur ^= 1;
     }
     MLP_STAMP(2);
-    if (ct == 0) {          // the scalar head: one wave per member
+    if (qwave && ct == 0) {          // the scalar head: one wave per member
         const f32x4 raw = gemm_tile(Q.xs[cur], Q.head, kMaxW, 0, 0);
         if ((lane & 15) == 0) {
 #pragma unroll
@@ -1419,7 +1429,7 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     MLP_STAMP(3);
     // d(mean_b -min_e q_e)/dq_m: -1/N on the rows where member m is the (first) arg-min (sac_base.py:1896-1903)
     float* qdelta = Q.xs[cur ^ 1];           // (the forward is done with both tiles; x_3 itself is not needed again)
-    {
+    if (qwave) {
         const int t = threadIdx.x & 255;     // the member's 256 threads clear its 16 x 16 delta tile
         const int r = t >> 4, c = t & 15;
         float g = 0.f;
@@ -1432,18 +1442,23 @@ __global__ __launch_bounds__(kPsThreads) void k_policy_step(const PolicyStepArgs
     __syncthreads();
     MLP_STAMP(4);
     // ---- critics backward to the action ---------------------------------------------------------------------------
-    f32x4 g = gemm_tile_nt(qdelta, Q.head, kHeadPad, 0, ct);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (qwave) g = gemm_tile_nt(qdelta, Q.head, kHeadPad, 0, ct);
 #pragma unroll
     for (int l = 2; l >= 0; --l) {
         __syncthreads();
+        if (qwave) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) qdelta[(4 * (lane >> 4) + r) * kP + col] = g[r] * z[l][r];
+            for (int r = 0; r < 4; ++r) qdelta[(4 * (lane >> 4) + r) * kP + col] = g[r] * z[l][r];
+        }
         __syncthreads();
-        f32x4 gin = gemm_tile_nt(qdelta, Q.w[l], kMaxW, 0, ct);
-        if (a.q.d.residual[l]) gin += g;
-        g = gin;
+        if (qwave) {
+            f32x4 gin = gemm_tile_nt(qdelta, Q.w[l], kMaxW, 0, ct);
+            if (a.q.d.residual[l]) gin += g;
+            g = gin;
+        }
     }
-    if (col >= S && col < K0q) {
+    if (qwave && col >= S && col < K0q) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) L.ga[m][(4 * (lane >> 4) + r) * kHeadPad + (col - S)] = g[r];
     }
