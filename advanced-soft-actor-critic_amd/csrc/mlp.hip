@@ -42,6 +42,11 @@ constexpr int kHeadPad = 16;     // head output columns are padded to one MFMA t
 #ifndef ASAC_PS_WAVES
 #define ASAC_PS_WAVES 16
 #endif
+// ... and of k_pi_sample_q's fused job (its plain forward jobs and sidecars run on four)
+#ifndef ASAC_PIQ_WAVES
+#define ASAC_PIQ_WAVES 8      // (sixteen: 120 VGPRs, no spills, and 0.9 % slower on cfg2 — A/B on one box, round 3)
+#endif
+constexpr int kPiQThreads = 64 * ASAC_PIQ_WAVES;
 template <int TM> constexpr int threads_of() { return TM * 16; }    // one thread per (row, 4-column group)
 
 // 16-row tiles while they still fit one resident round of workgroups
@@ -1706,8 +1711,8 @@ template <bool WINDOW>
 __device__ __forceinline__ void pi_q_tiles(const ASAC_KARG PiQLaunch& a, PiQLds& L) {
     // eight waves: the staging (loads and LDS writes of two networks and the input tile) is dealt over 512 threads —
     // 1.5 us instead of 2.5; the forward chains have four column tiles: waves 4..7 only keep the barriers company there
-    constexpr int THREADS = 512;
-    constexpr int SLOTS = 2;                 // of the 16 x 64 input tile per thread
+    constexpr int THREADS = kPiQThreads;
+    constexpr int SLOTS = 1024 / kPiQThreads;      // of the 16 x 64 input tile per thread
     const bool comp = (threadIdx.x >> 6) < 4;
     const int e = (int)blockIdx.x % a.E, group = (int)blockIdx.x / a.E;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1918,7 +1923,7 @@ static_assert(sizeof(PiQLaunch) <= 672, "kernel arguments of k_pi_sample_q (was 
 static_assert(sizeof(PiQLaunch) + sizeof(SidecarsDev) <= 4096, "kernel arguments of k_pi_sample_q");
 
 template <int NSC>
-__global__ __launch_bounds__(512) void k_pi_sample_q(const PiQLaunch m_by_value, const SidecarsT<NSC> sc) {
+__global__ __launch_bounds__(kPiQThreads) void k_pi_sample_q(const PiQLaunch m_by_value, const SidecarsT<NSC> sc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // (`m_by_value` sits at offset 0 of the kernarg segment; it is read through `m`, field by field, where used)
     const ASAC_KARG PiQLaunch& m = *static_cast<const ASAC_KARG PiQLaunch*>(kernarg_base());
@@ -2487,10 +2492,10 @@ int asac_policy_sample_q_forward(const asac_pi_q_job_t* job, const asac_mlp_job_
         const bool last = rep == g_launch_repeat - 1;
         const dim3 grid((unsigned)(m.blocks + blocks + (last ? sc.blocks : 0)));
         if (sc.n <= 1)
-            hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(512), sizeof(PiQLds), as_stream(stream), m,
+            hipLaunchKernelGGL(k_pi_sample_q<1>, grid, dim3(kPiQThreads), sizeof(PiQLds), as_stream(stream), m,
                                sidecars_first<1>(last ? sc : none));
         else
-            hipLaunchKernelGGL(k_pi_sample_q<ASAC_MAX_SIDECARS>, grid, dim3(512), sizeof(PiQLds), as_stream(stream), m,
+            hipLaunchKernelGGL(k_pi_sample_q<ASAC_MAX_SIDECARS>, grid, dim3(kPiQThreads), sizeof(PiQLds), as_stream(stream), m,
                                last ? sc : none);
     }
     return finish_launch("asac_policy_sample_q_forward");
