@@ -34,6 +34,21 @@ inline AdamScalars adam_scalars(float lr, float beta1, float beta2, float eps) {
     return c;
 }
 
+// The step's two bias corrections, lr / (1 - b1^t) and sqrt(1 - b2^t) with t = done + 1, in double precision and rounded
+// to float as torch's single-tensor Adam has them.  b^t by binary powering (t is an integer): <= 2 log2 t dependent
+// multiplies per base, the two bases interleaved — a library pow(double, double) is some 150 instructions each and was
+// the long pole of the one-workgroup temperature step (tools/td_phases.py: 2.55 -> 2.02 us, the same as no pow at
+// all).  The powering's rounding (<= log2 t ulp of double) disappears in the cast to float.
+__device__ __forceinline__ void adam_bias_terms(const AdamScalars& c, int64_t done, float* step_size, float* bc2_sqrt) {
+    double x1 = c.b1, x2 = c.b2d, r1 = 1.0, r2 = 1.0;
+    for (int64_t e = done + 1; e > 0; e >>= 1) {
+        if (e & 1) r1 *= x1, r2 *= x2;
+        x1 *= x1, x2 *= x2;
+    }
+    *step_size = (float)(c.lr / (1.0 - r1));
+    *bc2_sqrt = (float)sqrt(1.0 - r2);
+}
+
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& c,
                                       float step_size, float bc2_sqrt) {
     m = m + c.w1 * (g - m);                         // lerp, weight < 0.5
@@ -87,15 +102,11 @@ __device__ __forceinline__ float alpha_adam_block(const AlphaAdamArgs& a, float*
     float p = 0.f, g = 0.f, m = 0.f, v = 0.f;
     if (mine) p = a.param[tid], g = a.grad[tid], m = a.exp_avg[tid], v = a.exp_avg_sq[tid];
     float ps = a.param[a.slot], ms = a.exp_avg[a.slot], vs = a.exp_avg_sq[a.slot];
-    // the bias corrections (two double-precision pow: the long pole of the step) by ONE wave — the second, idle once
+    // the bias corrections (double precision) by ONE wave — the second, idle once
     // the reduction's first stage is through — while the first finishes the sum; a 1024-thread host workgroup would
     // otherwise run them in all of its 16 waves, four deep on every SIMD
     float step_size = 0.f, bc2_sqrt = 0.f;
-    if ((tid >> 6) == 1) {
-        const double t = (double)(done + 1);
-        step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));
-        bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
-    }
+    if ((tid >> 6) == 1) adam_bias_terms(a.c, done, &step_size, &bc2_sqrt);
     if (tid < 256) red[tid] = part;
     __syncthreads();
     if (tid < 128) red[tid] += red[tid + 128];
@@ -134,9 +145,8 @@ __device__ __forceinline__ float alpha_adam_preview(const AlphaAdamArgs& a, floa
     for (int b = tid; b < a.B; b += 256) part += -a.logp[b] - a.target;
     const int64_t done = *a.steps_done;
     float p = a.param[a.slot], m = a.exp_avg[a.slot], v = a.exp_avg_sq[a.slot];
-    const double t = (double)(done + 1);
-    const float step_size = (float)(a.c.lr / (1.0 - pow(a.c.b1, t)));      // (overlaps the loads above)
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(a.c.b2d, t));
+    float step_size, bc2_sqrt;
+    adam_bias_terms(a.c, done, &step_size, &bc2_sqrt);                      // (overlaps the loads above)
     red[tid] = part;
     __syncthreads();
     alpha_reduce_256(red);

@@ -163,9 +163,15 @@ __device__ __forceinline__ bool sumtree_update_wg_own(float* tree, int levels, i
             }
         }
     }
+#ifdef TD_STAMP
+    TD_STAMP(5);
+#endif
     if (last) tree[leaf1 - 1] = p;
     with_leaves();
     __syncthreads();
+#ifdef TD_STAMP
+    TD_STAMP(6);
+#endif
     propagate_leaf(tree, levels, leaf1);
     return true;
 }

@@ -18,9 +18,8 @@ __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, cons
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ param, const float* __restrict__ grad,
                                               float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                               int64_t n, AdamScalars c, const int64_t* __restrict__ steps_done) {
-    const double t = (double)(*steps_done + 1);
-    const float step_size = (float)(c.lr / (1.0 - pow(c.b1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(c.b2d, t));
+    float step_size, bc2_sqrt;
+    adam_bias_terms(c, *steps_done, &step_size, &bc2_sqrt);
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool aligned = ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) |
@@ -97,9 +96,8 @@ __global__ __launch_bounds__(256) void k_adam_partials(float* __restrict__ param
     }
     float l = 0.f;
     if (loss_partial && tid < E) l = sum_tiles(loss_partial + tid, E, tiles);
-    const double t = (double)(*steps_done + 1);
-    const float step_size = (float)(c.lr / (1.0 - pow(c.b1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(c.b2d, t));
+    float step_size, bc2_sqrt;
+    adam_bias_terms(c, *steps_done, &step_size, &bc2_sqrt);
     if (loss_partial && tid < E) loss_out[tid] = l * inv_n;
     if (tid < n) {
         if (summed) {

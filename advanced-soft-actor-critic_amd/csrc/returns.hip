@@ -6,6 +6,19 @@
 #include "asac_common.h"
 #include "asac_sidecar.h"
 #include "asac_squash.h"
+#include "asac_common.h"
+namespace asac {
+// phase time stamps of the workgroup for tools/td_phases.py (100 MHz wall clock); compiled out of the library
+#ifdef ASAC_TD_STAMPS
+__device__ unsigned long long g_td_stamps[16];
+#define TD_STAMP(i)                                              \
+    do {                                                         \
+        if (threadIdx.x == 0) g_td_stamps[i] = wall_clock64();   \
+    } while (0)
+#else
+#define TD_STAMP(i)
+#endif
+}  // namespace asac
 #include "asac_tree_update.h"
 #include "asac_vtrace.h"
 
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     }
     const asac_vtrace_args_t& a = u.a;
     const int n = a.n, B = a.B, pitch = (n + 1) | 1;
+    TD_STAMP(0);
     float* s_d = lds;
     float* s_c = s_d + B * pitch;
     float* s_v0 = lds + ((2 * B * pitch + 3) & ~3);                     // (16-byte aligned: so are the arrays behind it)
@@ -294,18 +308,27 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
     const bool have0 = f0 < B * n;
     VtraceStepRaw raw0{};
     if (have0) raw0 = vtrace_step_load(a, f0 / n, f0 - (f0 / n) * n);
-    int leaf1 = 0;
     float q_on[4] = {0.f, 0.f, 0.f, 0.f};
     if (row < B) {
-        const int slot = ring_slot(id, u.capacity);
-        if (u.slot_ids == nullptr || u.slot_ids[slot] == id) leaf1 = slot + u.capacity;
 #pragma unroll
         for (int j = 0; j < 4; ++j) q_on[j] = a.q_online[(int64_t)min(j, a.E_online - 1) * B + row];
     }
+    // (nothing above is USED yet: the id -> ring slot -> id-map lookup is a dependent round trip, and taken here it held
+    // the whole workgroup 2 us in front of the temperature step, whose own loads were not even issued — tools/td_phases.py.
+    // The step's loads go out now, beside the row's; the id map is asked once the step is through and answers under
+    // the return's phases)
     float log_alpha;
+    TD_STAMP(1);
     if (u.has_alpha) log_alpha = alpha_adam_block(u.alpha, lds);
     else log_alpha = *a.log_alpha;
     __syncthreads();
+    TD_STAMP(2);
+    int slot = 0;
+    int64_t resident = 0;
+    if (row < B) {
+        slot = ring_slot(id, u.capacity);
+        resident = u.slot_ids ? u.slot_ids[slot] : id;
+    }
     const float alpha = expf(log_alpha);
     for (int f = threadIdx.x; f < B * n; f += blockDim.x) {
         const int r = f / n, t = f - r * n;
@@ -316,6 +339,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
         s_c[r * pitch + t] = c;
     }
     __syncthreads();
+    TD_STAMP(3);
     // what follows has one lane per ROW (B <= blockDim.x): waves without a row leave (a finished wave no longer counts
     // at the barriers of the climb: 4 waves instead of 16 at each of them for a batch of 256).  This leans on the CDNA
     // rule for S_BARRIER — "if some waves of the workgroup have already terminated, the barrier waits for the surviving
@@ -340,12 +364,21 @@ __global__ __launch_bounds__(kUpdateBlock) void k_td_update(const TdUpdateArgs u
         }
         td = s / (float)a.E_online;
     }
+    const int leaf1 = (row < B && resident == id) ? slot + u.capacity : 0;
     // (the outputs are stored with the leaves, behind the election)
+    TD_STAMP(4);
     const bool fine = sumtree_update_wg_own(u.tree, u.levels, B, leaf1, td, u.alpha_pow, u.td_min, u.td_max, u.nan_flag, s_leaf,
                                             min((int)blockDim.x, (B + 63) & ~63),
                                             [&] { if (row < B) a.y_out[row] = y, a.td_error_out[row] = td; });
     if (!fine && row < B) a.y_out[row] = y, a.td_error_out[row] = td;
+    TD_STAMP(7);
 }
+
+#ifdef ASAC_TD_STAMPS
+extern "C" int asac_debug_td_stamps(unsigned long long* out_host) {
+    return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_td_stamps), sizeof(g_td_stamps));
+}
+#endif
 
 // precomputed-V variant of phase 1a (discrete / hybrid branches hand V in directly)
 __global__ __launch_bounds__(256) void k_vtrace_direct(const VtraceDev v, const float* __restrict__ v_n,
