@@ -107,6 +107,30 @@ class TwinPass:
         return own
 
 
+# `backward_from_position`: (the _GruFn node, members [E, B, H], position) while that node's backward is the next to run
+_TOP_AT = None
+
+
+def is_fused_top(t: torch.Tensor) -> bool:
+    """is `t` the top-layer output of a fused GRU launch itself (no module stands between the two)?"""
+    fn = t.grad_fn
+    return fn is not None and type(fn).__name__ == '_GruFnBackward' and t.output_nr == 0
+
+
+def backward_from_position(top, members, position, placeholder):
+    """Back-propagate d loss / d top[:, position] = sum_e members[e] (zero at every other position) from the fused
+    GRU's own output `top` (`is_fused_top`): the launch sums the members itself and starts its recursion at the position
+    (`asac_gru_backward_at`) — no member-sum launch, no [B, L, H] gradient read.  `placeholder`: any [B, L, H] tensor
+    (autograd wants a gradient object of the output's shape; its values are not read)."""
+    global _TOP_AT
+    assert is_fused_top(top) and members.shape[1:] == (top.shape[0], top.shape[2])
+    _TOP_AT = (top.grad_fn, members.contiguous(), int(position) % top.shape[1])
+    try:
+        torch.autograd.backward([top], [placeholder])
+    finally:
+        _TOP_AT = None
+
+
 class _GruFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, padding_mask, desc, twin, *weights):
@@ -159,17 +183,27 @@ class _GruFn(torch.autograd.Function):
         g_h0 = torch.empty((B, layers, desc.hidden), dtype=x.dtype, device=x.device) \
             if (h0 is not None and ctx.needs_input_grad[1]) else None
         ws = torch.empty(native.gru_backward_workspace(desc, B), dtype=x.dtype, device=x.device)
+        at = _TOP_AT if (_TOP_AT is not None and _TOP_AT[0] is ctx and grad_hn is None) else None
+        assert _TOP_AT is None or at is not None, 'backward_from_position: another node ran first'
         grad_out = None if grad_out is None else grad_out.contiguous()
         grad_hn = None if grad_hn is None else grad_hn.contiguous()
+
+        def launch(g_params, gt, accumulate):
+            if at is not None:
+                native.gru_backward_at(desc, w, x, h0, mask, hn, gates, at[1], at[2], g_x, g_h0, g_params, gt,
+                                       accumulate, ws)
+            else:
+                native.gru_backward(desc, w, x, h0, mask, hn, gates, grad_hn, grad_out, g_x, g_h0, g_params, gt,
+                                    accumulate, ws)
         direct = DIRECT_PARAM_GRADS and direct_enabled() and all(
             t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32 and t.grad.is_cuda
             for t in weights)
         if direct:
             gt = [tuple(t.grad for t in weights[4 * l:4 * l + 4]) for l in range(layers)]
-            native.gru_backward(desc, w, x, h0, mask, hn, gates, grad_hn, grad_out, g_x, g_h0, None, gt, True, ws)
+            launch(None, gt, True)
             return (g_x, g_h0, None, None, None, *([None] * len(weights)))
         g_params = torch.empty(native.gru_param_count(desc), dtype=x.dtype, device=x.device)
-        native.gru_backward(desc, w, x, h0, mask, hn, gates, grad_hn, grad_out, g_x, g_h0, g_params, None, False, ws)
+        launch(g_params, None, False)
         g_w, off = [], 0
         for t in weights:
             k = t.numel()

@@ -107,6 +107,7 @@ class PrioritizedReplayBuffer:
         self._columns: dict[str, torch.Tensor] | None = None   # key -> ring [C, *shape]
         self._batch: dict[str, torch.Tensor] | None = None     # key -> [B, L, *shape]
         self._gather_keys = None
+        self._join_action_width, self.joint_pre_action = None, None
         self._size = 0
         self._next_id = 0
 
@@ -195,20 +196,48 @@ class PrioritizedReplayBuffer:
     # ------------------------------------------------------------------------------------------
     # sample
     # ------------------------------------------------------------------------------------------
-    def _window_specs(self, n: int):
+    def join_vector_obs_with_pre_action(self, action_width: int | None) -> None:
+        """Lay the static batch's vector observations out as column blocks of ONE [B, L, sum(widths) + action_width]
+        tensor whose last block (`joint_pre_action`) the learner fills with the previous actions: the concatenation a
+        recurrent representation starts with (reference envs/*/nn*.py: `torch.cat([obs, pre_action], dim=-1)`) then
+        already exists in memory and `adjacent_cat.AdjacentCat` hands it out as a view.  None: dense tensors per key."""
+        self._join_action_width = action_width
+        self._batch, self._gather_keys, self.joint_pre_action = None, None, None
+
+    def _out_kind(self, k, col, pad):
+        if pad and k.startswith('obs_') and col.dtype in (torch.uint8, torch.bool):
+            return torch.float32, native.CVT_U8_TO_F32_UNIT if col.dtype == torch.uint8 else native.CVT_BOOL_TO_F32
+        return col.dtype, native.CVT_NONE
+
+    def _window_specs(self, n: int, joined: bool = False):
         """destination tensors [n, L, *shape] per key (+ `padding_mask` with the fused padding) and the gather key
         table that fills them"""
         L, dev = self.window, self.device
         pad = self._pad_action is not None
         batch, specs = {}, []
+        joint, joint_at = None, {}
+        if joined and self._join_action_width:
+            members = [(k, col.shape[1]) for k, col in self._columns.items()
+                       if k.startswith('obs_') and col.dim() == 2 and col.shape[1] > 0
+                       and self._out_kind(k, col, pad)[0] == torch.float32]
+            if members:
+                width = sum(w for _, w in members)
+                joint = torch.zeros((n, L, width + self._join_action_width), dtype=torch.float32, device=dev)
+                off = 0
+                for k, w in members:
+                    joint_at[k] = off
+                    off += w
+                self.joint_pre_action = joint[..., width:]
         for k, col in self._columns.items():
             shape = tuple(col.shape[1:])
             row_bytes = int(np.prod(shape, dtype=np.int64)) * col.element_size() if shape else col.element_size()
-            out_dtype, convert = col.dtype, native.CVT_NONE
-            if pad and k.startswith('obs_') and col.dtype in (torch.uint8, torch.bool):
-                convert = native.CVT_U8_TO_F32_UNIT if col.dtype == torch.uint8 else native.CVT_BOOL_TO_F32
-                out_dtype = torch.float32
-            out = torch.zeros((n, L, *shape), dtype=out_dtype, device=dev)
+            out_dtype, convert = self._out_kind(k, col, pad)
+            pitch = 0
+            if k in joint_at:      # a column block of the joint tensor
+                out = joint[..., joint_at[k]:joint_at[k] + shape[0]]
+                pitch = joint.shape[-1] * 4
+            else:
+                out = torch.zeros((n, L, *shape), dtype=out_dtype, device=dev)
             batch[k] = out
             mode, word, pad_row = native.PAD_KEEP, 0, None
             if pad:
@@ -228,7 +257,7 @@ class PrioritizedReplayBuffer:
             if row_bytes == 0:
                 continue   # e.g. pre_seq_hidden_state of shape [C, 0]: nothing to move
             specs.append(dict(src=col, dst=out, row_bytes=row_bytes, pad_mode=mode, pad_word=word,
-                              pad_row=pad_row, convert=convert))
+                              pad_row=pad_row, convert=convert, dst_row_pitch=pitch))
         if pad:
             batch['padding_mask'] = torch.zeros((n, L), dtype=torch.bool, device=dev)
             specs.append(dict(src=None, dst=batch['padding_mask'], pad_mode=native.PAD_EMIT_MASK))
@@ -236,7 +265,7 @@ class PrioritizedReplayBuffer:
         return batch, specs
 
     def _build_batch(self) -> None:
-        self._batch, specs = self._window_specs(self.batch_size)
+        self._batch, specs = self._window_specs(self.batch_size, joined=True)
         self._gather_keys = native.make_gather_keys(specs)
         self._gather_refs = specs   # keep tensors alive
 

@@ -33,6 +33,7 @@ from torch.nn import functional
 
 from asac_amd import native
 
+from . import fused_gru
 from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls
 from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
@@ -231,6 +232,9 @@ class SAC_Base(AuxHeadsMixin):
         self._deferred_return = None
         self._td_update_with = None     # (replay buffer, ids): the TD error's return launch also updates the priorities
         self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
+        self._gru_backward_at = bool(hip_config.get('gru_backward_at', True))
+        self._adjacent_cat = bool(hip_config.get('adjacent_cat', True))
+        self._cat_mode = None
         self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
         self._dist_sampling = hip_config.get('dist_sampling', 'throughput')     # 'throughput' | 'parity' 
@@ -544,6 +548,13 @@ class SAC_Base(AuxHeadsMixin):
                                                      **(replay_config or {}))
         self.replay_buffer.set_window_padding(self._padding_action)
         self.replay_buffer.uniform_source = self.noise
+        self._cat_mode = None
+        if self._adjacent_cat and self.seq_encoder is not None and type(self.model_rep) is not ModelSimpleRep:
+            # a sequence representation receives (obs, previous actions): keep them side by side in the static batch so
+            # that the concatenation such modules start with is a view (adjacent_cat.py)
+            from .adjacent_cat import AdjacentCat
+            self.replay_buffer.join_vector_obs_with_pre_action(self.d_action_summed_size + self.c_action_size)
+            self._cat_mode = AdjacentCat
         if self._dist is not None and self._dist_sampling == 'parity':
             # SURVEY 8e "parity": every batch is the reference's stratified sample over the UNION of the ranks' shards
             # (global batch = world_size * batch_size, this rank trains on batch_size rows of it)
@@ -798,14 +809,16 @@ class SAC_Base(AuxHeadsMixin):
     # ==========================================================================================
     # states (reference sac_base.py:1090-1189)
     # ==========================================================================================
-    def get_bnx_data(self, bn_indexes, bn_padding_masks, bn_actions):
+    def get_bnx_data(self, bn_indexes, bn_padding_masks, bn_actions, pre_action_out=None):
         if (bn_indexes.is_cuda and bn_indexes.dtype == torch.int32 and bn_indexes.shape[1] >= 1
                 and bn_padding_masks.dtype == torch.bool and bn_actions.dtype == torch.float32
                 and bn_indexes.stride(1) == 1 and bn_padding_masks.stride(1) == 1 and bn_actions.stride(2) == 1):
             B, Lm1 = bn_indexes.shape      # one launch instead of six concatenation / fill kernels
             index_x = torch.empty((B, Lm1 + 1), dtype=torch.int32, device=bn_indexes.device)
             pad_x = torch.empty((B, Lm1 + 1), dtype=torch.bool, device=bn_indexes.device)
-            pre_action = torch.empty((B, Lm1 + 1, bn_actions.shape[-1]), dtype=torch.float32, device=bn_indexes.device)
+            pre_action = pre_action_out      # (the static batch's column block beside the vector observations)
+            if pre_action is None or pre_action.shape != (B, Lm1 + 1, bn_actions.shape[-1]):
+                pre_action = torch.empty((B, Lm1 + 1, bn_actions.shape[-1]), dtype=torch.float32, device=bn_indexes.device)
             native.window_aux(bn_indexes, bn_padding_masks, bn_actions, index_x, pad_x, pre_action)
             return index_x, pad_x, pre_action
         bnx_indexes = torch.concat([bn_indexes, bn_indexes[:, -1:] + (bn_indexes[:, -1:] != -1)], dim=1)
@@ -1175,9 +1188,16 @@ class SAC_Base(AuxHeadsMixin):
                 g_base = self._g_state_base
                 if g_base is None or g_base.shape != base.shape:
                     g_base = self._g_state_base = torch.zeros_like(base)
-                torch.sum(g0, dim=0, out=g_base[:, t])
+                at_position = self._gru_backward_at and fused_gru.is_fused_top(base)
+                if not at_position:
+                    torch.sum(g0, dim=0, out=g_base[:, t])
             with direct_param_grads():
-                torch.autograd.backward([base], [g_base])
+                if at_position:
+                    # the window IS a fused GRU's output: its backward sums the members' gradients itself and starts at
+                    # position t (the steps behind it only feed detached targets) — no member-sum launch in between
+                    fused_gru.backward_from_position(base, g0, t, g_base)
+                else:
+                    torch.autograd.backward([base], [g_base])
             return self._finish_rep_q(None, None)
         q_list = None
         if self.d_action_sizes:
@@ -1645,7 +1665,8 @@ class SAC_Base(AuxHeadsMixin):
             # the stock concatenation rep ignores index / mask / previous actions: do not build them
             w.rep_in = (None, None, w.bnx_obses_list, None, w.bnx_hidden)
         else:
-            bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(w.bn_indexes, w.bn_pad, w.bn_actions)
+            bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(
+                w.bn_indexes, w.bn_pad, w.bn_actions, pre_action_out=rb.joint_pre_action)
             w.rep_in = (bnx_indexes, bnx_padding_masks, w.bnx_obses_list, bnx_pre_actions, w.bnx_hidden)
         return w
 
@@ -1653,7 +1674,8 @@ class SAC_Base(AuxHeadsMixin):
         """reference `_train` 2066-2103: online and target representation over the window, `_train_rep_q`, the states
         again under the updated representation -> w.bnx_states, w.bnx_target_states, w.next_hidden"""
         b = self.burn_in_step
-        with self._rep_twin if self._rep_twin else contextlib.nullcontext():
+        cat_mode = self._cat_mode if self._cat_mode is not None else contextlib.nullcontext
+        with (self._rep_twin if self._rep_twin else contextlib.nullcontext()), cat_mode():
             bnx_states, next_hidden = self.get_l_states(*w.rep_in, is_target=False)
             with torch.no_grad():
                 w.bnx_target_states, _ = self.get_l_states(*w.rep_in, is_target=True)
@@ -1669,7 +1691,7 @@ class SAC_Base(AuxHeadsMixin):
         if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
             self.after_rep_q_update()
         if w.rep_trainable:   # states under the updated representation (reference 2097-2103)
-            with torch.no_grad():
+            with torch.no_grad(), cat_mode():
                 w.bnx_states, w.next_hidden = self.get_l_states(*w.rep_in, is_target=False)
         else:
             w.bnx_states, w.next_hidden = bnx_states.detach(), next_hidden.detach()

@@ -32,6 +32,7 @@ struct GatherKeyDev {
     int32_t unit_log2;       // log2 of the SOURCE unit size in bytes (0, 2 or 4)
     int32_t units_per_row;
     uint32_t first_block;    // prefix sum of blocks over the keys
+    int32_t dst_pitch;       // bytes between destination rows (dense: the output row's size)
 };
 
 struct GatherArgs {          // what every key's blocks share
@@ -83,7 +84,7 @@ template <typename Unit, int kUnroll>
 __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                            int64_t total_units) {
     // g indexes units of the dense destination [B, L, units_per_row]
-    int64_t g[kUnroll];
+    int64_t g[kUnroll], at[kUnroll];
     Unit val[kUnroll];
     bool live[kUnroll];
 #pragma unroll
@@ -93,6 +94,7 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
         if (!live[r]) continue;
         const int64_t row = g[r] / k.units_per_row;
         const int w = (int)(g[r] - row * k.units_per_row);
+        at[r] = row * k.dst_pitch + (int64_t)w * (int)sizeof(Unit);
         const int sample = (int)(row / a.L);
         const int j = (int)(row - (int64_t)sample * a.L);
         const int64_t id = a.ids[sample];
@@ -106,7 +108,7 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
     }
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r)
-        if (live[r]) reinterpret_cast<Unit*>(k.dst)[g[r]] = val[r];
+        if (live[r]) *reinterpret_cast<Unit*>(k.dst + at[r]) = val[r];
 }
 
 // conversion path: 4 source bytes -> 4 floats (uint8/255 or bool)
@@ -124,7 +126,7 @@ __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherK
         const int64_t id = a.ids[sample];
         const int slot = ring_slot(id + (j - a.prev_n), a.capacity);
         const uint8_t* srow = k.src + (int64_t)slot * k.row_bytes;
-        float* drow = reinterpret_cast<float*>(k.dst) + row * k.row_bytes;
+        float* drow = reinterpret_cast<float*>(k.dst + row * k.dst_pitch);
         if (k.unit_log2 == 2) {
             const uint32_t x = reinterpret_cast<const uint32_t*>(srow)[w];
             float4 o;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void k_window_aux(const int32_t* __restrict__ 
                                                     const float* __restrict__ action, int64_t action_sb,
                                                     int64_t action_st, int B, int L, int A,
                                                     int32_t* __restrict__ index_x, uint8_t* __restrict__ pad_x,
-                                                    float* __restrict__ pre_action) {
+                                                    float* __restrict__ pre_action, int64_t pre_action_st) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * L) return;
     const int b = i / L, t = i - b * L;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void k_window_aux(const int32_t* __restrict__ 
     const int32_t iv = index[(int64_t)b * index_sb + ts];
     index_x[i] = t < L - 1 ? iv : iv + (iv != -1 ? 1 : 0);
     pad_x[i] = pad[(int64_t)b * pad_sb + ts];
-    float* dst = pre_action + (int64_t)i * A;
+    float* dst = pre_action + (int64_t)i * pre_action_st;
     const float* src = action + (int64_t)b * action_sb + (int64_t)(t - 1) * action_st;
     for (int d = 0; d < A; ++d) dst[d] = t == 0 ? 0.f : src[d];
 }
@@ -218,13 +220,14 @@ extern "C" {
 int asac_window_aux(const int32_t* index, int64_t index_stride_b, const uint8_t* padding_mask,
                     int64_t mask_stride_b, const float* action, int64_t action_stride_b, int64_t action_stride_t,
                     int B, int L, int A, int32_t* index_x_out, uint8_t* padding_mask_x_out,
-                    float* pre_action_out, void* stream) {
+                    float* pre_action_out, int64_t pre_action_stride_t, void* stream) {
+    if (pre_action_stride_t == 0) pre_action_stride_t = A;
     if (B <= 0 || L < 2 || A <= 0 || !index || !padding_mask || !action || !index_x_out || !padding_mask_x_out ||
-        !pre_action_out)
+        !pre_action_out || pre_action_stride_t < A)
         return bad_arg("asac_window_aux");
     ASAC_LAUNCH(k_window_aux, dim3((unsigned)((B * L + 255) / 256)), dim3(256), 0, as_stream(stream), index,
                 index_stride_b, padding_mask, mask_stride_b, action, action_stride_b, action_stride_t, B, L, A,
-                index_x_out, padding_mask_x_out, pre_action_out);
+                index_x_out, padding_mask_x_out, pre_action_out, pre_action_stride_t);
     return finish_launch("asac_window_aux");
 }
 
@@ -255,18 +258,22 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
         d.pad_mode = h.pad_mode;
         d.pad_word = h.pad_word;
         d.convert = h.convert;
+        const int out_row_bytes = h.convert != ASAC_CVT_NONE ? 4 * h.row_bytes : h.row_bytes;
+        d.dst_pitch = h.dst_row_pitch ? h.dst_row_pitch : out_row_bytes;
         if (h.pad_mode == ASAC_PAD_EMIT_MASK) {
+            if (h.dst_row_pitch) return bad_arg("asac_window_gather_pad: the mask is dense");
             d.unit_log2 = 0;
             d.units_per_row = 1;
         } else {
-            if (h.row_bytes <= 0 || !h.src || !h.dst) return bad_arg("asac_window_gather_pad: key");
+            if (h.row_bytes <= 0 || !h.src || !h.dst || d.dst_pitch < out_row_bytes) return bad_arg("asac_window_gather_pad: key");
             const uintptr_t al = reinterpret_cast<uintptr_t>(h.src) | reinterpret_cast<uintptr_t>(h.dst) |
+                                 (uintptr_t)(uint32_t)d.dst_pitch |
                                  (h.pad_mode == ASAC_PAD_ROW ? reinterpret_cast<uintptr_t>(h.pad_row) : 0);
             int ul = 0;
             if (h.convert != ASAC_CVT_NONE) {
                 // source rows of 4-byte groups when possible; destination is 4x wider
                 ul = (h.row_bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(h.src) % 4 == 0) &&
-                      (reinterpret_cast<uintptr_t>(h.dst) % 16 == 0)) ? 2 : 0;
+                      (reinterpret_cast<uintptr_t>(h.dst) % 16 == 0) && d.dst_pitch % 16 == 0) ? 2 : 0;
                 if (h.pad_mode != ASAC_PAD_KEEP) return bad_arg("asac_window_gather_pad: convert+pad");
             } else if (h.row_bytes % 16 == 0 && al % 16 == 0) {
                 ul = 4;

@@ -68,6 +68,11 @@ struct GruArgs {
     float* g_h0;              // [B, layers, H] or NULL
     float* partial;           // [blocks][param_count]
     int64_t param_count;
+    // backward from ONE window position (asac_gru_backward_at): the top layer's output gradient at step L_run - 1 is
+    // sum_e g_top_m[e][b][:], every other output gradient is zero, so the recursion starts there — the steps behind
+    // it would only push zeros around (L_run == L otherwise)
+    const float* g_top_m;     // [E][B][H] or NULL
+    int32_t g_top_E, L_run;
 };
 
 // sigmoid / tanh on the hardware exp2 and reciprocal (each ~1 ulp): absolute error ~1e-7, far inside
@@ -434,7 +439,8 @@ __global__ __launch_bounds__(kBwdThreads) void k_gru_bwd(const GruArgs a) {
     const bool row_ok = b < a.B;
     const bool live = row_ok && j < H;
     const int GS = layers * 5 * H, HS = layers * H;
-    const int n_chunks = (a.L + kBwdChunk - 1) / kBwdChunk;
+    const int Lr = a.L_run;                 // steps the recursion covers (strides stay those of the L-step window)
+    const int n_chunks = (Lr + kBwdChunk - 1) / kBwdChunk;
 
     for (int i = threadIdx.x; i < p.total; i += kBwdThreads) lds[i] = 0.f;
     __syncthreads();
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_gru_bwd(const GruArgs a) {
     if (wave != 0) {               // producers run one chunk ahead of the compute wave
         for (int c = n_chunks - 1; c >= -1; --c) {
             if (c >= 0) {
-                const int t0 = c * kBwdChunk, n = min(kBwdChunk, a.L - t0), buf = c & 1;
+                const int t0 = c * kBwdChunk, n = min(kBwdChunk, Lr - t0), buf = c & 1;
                 const int64_t bs = row_ok ? b : 0;
                 if (wave == 1) {
                     const int skip0 = t0 == 0 ? GS : 0;     // there is no step -1
@@ -476,6 +482,17 @@ __global__ __launch_bounds__(kBwdThreads) void k_gru_bwd(const GruArgs a) {
                         for (int e = u; e < n * H; e += GP) {
                             const int tt = e / H, k = e - tt * H;
                             if (row_ok) gh[tt * HS + (layers - 1) * H + k] += gt[e];
+                        }
+                    }
+                    if (a.g_top_m && t0 + n == Lr) {        // the one position with a gradient: members summed in order
+                        wave_sync();
+                        for (int k = u; k < H; k += GP) {
+                            float sum = 0.f;
+                            for (int e = 0; e < a.g_top_E; ++e) {
+                                const float v = a.g_top_m[((int64_t)e * a.B + bs) * H + k];
+                                sum = e == 0 ? v : sum + v;
+                            }
+                            if (row_ok) gh[(n - 1) * HS + (layers - 1) * H + k] += sum;
                         }
                     }
                 } else {
@@ -547,8 +564,8 @@ __global__ __launch_bounds__(kBwdThreads) void k_gru_bwd(const GruArgs a) {
 
     __syncthreads();               // the last chunk is staged (and the transposed weights are in place)
     int c = n_chunks - 1;
-    for (int k = a.L - 1; k >= (TWO ? -1 : 0); --k) {
-        const bool onA = k >= 0, onB = TWO && k + 1 < a.L;
+    for (int k = Lr - 1; k >= (TWO ? -1 : 0); --k) {
+        const bool onA = k >= 0, onB = TWO && k + 1 < Lr;
         const int t0 = c * kBwdChunk, tt = onA ? k - t0 : 0;
         const float* Gc = lds + p.G + (c & 1) * p.gsz + r * (kBwdChunk + 1) * GS;
         const float* GHc = lds + p.GH + (c & 1) * p.hsz + r * kBwdChunk * HS;
@@ -940,16 +957,17 @@ int asac_gru_forward_twin(const asac_gru_desc_t* desc, const float* const* w_ih,
                               hn_out, out_top, gates_out, twin_hn_out, twin_out_top, stream);
 }
 
-int asac_gru_backward(const asac_gru_desc_t* desc, const float* const* w_ih, const float* const* w_hh,
-                      const float* const* b_ih, const float* const* b_hh, const float* x, int64_t x_stride_b,
-                      int64_t x_stride_t, const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask,
-                      int64_t mask_stride_b, int B, int L, const float* hn, const float* gates,
-                      const float* grad_hn, const float* grad_top, float* grad_x, float* grad_h0,
-                      float* grad_params, float* const* grad_param_tensors, int accumulate, float* workspace,
-                      void* stream) {
+static int gru_backward_launch(const char* where, const asac_gru_desc_t* desc, const float* const* w_ih,
+                               const float* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                               const float* x, int64_t x_stride_b, int64_t x_stride_t, const float* h0,
+                               int64_t h0_stride_b, const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L,
+                               const float* hn, const float* gates, const float* grad_hn, const float* grad_top,
+                               const float* grad_top_members, int members, int position, float* grad_x,
+                               float* grad_h0, float* grad_params, float* const* grad_param_tensors, int accumulate,
+                               float* workspace, void* stream) {
     if (!desc || !gru_desc_ok(*desc) || B <= 0 || L <= 0 || !x || !hn || !gates || !workspace ||
         (!grad_params == !grad_param_tensors))
-        return bad_arg("asac_gru_backward");
+        return bad_arg(where);
     GruArgs a{};
     a.d = *desc;
     gru_fill_ptrs(a, w_ih, w_hh, b_ih, b_hh);
@@ -961,18 +979,24 @@ int asac_gru_backward(const asac_gru_desc_t* desc, const float* const* w_ih, con
     a.gates = const_cast<float*>(gates);
     a.g_hn = grad_hn;
     a.g_top = grad_top;
+    a.g_top_m = grad_top_members;
+    a.g_top_E = members;
+    a.L_run = grad_top_members ? position + 1 : L;
     a.g_x = grad_x;
     a.g_h0 = grad_h0;
     a.partial = workspace;
     a.param_count = asac_gru_param_count(desc);
     const int rows = kGruWave / (4 * desc->hidden_pow2), blocks = (B + rows - 1) / rows;
     hipStream_t s = as_stream(stream);
+    if (grad_x && a.L_run < L) {        // the inputs behind the position receive no gradient: the kernel does not visit them
+        if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)B * L * desc->input, s) != hipSuccess) return finish_launch(where);
+    }
     static bool attr[4] = {false, false, false, false};
     const int maxd = gru_maxd(*desc);
     const size_t lds = (size_t)gru_bwd_plan(*desc, rows, maxd).total * sizeof(float);
 #define ASAC_GRU_BWD(MAXD, TWO, SLOT)                                                                              \
     do {                                                                                                           \
-        if (int rc = gru_lds_limit(reinterpret_cast<const void*>(k_gru_bwd<MAXD, TWO>), attr[SLOT], "asac_gru_backward")) \
+        if (int rc = gru_lds_limit(reinterpret_cast<const void*>(k_gru_bwd<MAXD, TWO>), attr[SLOT], where))        \
             return rc;                                                                                             \
         ASAC_LAUNCH((k_gru_bwd<MAXD, TWO>), dim3(blocks), dim3(kBwdThreads), lds, s, a);                           \
     } while (0)
@@ -1000,7 +1024,33 @@ int asac_gru_backward(const asac_gru_desc_t* desc, const float* const* w_ih, con
     // launched once (not under the repeat knob: it may accumulate)
     hipLaunchKernelGGL(k_gru_reduce, dim3((unsigned)((a.param_count + 63) / 64)), dim3(64 * kReduceSlices), 0, s, workspace,
                        blocks, a.param_count, g);
-    return finish_launch("asac_gru_backward");
+    return finish_launch(where);
+}
+
+int asac_gru_backward(const asac_gru_desc_t* desc, const float* const* w_ih, const float* const* w_hh,
+                      const float* const* b_ih, const float* const* b_hh, const float* x, int64_t x_stride_b,
+                      int64_t x_stride_t, const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask,
+                      int64_t mask_stride_b, int B, int L, const float* hn, const float* gates,
+                      const float* grad_hn, const float* grad_top, float* grad_x, float* grad_h0,
+                      float* grad_params, float* const* grad_param_tensors, int accumulate, float* workspace,
+                      void* stream) {
+    return gru_backward_launch("asac_gru_backward", desc, w_ih, w_hh, b_ih, b_hh, x, x_stride_b, x_stride_t, h0,
+                               h0_stride_b, padding_mask, mask_stride_b, B, L, hn, gates, grad_hn, grad_top, nullptr, 0,
+                               0, grad_x, grad_h0, grad_params, grad_param_tensors, accumulate, workspace, stream);
+}
+
+int asac_gru_backward_at(const asac_gru_desc_t* desc, const float* const* w_ih, const float* const* w_hh,
+                         const float* const* b_ih, const float* const* b_hh, const float* x, int64_t x_stride_b,
+                         int64_t x_stride_t, const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask,
+                         int64_t mask_stride_b, int B, int L, const float* hn, const float* gates,
+                         const float* grad_top_members, int members, int position, float* grad_x, float* grad_h0,
+                         float* grad_params, float* const* grad_param_tensors, int accumulate, float* workspace,
+                         void* stream) {
+    if (!grad_top_members || members <= 0 || position < 0 || position >= L) return bad_arg("asac_gru_backward_at");
+    return gru_backward_launch("asac_gru_backward_at", desc, w_ih, w_hh, b_ih, b_hh, x, x_stride_b, x_stride_t, h0,
+                               h0_stride_b, padding_mask, mask_stride_b, B, L, hn, gates, nullptr, nullptr,
+                               grad_top_members, members, position, grad_x, grad_h0, grad_params, grad_param_tensors,
+                               accumulate, workspace, stream);
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 50
+ABI_VERSION = 51
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -28,7 +28,7 @@ class AsacNativeError(RuntimeError):
 class GatherKey(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('pad_row', C.c_void_p),
                 ('row_bytes', C.c_int32), ('pad_mode', C.c_int32), ('pad_word', C.c_uint32),
-                ('convert', C.c_int32)]
+                ('convert', C.c_int32), ('dst_row_pitch', C.c_int32), ('reserved_', C.c_int32)]
 
 
 ROW_ITEM, ROW_SLOT, ROW_SLOT_ROW, ROW_BROADCAST = 0, 1, 2, 3
@@ -153,7 +153,7 @@ _SIGNATURES = {
     'asac_rows_move': (C.c_int, [C.POINTER(RowMove), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_void_p]),
     'asac_window_aux': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
-                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'asac_scatter_rows_if_id_match': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                 C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -267,6 +267,10 @@ _SIGNATURES = {
                                     C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_gru_backward_at': (C.c_int, [C.POINTER(GruDesc), _PtrArray, _PtrArray, _PtrArray, _PtrArray, C.c_void_p,
+                                       C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_policy_loss_fwd_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -529,6 +533,7 @@ def make_gather_keys(specs):
         k.pad_mode = int(s['pad_mode'])
         k.pad_word = int(s.get('pad_word', 0)) & 0xffffffff
         k.convert = int(s.get('convert', 0))
+        k.dst_row_pitch = int(s.get('dst_row_pitch', 0))
     return arr
 
 
@@ -557,15 +562,18 @@ def _ls_rows(loc, scale):
 @_profiled
 def window_aux(bn_indexes, bn_padding_masks, bn_actions, index_x, pad_x, pre_action):
     """bn_* = the L-1 leading rows of the sampled window ([B, L-1(, A)] views) -> index_x i32 [B, L],
-    pad_x bool [B, L], pre_action f32 [B, L, A] (dense outputs)."""
+    pad_x bool [B, L] (dense), pre_action f32 [B, L, A] (dense, or a column block of a wider [B, L, *] tensor)."""
     B, Lm1 = bn_indexes.shape
     A = bn_actions.shape[-1]
     assert bn_indexes.dtype == torch.int32 and bn_indexes.stride(1) == 1 and bn_padding_masks.stride(1) == 1
     assert bn_padding_masks.element_size() == 1 and bn_actions.stride(2) == 1 and bn_actions.dtype == torch.float32
-    assert index_x.is_contiguous() and pad_x.is_contiguous() and pre_action.is_contiguous()
+    assert index_x.is_contiguous() and pad_x.is_contiguous()
+    assert pre_action.shape == (B, Lm1 + 1, A) and pre_action.stride(2) == 1 and pre_action.dtype == torch.float32
+    assert pre_action.stride(0) == (Lm1 + 1) * pre_action.stride(1)
     _check(load().asac_window_aux(_p(bn_indexes), bn_indexes.stride(0), _p(bn_padding_masks), bn_padding_masks.stride(0),
                                   _p(bn_actions), bn_actions.stride(0), bn_actions.stride(1), B, Lm1 + 1, A,
-                                  _p(index_x), _p(pad_x), _p(pre_action), _stream()), 'asac_window_aux')
+                                  _p(index_x), _p(pad_x), _p(pre_action), pre_action.stride(1), _stream()),
+           'asac_window_aux')
 
 
 @_profiled
@@ -1208,6 +1216,18 @@ def gru_forward_twin(desc, weights, twin_weights, x, h0, padding_mask, hn_out, o
                                         _p(twin_hn_out), _p(twin_out_top), _stream()), 'asac_gru_forward_twin')
 
 
+def _gru_grad_ptrs(grad_tensors, desc):
+    if grad_tensors is None:
+        return None
+    gt = (C.c_void_p * (4 * GRU_MAX_LAYERS))()
+    for l in range(desc.layers):
+        for k in range(4):
+            t = grad_tensors[l][k]
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+            gt[4 * l + k] = t.data_ptr()
+    return gt
+
+
 @_profiled
 def gru_backward(desc, weights, x, h0, padding_mask, hn, gates, grad_hn, grad_top, grad_x, grad_h0, grad_params,
                  grad_tensors, accumulate, workspace):
@@ -1217,18 +1237,29 @@ def gru_backward(desc, weights, x, h0, padding_mask, hn, gates, grad_hn, grad_to
     px, sb, st = _gru_x(x)
     pm, ms = _gru_mask(padding_mask)
     ph, hs = _gru_h0(h0, desc)
-    gt = None
-    if grad_tensors is not None:
-        gt = (C.c_void_p * (4 * GRU_MAX_LAYERS))()
-        for l in range(desc.layers):
-            for k in range(4):
-                t = grad_tensors[l][k]
-                assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
-                gt[4 * l + k] = t.data_ptr()
+    gt = _gru_grad_ptrs(grad_tensors, desc)
     _check(load().asac_gru_backward(C.byref(desc), wi, wh, bi, bh, px, sb, st, ph, hs, pm, ms, x.shape[0],
                                     x.shape[1], _p(hn), _p(gates), _p(grad_hn), _p(grad_top), _p(grad_x), _p(grad_h0),
                                     _p(grad_params), gt, int(bool(accumulate)), _p(workspace), _stream()),
            'asac_gru_backward')
+
+
+@_profiled
+def gru_backward_at(desc, weights, x, h0, padding_mask, hn, gates, grad_top_members, position, grad_x, grad_h0,
+                    grad_params, grad_tensors, accumulate, workspace):
+    """`gru_backward` for an output gradient that lives at ONE window position: grad_top_members [E, B, H] are the
+    ensemble members' gradients of out_top[:, position] (summed inside the launch); the recursion starts there."""
+    wi, wh, bi, bh = _gru_ptrs(weights, desc)
+    px, sb, st = _gru_x(x)
+    pm, ms = _gru_mask(padding_mask)
+    ph, hs = _gru_h0(h0, desc)
+    m = grad_top_members
+    assert m.dim() == 3 and m.is_contiguous() and m.dtype == torch.float32 and m.shape[1:] == (x.shape[0], desc.hidden)
+    gt = _gru_grad_ptrs(grad_tensors, desc)
+    _check(load().asac_gru_backward_at(C.byref(desc), wi, wh, bi, bh, px, sb, st, ph, hs, pm, ms, x.shape[0],
+                                       x.shape[1], _p(hn), _p(gates), _p(m), m.shape[0], int(position), _p(grad_x),
+                                       _p(grad_h0), _p(grad_params), gt, int(bool(accumulate)), _p(workspace),
+                                       _stream()), 'asac_gru_backward_at')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 50
+#define ASAC_ABI_VERSION 51
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -165,6 +165,10 @@ typedef struct {
     int32_t pad_mode;
     uint32_t pad_word;
     int32_t convert;
+    int32_t dst_row_pitch; /* bytes between destination rows; 0 = dense (out_row_bytes).  A wider pitch lets a key
+                              land as a column block of a wider [batch, L, *] tensor: the vector observation beside
+                              the previous action, the concatenation a recurrent representation starts with */
+    int32_t reserved_;
 } asac_gather_key_t;
 
 /* K3: for every sampled id gather the rows id-prev_n .. id+post_n of every key (ring slot =
@@ -224,12 +228,12 @@ int asac_rows_move(const asac_row_move_t* keys_host, int n_keys, const int32_t* 
  * rows `bn` of every sampled window
  *   index_x      [B][L]    = bn indexes, then last + (last != -1)
  *   pad_x        [B][L]    = bn padding mask, then its last entry again
- *   pre_action   [B][L][A] = zeros, then the bn actions
+ *   pre_action   [B][L][A] = zeros, then the bn actions (rows pre_action_stride_t floats apart; 0 = A, dense)
  * index / padding_mask / action are the window tensors ([B][>=L-1] with the given strides in elements). */
 int asac_window_aux(const int32_t* index, int64_t index_stride_b, const uint8_t* padding_mask,
                     int64_t mask_stride_b, const float* action, int64_t action_stride_b, int64_t action_stride_t,
                     int B, int L, int A, int32_t* index_x_out, uint8_t* padding_mask_x_out,
-                    float* pre_action_out, void* stream);
+                    float* pre_action_out, int64_t pre_action_stride_t, void* stream);
 
 /* K7: rows[s, j] -> ring[(ids[s] + first_off + j) mod C] for j in [0, count), only where
  * padding_mask[s, j] == 0 and the slot still holds that id; when several rows target one slot the
@@ -701,6 +705,21 @@ int asac_gru_backward(const asac_gru_desc_t* desc_host, const float* const* w_ih
                       const float* gates, const float* grad_hn, const float* grad_top, float* grad_x,
                       float* grad_h0, float* grad_params, float* const* grad_param_tensors, int accumulate,
                       float* workspace, void* stream);
+
+/* BPTT from ONE window position: the loss reads the representation's state at a single step of the window
+ * (SAC_Base._train_rep_q takes `m_states[:, burn_in_step]`, sac_base.py:2104-2110, everything behind it only feeds
+ * detached targets), and E critics each hand back d loss / d state there.  The gradient of out_top is
+ * sum_e grad_top_members[e][b][:] (summed in member order) at `position` and zero elsewhere, grad_hn is zero — the
+ * values asac_gru_backward returns for that dense gradient, bit for bit, but the recursion starts AT the position
+ * (the steps behind it carry zeros) and no [B][L][H] gradient tensor is formed or read.
+ *   grad_top_members [members][B][H];  0 <= position < L;  grad_x (when asked for) is zero behind the position. */
+int asac_gru_backward_at(const asac_gru_desc_t* desc_host, const float* const* w_ih, const float* const* w_hh,
+                         const float* const* b_ih, const float* const* b_hh, const float* x,
+                         int64_t x_stride_b, int64_t x_stride_t, const float* h0, int64_t h0_stride_b,
+                         const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, const float* hn,
+                         const float* gates, const float* grad_top_members, int members, int position,
+                         float* grad_x, float* grad_h0, float* grad_params, float* const* grad_param_tensors,
+                         int accumulate, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused two-layer convolution stack: Conv2d(C->out1, kernel1, stride1) GELU Conv2d(out1->out2, kernel2,

@@ -193,3 +193,75 @@ def test_twin_pass_equals_two_passes(H, layers, B, L):
         with torch.no_grad():
             target(a, b, h0, mask)
     assert 'asac_gru_forward_twin' not in prof.summary()
+
+
+@pytest.mark.parametrize('I,H,layers,B,L,position,E,with_h0,mask_kind,want_gx', [
+    (8, 8, 2, 256, 81, 40, 2, True, 'lead', False),      # the cfg3 step: state at burn_in_step of a window of 81
+    (8, 8, 2, 37, 13, 12, 3, False, 'none', True),       # the last position: the whole window is walked
+    (12, 6, 1, 70, 9, 0, 1, True, 'lead+tail', True),    # the first position: one step
+    (16, 16, 2, 33, 21, 7, 2, True, 'lead', True),       # position at a chunk's last slot
+    (3, 16, 1, 5, 17, 8, 4, False, 'lead+tail', False),  # ... and at a chunk's first
+])
+def test_backward_from_one_position_equals_dense_backward(I, H, layers, B, L, position, E, with_h0, mask_kind, want_gx):
+    """`asac_gru_backward_at` (members summed in the launch, recursion started at the position) == `asac_gru_backward`
+    on the dense gradient that is sum_e members[e] at the position and zero elsewhere: every output bit for bit."""
+    from asac_amd import native
+    _, dev = _layers(I, H, layers)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, L, I, generator=gen).cuda()
+    h0 = (torch.randn(B, layers, H, generator=gen) * 0.5).cuda() if with_h0 else None
+    mask = _mask(B, L, mask_kind, gen)
+    mask = None if mask is None else mask.cuda()
+    members = torch.randn(E, B, H, generator=gen).cuda()
+    desc = native.gru_desc(I, H, layers)
+    w = [tuple(getattr(c, n).detach().contiguous() for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0'))
+         for c in dev._grus]
+    hn = torch.empty(B, L, layers, H, device='cuda')
+    out = torch.empty(B, L, H, device='cuda')
+    gates = torch.empty(B, L, layers, 5 * H, device='cuda')
+    native.gru_forward(desc, w, x, h0, mask, hn, out, gates)
+
+    def run(at):
+        g_x = torch.full((B, L, I), 7.0, device='cuda') if want_gx else None
+        g_h0 = torch.empty(B, layers, H, device='cuda') if with_h0 else None
+        g_p = torch.empty(native.gru_param_count(desc), device='cuda')
+        ws = torch.empty(native.gru_backward_workspace(desc, B), device='cuda')
+        if at:
+            native.gru_backward_at(desc, w, x, h0, mask, hn, gates, members, position, g_x, g_h0, g_p, None, False, ws)
+        else:
+            dense = torch.zeros(B, L, H, device='cuda')
+            acc = members[0].clone()
+            for e in range(1, E):
+                acc = acc + members[e]
+            dense[:, position] = acc
+            native.gru_backward(desc, w, x, h0, mask, hn, gates, None, dense, g_x, g_h0, g_p, None, False, ws)
+        torch.cuda.synchronize()
+        return g_x, g_h0, g_p
+
+    for name, a, b in zip(('grad_x', 'grad_h0', 'grad_params'), run(True), run(False)):
+        if a is not None:
+            assert torch.equal(a, b), name
+    assert run(True)[2].abs().sum() > 0
+
+
+def test_autograd_route_of_backward_from_position():
+    """`fused_gru.backward_from_position` through autograd == `torch.autograd.backward` with the dense gradient"""
+    import asac_amd  # noqa: F401
+    from algorithm import fused_gru
+    _, dev = _layers(8, 8, 2)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 21, 8, generator=gen).cuda()
+    members = torch.randn(2, 64, 8, generator=gen).cuda()
+    grads = []
+    for at in (True, False):
+        dev.zero_grad(set_to_none=True)
+        top, _ = dev(x)
+        assert fused_gru.is_fused_top(top) and not fused_gru.is_fused_top(top * 1.0)
+        dense = torch.zeros_like(top)
+        if at:
+            fused_gru.backward_from_position(top, members, 9, dense)
+        else:
+            dense[:, 9] = members[0] + members[1]
+            torch.autograd.backward([top], [dense])
+        grads.append([p.grad.clone() for p in dev.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))

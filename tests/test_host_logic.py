@@ -94,3 +94,39 @@ def test_config_enums_roundtrip():
     assert cfg['seq_encoder'] is enums.SEQ_ENCODER.RNN and cfg['curiosity'] is enums.CURIOSITY.FORWARD
     enums.convert_config_to_string(cfg)
     assert cfg == {'seq_encoder': 'RNN', 'siamese': None, 'curiosity': 'FORWARD'}
+
+
+def test_adjacent_cat_returns_views_only_for_side_by_side_blocks():
+    """`adjacent_cat.joined_view` / `AdjacentCat`: a last-dim concatenation of adjacent column blocks of one tensor is
+    handed out as a view of it; anything else is ATen's concatenation."""
+    import torch
+    import asac_amd  # noqa: F401
+    from algorithm.adjacent_cat import AdjacentCat, joined_view
+    base = torch.arange(4 * 5 * 9, dtype=torch.float32).reshape(4, 5, 9)
+    a, b, c = base[..., 0:4], base[..., 4:6], base[..., 6:9]
+    v = joined_view([a, b], -1)
+    assert v is not None and v.data_ptr() == a.data_ptr() and torch.equal(v, torch.cat([a, b], -1))
+    assert torch.equal(joined_view((a, b, c), 2), base)
+    assert joined_view([a, c], -1) is None                         # a gap between the blocks
+    assert joined_view([b, a], -1) is None                         # wrong order
+    assert joined_view([a, b], 0) is None and joined_view([a], -1) is None
+    assert joined_view([a, b.clone()], -1) is None                 # another storage
+    assert joined_view([a, b.double()], -1) is None
+    assert joined_view([a[:, :3], b[:, 1:4]], -1) is None          # different rows
+    ag = a.clone().requires_grad_()
+    assert joined_view([ag, b], -1) is None
+    flat = torch.arange(12.)
+    assert joined_view([flat[:6], flat[6:]], 0) is None            # one-dimensional: no row pitch to stay inside
+    tail = base[:, :, 5:9]
+    assert joined_view([tail, base[:, :, 0:4].roll(0)], -1) is None
+    with AdjacentCat():
+        assert torch.cat([a, b], dim=-1).data_ptr() == a.data_ptr()
+        assert torch.cat((a, b), -1).data_ptr() == a.data_ptr()
+        assert torch.concat([b, c], dim=2).data_ptr() == b.data_ptr()
+        fresh = torch.cat([a, c], dim=-1)
+        assert fresh.data_ptr() != a.data_ptr() and torch.equal(fresh, torch.cat([a.clone(), c.clone()], -1))
+        out = torch.empty(4, 5, 6)
+        torch.cat([a, b], dim=-1, out=out)
+        assert torch.equal(out, base[..., :6])
+        assert torch.equal(torch.cat([a, b], dim=1), torch.cat([a.clone(), b.clone()], 1)) if a.shape[-1] == b.shape[-1] else True
+        assert torch.equal(torch.stack([a, a]).sum(0), 2 * a)

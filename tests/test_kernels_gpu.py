@@ -666,6 +666,52 @@ def test_window_aux_matches_get_bnx_data_concatenations(nat):
     got_a = torch.empty(B, L, A, device='cuda')
     nat.window_aux(bn_i, bn_p, bn_a, got_i, got_p, got_a)
     assert torch.equal(got_i, want_i.to(torch.int32)) and torch.equal(got_p, want_p) and torch.equal(got_a, want_a)
+    # ... and with the previous actions as a column block of a wider tensor (the block beside the vector observations)
+    joint = torch.full((B, L, 5 + A), 9.0, device='cuda')
+    nat.window_aux(bn_i, bn_p, bn_a, got_i, got_p, joint[..., 5:])
+    assert torch.equal(joint[..., 5:], want_a) and bool((joint[..., :5] == 9.0).all())
+
+
+def test_replay_window_lands_beside_the_previous_actions(nat):
+    """A static batch whose vector observations are column blocks of one [B, L, widths + A] tensor
+    (`join_vector_obs_with_pre_action`: the gather's `dst_row_pitch`) holds the same values as the dense batch, and the
+    concatenation [obs..., pre_action] of its blocks is a view (`adjacent_cat.joined_view`)."""
+    import asac_amd  # noqa: F401
+    from algorithm.adjacent_cat import AdjacentCat, joined_view
+    from algorithm.replay_buffer import PrioritizedReplayBuffer
+    gen = np.random.default_rng(0)
+    n = 600
+
+    data = dict(index=(np.arange(n) % 37).astype(np.int32), obs_vec=gen.standard_normal((n, 6)).astype(np.float32),
+                obs_img=gen.integers(0, 255, (n, 4, 4, 3)).astype(np.uint8),
+                obs_flag=gen.integers(0, 2, (n, 5)).astype(bool),
+                action=gen.standard_normal((n, 3)).astype(np.float32), reward=gen.standard_normal(n).astype(np.float32),
+                done=np.zeros(n, bool), last_mask=np.zeros(n, bool), mu_prob=np.ones((n, 3), np.float32),
+                pre_seq_hidden_state=gen.standard_normal((n, 2)).astype(np.float32))
+    joined = PrioritizedReplayBuffer(batch_size=32, capacity=1024, sample_prev_n=3, sample_post_n=4, device='cuda')
+    joined.set_window_padding(torch.zeros(3))
+    joined.add(data)
+    _, batch_d, _ = joined.sample()                      # dense tensors per key
+    batch_d = {k: v.clone() for k, v in batch_d.items()}
+    joined.join_vector_obs_with_pre_action(3)
+    joined._build_batch()
+    joined.sample_into_static(sampled=True)              # the same ids gathered into the joint layout
+    batch_j = joined._batch
+    for k in batch_d:
+        assert torch.equal(batch_d[k], batch_j[k]), k
+    vec, flag, pre = batch_j['obs_vec'], batch_j['obs_flag'], joined.joint_pre_action
+    assert pre.shape == (32, 8, 3) and flag.dtype == torch.float32 and not vec.is_contiguous()
+    pre.copy_(torch.randn(32, 8, 3, device='cuda'))
+    want = torch.cat([vec, flag, pre], dim=-1)
+    view = joined_view([vec, flag, pre], -1)
+    assert view is not None and view.data_ptr() == vec.data_ptr() and torch.equal(view, want)
+    with AdjacentCat():
+        got = torch.cat([vec, flag, pre], dim=-1)
+        other = torch.cat([flag, vec], dim=-1)           # not adjacent in that order: ATen's copy
+        part = torch.concat((flag, pre), -1)
+    assert got.data_ptr() == vec.data_ptr() and torch.equal(other, torch.cat([flag.clone(), vec.clone()], -1))
+    assert part.data_ptr() == flag.data_ptr() and torch.equal(part, want[..., 6:])
+    assert joined_view([batch_d['obs_vec'], batch_d['action']], -1) is None
 
 
 def test_gelu_against_torch(nat):
