@@ -107,7 +107,8 @@ class TwinPass:
         return own
 
 
-# `backward_from_position`: (the _GruFn node, members [E, B, H], position) while that node's backward is the next to run
+# `backward_from_position`: [the _GruFn node, members [E, B, H], position, adam epilogue | None, epilogue ran] while
+# that node's backward is the next to run
 _TOP_AT = None
 
 
@@ -117,18 +118,22 @@ def is_fused_top(t: torch.Tensor) -> bool:
     return fn is not None and type(fn).__name__ == '_GruFnBackward' and t.output_nr == 0
 
 
-def backward_from_position(top, members, position, placeholder):
+def backward_from_position(top, members, position, placeholder, adam=None) -> bool:
     """Back-propagate d loss / d top[:, position] = sum_e members[e] (zero at every other position) from the fused
     GRU's own output `top` (`is_fused_top`): the launch sums the members itself and starts its recursion at the position
     (`asac_gru_backward_at`) — no member-sum launch, no [B, L, H] gradient read.  `placeholder`: any [B, L, H] tensor
-    (autograd wants a gradient object of the output's shape; its values are not read)."""
+    (autograd wants a gradient object of the output's shape; its values are not read).  `adam`
+    (`native.adam_epilogue` over the learner's flat buffers): the launch that finishes the cell parameters' gradients
+    also takes their optimizer step, when those gradients are written in place -> True (else the caller still has
+    to step them)."""
     global _TOP_AT
     assert is_fused_top(top) and members.shape[1:] == (top.shape[0], top.shape[2])
-    _TOP_AT = (top.grad_fn, members.contiguous(), int(position) % top.shape[1])
+    state = _TOP_AT = [top.grad_fn, members.contiguous(), int(position) % top.shape[1], adam, False]
     try:
         torch.autograd.backward([top], [placeholder])
     finally:
         _TOP_AT = None
+    return state[4]
 
 
 class _GruFn(torch.autograd.Function):
@@ -190,8 +195,10 @@ class _GruFn(torch.autograd.Function):
 
         def launch(g_params, gt, accumulate):
             if at is not None:
+                adam = at[3] if gt is not None else None
                 native.gru_backward_at(desc, w, x, h0, mask, hn, gates, at[1], at[2], g_x, g_h0, g_params, gt,
-                                       accumulate, ws)
+                                       accumulate, ws, adam=adam)
+                at[4] = adam is not None
             else:
                 native.gru_backward(desc, w, x, h0, mask, hn, gates, grad_hn, grad_out, g_x, g_h0, g_params, gt,
                                     accumulate, ws)

@@ -234,6 +234,8 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_q_state_grads = bool(hip_config.get('fused_q_state_grads', True))
         self._gru_backward_at = bool(hip_config.get('gru_backward_at', True))
         self._adjacent_cat = bool(hip_config.get('adjacent_cat', True))
+        self._fold_rep_q_adam = bool(hip_config.get('fold_rep_q_adam', True))
+        self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
         self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
@@ -1174,15 +1176,21 @@ class SAC_Base(AuxHeadsMixin):
                 self._defer_return = False
                 w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                 ret, self._deferred_return = self._deferred_return, None
+                # one GPU: the critics' tile reduction is folded into their Adam launch (as without a trainable
+                # representation), which then no longer waits for the representation's backward
+                opt = self.optimizer_q_list[0]
+                fold = self._dist is None and self._fold_rep_q_adam
                 if ret is not None and self._fq.backward_qloss_return_ok(x0.shape[-2], ret[0]):
                     # (short windows: the return target is formed by the backward's own workgroups, no launch of its own)
                     g0 = self._fq.backward_qloss_return(x0, a0, t_q.view(self.ensemble_q_num, -1), ret[0], w,
-                                                        self.clip_epsilon, self._loss_q_e, state_grads=True)
+                                                        self.clip_epsilon, self._loss_q_e, state_grads=True, defer=fold)
                 else:
                     if ret is not None:
                         native.vtrace_return_min(ret[0])
                     g0 = self._fq.backward_qloss(x0, a0, t_q.view(self.ensemble_q_num, -1), c_y.reshape(-1), w,
-                                                 self.clip_epsilon, self._loss_q_e, state_grads=True)
+                                                 self.clip_epsilon, self._loss_q_e, state_grads=True, defer=fold)
+                if fold:
+                    self._fq.adam_partials(opt, loss_out=self._loss_q_e)
                 # d loss / d (window states): zero except at position t — a buffer that stays zero elsewhere, so only the
                 # slice is written each step (no memset launch)
                 g_base = self._g_state_base
@@ -1191,13 +1199,20 @@ class SAC_Base(AuxHeadsMixin):
                 at_position = self._gru_backward_at and fused_gru.is_fused_top(base)
                 if not at_position:
                     torch.sum(g0, dim=0, out=g_base[:, t])
+            rep_stepped = False
             with direct_param_grads():
                 if at_position:
                     # the window IS a fused GRU's output: its backward sums the members' gradients itself and starts at
-                    # position t (the steps behind it only feed detached targets) — no member-sum launch in between
-                    fused_gru.backward_from_position(base, g0, t, g_base)
+                    # position t (the steps behind it only feed detached targets) — no member-sum launch in between;
+                    # where that GRU is all the representation has, the launch finishing its gradients steps it too
+                    rep_stepped = fused_gru.backward_from_position(base, g0, t, g_base,
+                                                                   adam=self._rep_adam_epilogue() if fold else None)
                 else:
                     torch.autograd.backward([base], [g_base])
+            if fold:
+                if not rep_stepped:
+                    self.optimizer_q_list[0].step(*self._params.span('rep'))
+                return
             return self._finish_rep_q(None, None)
         q_list = None
         if self.d_action_sizes:
@@ -1240,6 +1255,22 @@ class SAC_Base(AuxHeadsMixin):
         return self._finish_rep_q(loss_q_list.sum(), loss_q_list[0], aux,
                                   dict(n_padding_masks=n_padding_masks, nx_obses_list=nx_obses_list,
                                        nx_states=nx_states, nx_actions=nx_actions, n_rewards=n_rewards))
+
+    def _rep_adam_epilogue(self):
+        """-> `native.adam_epilogue` for the representation's parameters when they are exactly one fused GRU layer's
+        cell weights (then the launch that finishes their gradients can step them), else None"""
+        if self._rep_epilogue is False:
+            self._rep_epilogue = None
+            from .nn_models.layers.seq_layers import GRU
+            grus = [m for m in self.model_rep.modules() if isinstance(m, GRU)]
+            opt, (s, e) = self.optimizer_q_list[0], self._params.span('rep')
+            if (len(grus) == 1 and grus[0]._fusable and self.optimizer_rep is not None and e > s
+                    and {id(p) for p in grus[0].parameters()} == {id(p) for p in self.model_rep.parameters()}):
+                g = self._params
+                self._rep_epilogue = native.adam_epilogue(g.flat[s:e], g.grad[s:e], opt.exp_avg[s:e], opt.exp_avg_sq[s:e],
+                                                          self.optimizer_rep.lr, *self.optimizer_rep.betas,
+                                                          self.optimizer_rep.eps, opt.steps_done)
+        return self._rep_epilogue
 
     def _finish_rep_q(self, total_loss, loss_q0, aux=None, ctx=None):
         if total_loss is not None:

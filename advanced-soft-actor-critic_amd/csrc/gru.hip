@@ -31,6 +31,7 @@
 //     in block order (deterministic, no float atomics).
 // Sizes: input, hidden <= 16, layers <= 2 (register budget); larger cells use the generic path.
 #include "asac_common.h"
+#include "asac_sidecar.h"
 
 #include <cmath>
 
@@ -790,6 +791,14 @@ struct GruGradDst {
     float* dst[4 * kGruMaxLayers];         // per tensor: w_ih, w_hh, b_ih, b_hh of layer 0, 1, ...
     int64_t start[4 * kGruMaxLayers + 1];  // packed offsets of the tensors
     int32_t n_dst, accumulate;
+    // optimizer epilogue (asac_adam_epilogue_t): the finished gradient's parameter is stepped by the lane that summed it
+    int32_t adam_on;
+    float* adam_param;
+    const float* adam_grad;
+    float* adam_m;
+    float* adam_v;
+    AdamScalars adam_c;
+    const int64_t* adam_steps;
 };
 
 // 64 parameters per workgroup; wave s of the 16 sums a contiguous slice of the workgroups' partials (coalesced
@@ -803,6 +812,22 @@ __global__ __launch_bounds__(64 * kReduceSlices) void k_gru_reduce(const float* 
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
     const int per = (blocks + kReduceSlices - 1) / kReduceSlices;
     const int lo = sl * per, hi = min(lo + per, blocks);
+    // (epilogue: this lane's destination, its parameter and moments are requested with the partials, not behind them)
+    const bool owner = sl == 0 && i < n && !g.packed;
+    float* d = nullptr;
+    float d_old = 0.f, pv = 0.f, mv = 0.f, vv = 0.f;
+    int64_t off = 0, done = 0;
+    if (owner) {
+        int k = 0;
+        while (k + 1 < g.n_dst && i >= g.start[k + 1]) ++k;
+        d = g.dst[k] + (i - g.start[k]);
+        if (g.accumulate) d_old = *d;
+        if (g.adam_on) {
+            off = d - g.adam_grad;
+            pv = g.adam_param[off], mv = g.adam_m[off], vv = g.adam_v[off];
+            done = *g.adam_steps;
+        }
+    }
     float s = 0.f;
     if (i < n) {
         int bk = lo;
@@ -825,10 +850,14 @@ __global__ __launch_bounds__(64 * kReduceSlices) void k_gru_reduce(const float* 
         g.packed[i] = s;
         return;
     }
-    int k = 0;
-    while (k + 1 < g.n_dst && i >= g.start[k + 1]) ++k;
-    float* d = g.dst[k] + (i - g.start[k]);
-    *d = g.accumulate ? *d + s : s;
+    s = g.accumulate ? d_old + s : s;
+    *d = s;
+    if (g.adam_on) {
+        float step_size, bc2_sqrt;
+        adam_bias_terms(g.adam_c, done, &step_size, &bc2_sqrt);
+        adam1(pv, s, mv, vv, g.adam_c, step_size, bc2_sqrt);
+        g.adam_param[off] = pv, g.adam_m[off] = mv, g.adam_v[off] = vv;
+    }
 }
 
 constexpr size_t kGruLdsLimit = 128 * 1024;     // of the CU's 160 KB; one workgroup per CU is plenty here
@@ -964,9 +993,11 @@ static int gru_backward_launch(const char* where, const asac_gru_desc_t* desc, c
                                const float* hn, const float* gates, const float* grad_hn, const float* grad_top,
                                const float* grad_top_members, int members, int position, float* grad_x,
                                float* grad_h0, float* grad_params, float* const* grad_param_tensors, int accumulate,
-                               float* workspace, void* stream) {
+                               const asac_adam_epilogue_t* adam, float* workspace, void* stream) {
     if (!desc || !gru_desc_ok(*desc) || B <= 0 || L <= 0 || !x || !hn || !gates || !workspace ||
-        (!grad_params == !grad_param_tensors))
+        (!grad_params == !grad_param_tensors) || (adam && !grad_param_tensors))
+        return bad_arg(where);
+    if (adam && !(adam->param_base && adam->grad_base && adam->exp_avg_base && adam->exp_avg_sq_base && adam->steps_done))
         return bad_arg(where);
     GruArgs a{};
     a.d = *desc;
@@ -1021,6 +1052,15 @@ static int gru_backward_launch(const char* where, const asac_gru_desc_t* desc, c
         }
         g.start[g.n_dst] = off;
     }
+    if (adam) {
+        g.adam_on = 1;
+        g.adam_param = adam->param_base;
+        g.adam_grad = adam->grad_base;
+        g.adam_m = adam->exp_avg_base;
+        g.adam_v = adam->exp_avg_sq_base;
+        g.adam_c = adam_scalars(adam->lr, adam->beta1, adam->beta2, adam->eps);
+        g.adam_steps = adam->steps_done;
+    }
     // launched once (not under the repeat knob: it may accumulate)
     hipLaunchKernelGGL(k_gru_reduce, dim3((unsigned)((a.param_count + 63) / 64)), dim3(64 * kReduceSlices), 0, s, workspace,
                        blocks, a.param_count, g);
@@ -1036,7 +1076,7 @@ int asac_gru_backward(const asac_gru_desc_t* desc, const float* const* w_ih, con
                       void* stream) {
     return gru_backward_launch("asac_gru_backward", desc, w_ih, w_hh, b_ih, b_hh, x, x_stride_b, x_stride_t, h0,
                                h0_stride_b, padding_mask, mask_stride_b, B, L, hn, gates, grad_hn, grad_top, nullptr, 0,
-                               0, grad_x, grad_h0, grad_params, grad_param_tensors, accumulate, workspace, stream);
+                               0, grad_x, grad_h0, grad_params, grad_param_tensors, accumulate, nullptr, workspace, stream);
 }
 
 int asac_gru_backward_at(const asac_gru_desc_t* desc, const float* const* w_ih, const float* const* w_hh,
@@ -1044,13 +1084,13 @@ int asac_gru_backward_at(const asac_gru_desc_t* desc, const float* const* w_ih, 
                          int64_t x_stride_t, const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask,
                          int64_t mask_stride_b, int B, int L, const float* hn, const float* gates,
                          const float* grad_top_members, int members, int position, float* grad_x, float* grad_h0,
-                         float* grad_params, float* const* grad_param_tensors, int accumulate, float* workspace,
-                         void* stream) {
+                         float* grad_params, float* const* grad_param_tensors, int accumulate,
+                         const asac_adam_epilogue_t* adam, float* workspace, void* stream) {
     if (!grad_top_members || members <= 0 || position < 0 || position >= L) return bad_arg("asac_gru_backward_at");
     return gru_backward_launch("asac_gru_backward_at", desc, w_ih, w_hh, b_ih, b_hh, x, x_stride_b, x_stride_t, h0,
                                h0_stride_b, padding_mask, mask_stride_b, B, L, hn, gates, nullptr, nullptr,
                                grad_top_members, members, position, grad_x, grad_h0, grad_params, grad_param_tensors,
-                               accumulate, workspace, stream);
+                               accumulate, adam, workspace, stream);
 }
 
 }  // extern "C"

@@ -31,6 +31,25 @@ class GatherKey(C.Structure):
                 ('convert', C.c_int32), ('dst_row_pitch', C.c_int32), ('reserved_', C.c_int32)]
 
 
+class AdamEpilogue(C.Structure):
+    _fields_ = [('param_base', C.c_void_p), ('grad_base', C.c_void_p), ('exp_avg_base', C.c_void_p),
+                ('exp_avg_sq_base', C.c_void_p), ('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float),
+                ('eps', C.c_float), ('steps_done', C.c_void_p)]
+
+
+def adam_epilogue(param_flat, grad_flat, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, steps_done) -> AdamEpilogue:
+    """The optimizer step a gradient-finishing launch takes itself (`asac_adam_epilogue_t`): flat buffers of one
+    layout; the gradients the launch writes must be views of `grad_flat`."""
+    for t in (param_flat, grad_flat, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == param_flat.numel()
+    assert steps_done.dtype == torch.int64 and steps_done.is_cuda
+    ep = AdamEpilogue(param_flat.data_ptr(), grad_flat.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                      float(lr), float(beta1), float(beta2), float(eps), steps_done.data_ptr())
+    ep._keep = (param_flat, grad_flat, exp_avg, exp_avg_sq, steps_done)
+    ep._span = (grad_flat.data_ptr(), grad_flat.data_ptr() + 4 * grad_flat.numel())
+    return ep
+
+
 ROW_ITEM, ROW_SLOT, ROW_SLOT_ROW, ROW_BROADCAST = 0, 1, 2, 3
 
 
@@ -270,7 +289,7 @@ _SIGNATURES = {
     'asac_gru_backward_at': (C.c_int, [C.POINTER(GruDesc), _PtrArray, _PtrArray, _PtrArray, _PtrArray, C.c_void_p,
                                        C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_policy_loss_fwd_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -1246,9 +1265,10 @@ def gru_backward(desc, weights, x, h0, padding_mask, hn, gates, grad_hn, grad_to
 
 @_profiled
 def gru_backward_at(desc, weights, x, h0, padding_mask, hn, gates, grad_top_members, position, grad_x, grad_h0,
-                    grad_params, grad_tensors, accumulate, workspace):
+                    grad_params, grad_tensors, accumulate, workspace, adam=None):
     """`gru_backward` for an output gradient that lives at ONE window position: grad_top_members [E, B, H] are the
-    ensemble members' gradients of out_top[:, position] (summed inside the launch); the recursion starts there."""
+    ensemble members' gradients of out_top[:, position] (summed inside the launch); the recursion starts there.
+    `adam` (`adam_epilogue`, with `grad_tensors`): the launch that finishes the gradients also steps those parameters."""
     wi, wh, bi, bh = _gru_ptrs(weights, desc)
     px, sb, st = _gru_x(x)
     pm, ms = _gru_mask(padding_mask)
@@ -1256,9 +1276,16 @@ def gru_backward_at(desc, weights, x, h0, padding_mask, hn, gates, grad_top_memb
     m = grad_top_members
     assert m.dim() == 3 and m.is_contiguous() and m.dtype == torch.float32 and m.shape[1:] == (x.shape[0], desc.hidden)
     gt = _gru_grad_ptrs(grad_tensors, desc)
+    if adam is not None:
+        assert grad_tensors is not None
+        for l in range(desc.layers):
+            for t in grad_tensors[l]:
+                assert adam._span[0] <= t.data_ptr() and t.data_ptr() + 4 * t.numel() <= adam._span[1], \
+                    'adam epilogue: a gradient tensor outside the flat gradient buffer'
     _check(load().asac_gru_backward_at(C.byref(desc), wi, wh, bi, bh, px, sb, st, ph, hs, pm, ms, x.shape[0],
                                        x.shape[1], _p(hn), _p(gates), _p(m), m.shape[0], int(position), _p(grad_x),
-                                       _p(grad_h0), _p(grad_params), gt, int(bool(accumulate)), _p(workspace),
+                                       _p(grad_h0), _p(grad_params), gt, int(bool(accumulate)),
+                                       C.byref(adam) if adam is not None else None, _p(workspace),
                                        _stream()), 'asac_gru_backward_at')
 
 

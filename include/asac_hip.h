@@ -712,14 +712,25 @@ int asac_gru_backward(const asac_gru_desc_t* desc_host, const float* const* w_ih
  * sum_e grad_top_members[e][b][:] (summed in member order) at `position` and zero elsewhere, grad_hn is zero — the
  * values asac_gru_backward returns for that dense gradient, bit for bit, but the recursion starts AT the position
  * (the steps behind it carry zeros) and no [B][L][H] gradient tensor is formed or read.
- *   grad_top_members [members][B][H];  0 <= position < L;  grad_x (when asked for) is zero behind the position. */
+ *   grad_top_members [members][B][H];  0 <= position < L;  grad_x (when asked for) is zero behind the position.
+ *   adam (may be NULL; grad_param_tensors form only): the launch that finishes the parameter gradients also takes the
+ *   optimizer step of those parameters — the representation's `optimizer_rep.step()` (sac_base.py:1601-1603) without a
+ *   launch of its own. */
+typedef struct {
+    float* param_base;          /* the parameter whose gradient is grad_base[k] is param_base[k] ...             */
+    const float* grad_base;     /* ... (the learner's flat buffers: every grad_param_tensors entry points inside) */
+    float* exp_avg_base;        /* Adam moments at the same offsets                                              */
+    float* exp_avg_sq_base;
+    float lr, beta1, beta2, eps;
+    const int64_t* steps_done;  /* device counter; the update uses step *steps_done + 1 and does not advance it  */
+} asac_adam_epilogue_t;
 int asac_gru_backward_at(const asac_gru_desc_t* desc_host, const float* const* w_ih, const float* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh, const float* x,
                          int64_t x_stride_b, int64_t x_stride_t, const float* h0, int64_t h0_stride_b,
                          const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, const float* hn,
                          const float* gates, const float* grad_top_members, int members, int position,
                          float* grad_x, float* grad_h0, float* grad_params, float* const* grad_param_tensors,
-                         int accumulate, float* workspace, void* stream);
+                         int accumulate, const asac_adam_epilogue_t* adam, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused two-layer convolution stack: Conv2d(C->out1, kernel1, stride1) GELU Conv2d(out1->out2, kernel2,

@@ -265,3 +265,47 @@ def test_autograd_route_of_backward_from_position():
             torch.autograd.backward([top], [dense])
         grads.append([p.grad.clone() for p in dev.parameters()])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+def test_adam_epilogue_of_the_gradient_reduction_equals_a_separate_adam_launch():
+    """`asac_gru_backward_at(..., adam)`: the launch that finishes the cell parameters' gradients steps them —
+    parameters, moments and gradients bit-equal to the same launch followed by `asac_adam_step` over the flat buffers."""
+    from asac_amd import native
+    I, H, layers, B, L, position = 8, 8, 2, 96, 21, 9
+    _, dev = _layers(I, H, layers)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, I, generator=gen).cuda()
+    members = torch.randn(2, B, H, generator=gen).cuda()
+    desc = native.gru_desc(I, H, layers)
+    n = native.gru_param_count(desc)
+    cells = [[getattr(c, k).detach() for k in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')] for c in dev._grus]
+    steps = torch.full((1,), 6, dtype=torch.int64, device='cuda')
+    results = []
+    for fused in (True, False):
+        flat, grad = torch.zeros(n + 5, device='cuda'), torch.full((n + 5,), 0.25, device='cuda')
+        m, v = torch.full((n + 5,), 0.01, device='cuda'), torch.full((n + 5,), 0.002, device='cuda')
+        w, gt, off = [], [], 3                         # the cells' tensors as views of flat buffers, 3 floats in
+        for cell in cells:
+            ws_, gs_ = [], []
+            for t in cell:
+                k = t.numel()
+                flat[off:off + k] = t.reshape(-1)
+                ws_.append(flat[off:off + k].view(t.shape))
+                gs_.append(grad[off:off + k].view(t.shape))
+                off += k
+            w.append(tuple(ws_))
+            gt.append(tuple(gs_))
+        hn = torch.empty(B, L, layers, H, device='cuda')
+        gates = torch.empty(B, L, layers, 5 * H, device='cuda')
+        native.gru_forward(desc, w, x, None, None, hn, None, gates)
+        ws = torch.empty(native.gru_backward_workspace(desc, B), device='cuda')
+        ep = native.adam_epilogue(flat, grad, m, v, 3e-4, 0.9, 0.999, 1e-8, steps) if fused else None
+        native.gru_backward_at(desc, w, x, None, None, hn, gates, members, position, None, None, None, gt, True, ws, adam=ep)
+        if not fused:
+            native.adam_step(flat[3:3 + n], grad[3:3 + n], m[3:3 + n], v[3:3 + n], 3e-4, 0.9, 0.999, 1e-8, steps)
+        torch.cuda.synchronize()
+        results.append((flat.clone(), grad.clone(), m.clone(), v.clone()))
+    for name, a, b in zip(('param', 'grad', 'exp_avg', 'exp_avg_sq'), *results):
+        assert torch.equal(a[3:3 + n], b[3:3 + n]), name
+        assert torch.equal(a[:3], b[:3]) and torch.equal(a[3 + n:], b[3 + n:]), name
+    assert int(steps.item()) == 6 and not torch.equal(results[0][0][3:3 + n], torch.cat([t.reshape(-1) for c in cells for t in c]))
