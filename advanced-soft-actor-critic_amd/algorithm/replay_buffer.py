@@ -107,7 +107,7 @@ class PrioritizedReplayBuffer:
         self._columns: dict[str, torch.Tensor] | None = None   # key -> ring [C, *shape]
         self._batch: dict[str, torch.Tensor] | None = None     # key -> [B, L, *shape]
         self._gather_keys = None
-        self._join_action_width, self.joint_pre_action = None, None
+        self._join_action_width, self.joint_pre_action, self.derived = None, None, None
         self._size = 0
         self._next_id = 0
 
@@ -200,9 +200,11 @@ class PrioritizedReplayBuffer:
         """Lay the static batch's vector observations out as column blocks of ONE [B, L, sum(widths) + action_width]
         tensor whose last block (`joint_pre_action`) the learner fills with the previous actions: the concatenation a
         recurrent representation starts with (reference envs/*/nn*.py: `torch.cat([obs, pre_action], dim=-1)`) then
-        already exists in memory and `adjacent_cat.AdjacentCat` hands it out as a view.  None: dense tensors per key."""
+        already exists in memory and `adjacent_cat.AdjacentCat` hands it out as a view.  The gather then also delivers the
+        representation's derived window inputs (`derived`: index_x, padding_mask_x, pre_action — SAC_Base.get_bnx_data,
+        reference sac_base.py:1090-1115) as derived keys of the same launch.  None: dense tensors per key, no derived keys."""
         self._join_action_width = action_width
-        self._batch, self._gather_keys, self.joint_pre_action = None, None, None
+        self._batch, self._gather_keys, self.joint_pre_action, self.derived = None, None, None, None
 
     def _out_kind(self, k, col, pad):
         if pad and k.startswith('obs_') and col.dtype in (torch.uint8, torch.bool):
@@ -261,6 +263,21 @@ class PrioritizedReplayBuffer:
         if pad:
             batch['padding_mask'] = torch.zeros((n, L), dtype=torch.bool, device=dev)
             specs.append(dict(src=None, dst=batch['padding_mask'], pad_mode=native.PAD_EMIT_MASK))
+        if (joined and pad and self._join_action_width and L >= 2 and 'index' in self._columns
+                and 'action' in self._columns and self._columns['action'].dtype == torch.float32
+                and tuple(self._columns['action'].shape[1:]) == (self._join_action_width,)
+                and len(specs) + 3 <= native.MAX_GATHER_KEYS):
+            A = self._join_action_width
+            pre = self.joint_pre_action if joint is not None else torch.zeros((n, L, A), dtype=torch.float32, device=dev)
+            self.derived = dict(index_x=torch.zeros((n, L), dtype=torch.int32, device=dev),
+                                padding_mask_x=torch.zeros((n, L), dtype=torch.bool, device=dev), pre_action=pre)
+            specs.append(dict(src=self._columns['index'], dst=self.derived['index_x'], row_bytes=4, pad_mode=native.PAD_WORD,
+                              pad_word=0xffffffff, derive=native.DERIVE_HOLD_LAST_NEXT))
+            specs.append(dict(src=None, dst=self.derived['padding_mask_x'], pad_mode=native.PAD_EMIT_MASK,
+                              derive=native.DERIVE_HOLD_LAST))
+            specs.append(dict(src=self._columns['action'], dst=pre, row_bytes=4 * A, pad_mode=native.PAD_ROW,
+                              pad_row=self._pad_action, derive=native.DERIVE_PREVIOUS,
+                              dst_row_pitch=pre.stride(1) * 4 if joint is not None else 0))
         assert len(specs) <= native.MAX_GATHER_KEYS, 'too many transition keys for one gather launch'
         return batch, specs
 

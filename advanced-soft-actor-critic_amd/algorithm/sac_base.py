@@ -1696,8 +1696,13 @@ class SAC_Base(AuxHeadsMixin):
             # the stock concatenation rep ignores index / mask / previous actions: do not build them
             w.rep_in = (None, None, w.bnx_obses_list, None, w.bnx_hidden)
         else:
-            bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(
-                w.bn_indexes, w.bn_pad, w.bn_actions, pre_action_out=rb.joint_pre_action)
+            if rb.derived is not None and rb.sharded is None:
+                # (the gather delivered them as derived keys of its launch: no `asac_window_aux`)
+                d = rb.derived
+                bnx_indexes, bnx_padding_masks, bnx_pre_actions = d['index_x'], d['padding_mask_x'], d['pre_action']
+            else:
+                bnx_indexes, bnx_padding_masks, bnx_pre_actions = self.get_bnx_data(
+                    w.bn_indexes, w.bn_pad, w.bn_actions, pre_action_out=rb.joint_pre_action)
             w.rep_in = (bnx_indexes, bnx_padding_masks, w.bnx_obses_list, bnx_pre_actions, w.bnx_hidden)
         return w
 

@@ -33,6 +33,7 @@ struct GatherKeyDev {
     int32_t units_per_row;
     uint32_t first_block;    // prefix sum of blocks over the keys
     int32_t dst_pitch;       // bytes between destination rows (dense: the output row's size)
+    int32_t derive;          // ASAC_DERIVE_*: the window row a destination row is taken from
 };
 
 struct GatherArgs {          // what every key's blocks share
@@ -80,6 +81,19 @@ __device__ __forceinline__ uint8_t pad_value<uint8_t>(const GatherKeyDev& k, int
     return (uint8_t)(k.pad_word & 0xff);
 }
 
+// Derived keys (ASAC_DERIVE_*): destination row j of the window is the key's padded row `src_row(j)`; the first row of a
+// PREVIOUS key is zeros, the last row of a HOLD_LAST_NEXT key (an i32 column: the step index) counts one further unless
+// it is the padding value -1 — SAC_Base.get_bnx_data (sac_base.py:1090-1115) formed inside the gather.
+__device__ __forceinline__ int derived_row(int derive, int j, int L) {
+    if (derive == ASAC_DERIVE_PREVIOUS) return j > 0 ? j - 1 : 0;
+    if (derive >= ASAC_DERIVE_HOLD_LAST) return min(j, L - 2);
+    return j;
+}
+template <typename Unit> __device__ __forceinline__ Unit zero_unit() { return Unit(0); }
+template <> __device__ __forceinline__ uint4 zero_unit<uint4>() { return make_uint4(0, 0, 0, 0); }
+template <typename Unit> __device__ __forceinline__ Unit next_index(Unit v) { return v; }
+template <> __device__ __forceinline__ uint32_t next_index<uint32_t>(uint32_t v) { return v + (v != 0xffffffffu ? 1u : 0u); }
+
 template <typename Unit, int kUnroll>
 __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                            int64_t total_units) {
@@ -101,10 +115,13 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
         // the row is read whether or not it turns out to belong to the centre row's episode (the slot is always a
         // valid address): the validity test's own loads — random reads of the index ring — travel WITH the data
         // instead of in front of it
-        const int slot = ring_slot(id + (j - a.prev_n), a.capacity);
+        const int js = derived_row(k.derive, j, a.L);
+        const int slot = ring_slot(id + (js - a.prev_n), a.capacity);
         const Unit data = reinterpret_cast<const Unit*>(k.src + (int64_t)slot * k.row_bytes)[w];
-        const bool valid = (k.pad_mode == ASAC_PAD_KEEP) || row_valid(a, id, j);
+        const bool valid = (k.pad_mode == ASAC_PAD_KEEP) || row_valid(a, id, js);
         val[r] = valid ? data : pad_value<Unit>(k, w);
+        if (k.derive == ASAC_DERIVE_PREVIOUS && j == 0) val[r] = zero_unit<Unit>();
+        if (k.derive == ASAC_DERIVE_HOLD_LAST_NEXT && j == a.L - 1) val[r] = next_index<Unit>(val[r]);
     }
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r)
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const Gather
             if (g >= rows) continue;
             const int sample = (int)(g / a.L);
             const int j = (int)(g - (int64_t)sample * a.L);
-            k.dst[g] = row_valid(a, a.ids[sample], j) ? 0 : 1;
+            k.dst[g] = row_valid(a, a.ids[sample], derived_row(k.derive, j, a.L)) ? 0 : 1;
         }
         return;
     }
@@ -260,6 +277,11 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
         d.convert = h.convert;
         const int out_row_bytes = h.convert != ASAC_CVT_NONE ? 4 * h.row_bytes : h.row_bytes;
         d.dst_pitch = h.dst_row_pitch ? h.dst_row_pitch : out_row_bytes;
+        d.derive = h.derive;
+        if (h.derive < ASAC_DERIVE_NONE || h.derive > ASAC_DERIVE_HOLD_LAST_NEXT ||
+            (h.derive != ASAC_DERIVE_NONE && (h.convert != ASAC_CVT_NONE || a.L < 2)) ||
+            (h.derive == ASAC_DERIVE_HOLD_LAST_NEXT && (h.row_bytes != 4 || h.pad_mode == ASAC_PAD_EMIT_MASK)))
+            return bad_arg("asac_window_gather_pad: derived key");
         if (h.pad_mode == ASAC_PAD_EMIT_MASK) {
             if (h.dst_row_pitch) return bad_arg("asac_window_gather_pad: the mask is dense");
             d.unit_log2 = 0;

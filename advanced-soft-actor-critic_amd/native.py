@@ -28,7 +28,7 @@ class AsacNativeError(RuntimeError):
 class GatherKey(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('pad_row', C.c_void_p),
                 ('row_bytes', C.c_int32), ('pad_mode', C.c_int32), ('pad_word', C.c_uint32),
-                ('convert', C.c_int32), ('dst_row_pitch', C.c_int32), ('reserved_', C.c_int32)]
+                ('convert', C.c_int32), ('dst_row_pitch', C.c_int32), ('derive', C.c_int32)]
 
 
 class AdamEpilogue(C.Structure):
@@ -51,6 +51,7 @@ def adam_epilogue(param_flat, grad_flat, exp_avg, exp_avg_sq, lr, beta1, beta2, 
 
 
 ROW_ITEM, ROW_SLOT, ROW_SLOT_ROW, ROW_BROADCAST = 0, 1, 2, 3
+DERIVE_NONE, DERIVE_PREVIOUS, DERIVE_HOLD_LAST, DERIVE_HOLD_LAST_NEXT = 0, 1, 2, 3
 
 
 class RowMove(C.Structure):
@@ -553,6 +554,7 @@ def make_gather_keys(specs):
         k.pad_word = int(s.get('pad_word', 0)) & 0xffffffff
         k.convert = int(s.get('convert', 0))
         k.dst_row_pitch = int(s.get('dst_row_pitch', 0))
+        k.derive = int(s.get('derive', 0))
     return arr
 
 

@@ -157,6 +157,14 @@ enum {
     ASAC_CVT_U8_TO_F32_UNIT = 1, /* uint8 -> f32 / 255  (sac_base.py:783-786) */
     ASAC_CVT_BOOL_TO_F32 = 2     /* bool  -> f32        (sac_base.py:787-788) */
 };
+/* Derived keys: a sequence representation is fed the window's step indexes, padding mask and PREVIOUS actions
+ * extended / shifted by one row (SAC_Base.get_bnx_data, sac_base.py:1090-1115; utils/operators.py gen_n_pre_actions);
+ * a key with `derive` set delivers that form straight from the ring — the padded window row it shows is
+ *   PREVIOUS         row j-1, zeros for j = 0                                  (pre_action from the action column)
+ *   HOLD_LAST        row min(j, L-2)                                           (the padding mask, ASAC_PAD_EMIT_MASK)
+ *   HOLD_LAST_NEXT   row min(j, L-2); at j = L-1 the i32 value + (value != -1)  (the step index)
+ * — the values asac_window_aux forms from the gathered window, without its launch.  L >= 2, no conversion. */
+enum { ASAC_DERIVE_NONE = 0, ASAC_DERIVE_PREVIOUS = 1, ASAC_DERIVE_HOLD_LAST = 2, ASAC_DERIVE_HOLD_LAST_NEXT = 3 };
 typedef struct {
     const void* src;     /* ring [C, row_bytes]                                                   */
     void* dst;           /* [batch, L, out_row_bytes]; out_row_bytes = row_bytes (x4 if converting) */
@@ -168,7 +176,7 @@ typedef struct {
     int32_t dst_row_pitch; /* bytes between destination rows; 0 = dense (out_row_bytes).  A wider pitch lets a key
                               land as a column block of a wider [batch, L, *] tensor: the vector observation beside
                               the previous action, the concatenation a recurrent representation starts with */
-    int32_t reserved_;
+    int32_t derive;        /* ASAC_DERIVE_*: which window row a destination row shows (0: its own)                */
 } asac_gather_key_t;
 
 /* K3: for every sampled id gather the rows id-prev_n .. id+post_n of every key (ring slot =

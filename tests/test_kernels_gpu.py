@@ -701,6 +701,15 @@ def test_replay_window_lands_beside_the_previous_actions(nat):
         assert torch.equal(batch_d[k], batch_j[k]), k
     vec, flag, pre = batch_j['obs_vec'], batch_j['obs_flag'], joined.joint_pre_action
     assert pre.shape == (32, 8, 3) and flag.dtype == torch.float32 and not vec.is_contiguous()
+    # the derived keys of the same launch == `asac_window_aux` on the gathered window (SAC_Base.get_bnx_data)
+    d = joined.derived
+    assert d is not None and d['pre_action'].data_ptr() == pre.data_ptr()
+    want_i = torch.empty(32, 8, dtype=torch.int32, device='cuda')
+    want_p = torch.empty(32, 8, dtype=torch.bool, device='cuda')
+    want_a = torch.empty(32, 8, 3, device='cuda')
+    nat.window_aux(batch_j['index'][:, :-1], batch_j['padding_mask'][:, :-1], batch_j['action'][:, :-1], want_i, want_p, want_a)
+    assert bool(batch_j['padding_mask'].any()) and bool((batch_j['index'][:, -2] == -1).any())   # (padded rows exist)
+    assert torch.equal(d['index_x'], want_i) and torch.equal(d['padding_mask_x'], want_p) and torch.equal(pre, want_a)
     pre.copy_(torch.randn(32, 8, 3, device='cuda'))
     want = torch.cat([vec, flag, pre], dim=-1)
     view = joined_view([vec, flag, pre], -1)
