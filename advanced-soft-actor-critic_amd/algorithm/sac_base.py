@@ -235,6 +235,7 @@ class SAC_Base(AuxHeadsMixin):
         self._gru_backward_at = bool(hip_config.get('gru_backward_at', True))
         self._adjacent_cat = bool(hip_config.get('adjacent_cat', True))
         self._fold_rep_q_adam = bool(hip_config.get('fold_rep_q_adam', True))
+        self._rep_grad_one_position = bool(hip_config.get('rep_grad_one_position', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
         self._g_state_base = None
@@ -551,9 +552,10 @@ class SAC_Base(AuxHeadsMixin):
         self.replay_buffer.set_window_padding(self._padding_action)
         self.replay_buffer.uniform_source = self.noise
         self._cat_mode = None
-        if self._adjacent_cat and self.seq_encoder is not None and type(self.model_rep) is not ModelSimpleRep:
-            # a sequence representation receives (obs, previous actions): keep them side by side in the static batch so
-            # that the concatenation such modules start with is a view (adjacent_cat.py)
+        if self._adjacent_cat and type(self.model_rep) is not ModelSimpleRep:
+            # a user representation receives (obs, previous actions): keep them side by side in the static batch so
+            # that the concatenation sequence modules start with is a view (adjacent_cat.py); the gather then also
+            # delivers the derived window inputs (index_x, padding_mask_x, pre_action) in its own launch
             from .adjacent_cat import AdjacentCat
             self.replay_buffer.join_vector_obs_with_pre_action(self.d_action_summed_size + self.c_action_size)
             self._cat_mode = AdjacentCat
@@ -1149,6 +1151,8 @@ class SAC_Base(AuxHeadsMixin):
         dsum = self.d_action_summed_size
         obs_list = [o[:, 0] for o in nx_obses_list]
         state, action = nx_states[:, 0], nx_actions[:, 0]
+        if state_base is not None and not nx_states.requires_grad:
+            state = state_base[0][:, state_base[1]]     # (`_step_rep_and_q`: the differentiable pass covered this position only)
         d_action, c_action = action[..., :dsum], action[..., dsum:]
 
         if (self._fused_q_state_grads and self._fq is not None and self._ftq is not None and not self.d_action_sizes
@@ -1711,19 +1715,35 @@ class SAC_Base(AuxHeadsMixin):
         again under the updated representation -> w.bnx_states, w.bnx_target_states, w.next_hidden"""
         b = self.burn_in_step
         cat_mode = self._cat_mode if self._cat_mode is not None else contextlib.nullcontext
+        with_aux = self.siamese is not None or self.use_prediction
+        # A representation without a sequence encoder maps every step on its own (it is handed single steps when
+        # acting), and the Q loss reads the state of ONE window position — everything else of the window only feeds
+        # detached targets.  The differentiable pass then covers that position's rows alone (B of B L frames: the
+        # backward of a convolution stack shrinks L-fold) beside a no-grad pass over the window.
+        one_position = (self._rep_grad_one_position and self.seq_encoder is None and w.rep_trainable and not with_aux
+                        and type(self.model_rep) is not ModelSimpleRep and w.bnx_actions.shape[1] > 1)
         with (self._rep_twin if self._rep_twin else contextlib.nullcontext()), cat_mode():
-            bnx_states, next_hidden = self.get_l_states(*w.rep_in, is_target=False)
+            with torch.no_grad() if one_position else contextlib.nullcontext():
+                bnx_states, next_hidden = self.get_l_states(*w.rep_in, is_target=False)
             with torch.no_grad():
                 w.bnx_target_states, _ = self.get_l_states(*w.rep_in, is_target=True)
+        state_base = (bnx_states, b)
+        if one_position:
+            at = lambda x: None if x is None else x[:, b:b + 1]  # noqa: E731
+            idx, pad, obs, pre, hidden = w.rep_in
+            with cat_mode():
+                state_b, _ = self.get_l_states(at(idx), at(pad), [o[:, b:b + 1] for o in obs], at(pre), at(hidden),
+                                               is_target=False)
+            state_base = (state_b, 0)
         aux = None
-        if self.siamese is not None or self.use_prediction:
+        if with_aux:
             aux = dict(n_indexes=w.bn_indexes[:, b:],
                        n_pre_actions=w.bn_actions[:, b - 1:-1] if b > 0 else w.bn_actions[:, 0:0],
                        n_pre_seq_hidden_states=w.bnx_hidden[:, b:-1], nx_target_states=w.bnx_target_states[:, b:])
         self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bnx_states[:, b:], w.bnx_actions[:, b:],
                           w.bn_rewards[:, b:], w.bn_dones[:, b:], w.bn_mu_probs[:, b:], w.priority_is, aux,
                           policy_sample=w.stock and not w.rep_trainable,
-                          state_base=(bnx_states, b))
+                          state_base=state_base)
         if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
             self.after_rep_q_update()
         if w.rep_trainable:   # states under the updated representation (reference 2097-2103)
