@@ -43,13 +43,93 @@ def joined_view(tensors, dim):
     return first.as_strided((*first.shape[:-1], width), first.stride(), offset)
 
 
+_materializing = False
+
+
+class DeferredCat:
+    """What `torch.cat([a, b], dim=-1)` WILL be, for a consumer that can read the two blocks where they are: the
+    plugin's `self.dense(torch.cat([vec, self.conv(img)], dim=-1))` with `dense` a fused Linear + Tanh head
+    (`fused_linear.LinearTanhHead`, two-input launch) never forms the concatenation — no `CatArrayBatchedCopy`
+    forward, no slice + copy of its gradient backward.  Anything else that touches the object (a torch function, a
+    method, an operator, an attribute) gets the real concatenation, formed once on first use."""
+    __slots__ = ('parts', 'width', '_value')
+
+    def __init__(self, parts):
+        self.parts, self._value = tuple(parts), None
+        self.width = sum(p.shape[-1] for p in parts)
+
+    def materialize(self) -> torch.Tensor:
+        global _materializing
+        if self._value is None:
+            _materializing = True
+            try:
+                self._value = torch.cat(self.parts, dim=-1)
+            finally:
+                _materializing = False
+        return self._value
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        real = lambda a: a.materialize() if isinstance(a, DeferredCat) else a  # noqa: E731
+
+        def walk(v):
+            if isinstance(v, (list, tuple)):
+                return type(v)(walk(i) for i in v)
+            if isinstance(v, dict):
+                return {k: walk(i) for k, i in v.items()}
+            return real(v)
+        return func(*walk(args), **walk(kwargs or {}))
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+
+def _forward_operator(name):
+    def op(self, *args, **kwargs):
+        return getattr(self.materialize(), name)(*args, **kwargs)
+    op.__name__ = name
+    return op
+
+
+for _name in ('__add__', '__radd__', '__sub__', '__rsub__', '__mul__', '__rmul__', '__truediv__', '__rtruediv__',
+              '__matmul__', '__rmatmul__', '__pow__', '__neg__', '__abs__', '__getitem__', '__len__', '__iter__',
+              '__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__', '__bool__', '__float__', '__int__',
+              '__repr__', '__format__'):
+    setattr(DeferredCat, _name, _forward_operator(_name))
+DeferredCat.__hash__ = object.__hash__
+
+
+def deferrable(tensors, dim, max_width) -> bool:
+    """two float32 device tensors with the same leading shape, concatenated along the last dim, narrow enough for the
+    fused head"""
+    if not isinstance(tensors, (list, tuple)) or len(tensors) != 2:
+        return False
+    a, b = tensors
+    if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)) or a.dim() < 2 or a.dim() != b.dim():
+        return False
+    if dim < 0:
+        dim += a.dim()
+    return (dim == a.dim() - 1 and a.shape[:-1] == b.shape[:-1] and a.is_cuda and b.is_cuda and a.device == b.device
+            and a.dtype == torch.float32 and b.dtype == torch.float32 and 0 < a.shape[-1] and 0 < b.shape[-1]
+            and a.shape[-1] + b.shape[-1] <= max_width)
+
+
 class AdjacentCat(TorchFunctionMode):
+    """`defer_width` > 0: a two-block last-dim concatenation up to that width that is not already a view comes back as a
+    `DeferredCat`"""
+
+    def __init__(self, defer_width: int = 0):
+        super().__init__()
+        self.defer_width = defer_width
+
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func in _CATS and args and 'out' not in kwargs:
+        if func in _CATS and args and 'out' not in kwargs and not _materializing:
             dim = kwargs.get('dim', kwargs.get('axis', args[1] if len(args) > 1 else 0))
             if isinstance(dim, int):
                 view = joined_view(args[0], dim)
                 if view is not None:
                     return view
+                if self.defer_width and deferrable(args[0], dim, self.defer_width):
+                    return DeferredCat(args[0])
         return func(*args, **kwargs)

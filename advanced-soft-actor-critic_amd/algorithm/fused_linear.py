@@ -18,40 +18,80 @@ _WORKSPACES = weakref.WeakKeyDictionary()
 FUSED_LINEAR_TANH = True      # module switch (tests compare against the module path)
 
 
+def _as_rows(x):
+    rows = x.reshape(-1, x.shape[-1])
+    return rows if rows.stride(1) == 1 else rows.contiguous()
+
+
+# `backward_from_members`: [the _LinearTanhFn node, members [E, B, O], window, position] while that node's backward is
+# the next to run
+_MEMBERS = None
+
+
+def is_fused_head_output(t: torch.Tensor) -> bool:
+    fn = t.grad_fn
+    return fn is not None and type(fn).__name__ == '_LinearTanhFnBackward'
+
+
+def backward_from_members(out, members, position, placeholder) -> None:
+    """Back-propagate d loss / d out[:, position] = sum_e members[e] (zero at the window's other positions) from the
+    fused head's own output `out` [B, L, O] (`is_fused_head_output`): the head's backward launch sums the members itself
+    (no member-sum launch, no dense [B, L, O] gradient read).  `placeholder`: any tensor of out's shape."""
+    global _MEMBERS
+    assert is_fused_head_output(out) and out.dim() == 3 and members.shape[1:] == (out.shape[0], out.shape[2])
+    _MEMBERS = [out.grad_fn, members.contiguous(), out.shape[1], int(position) % out.shape[1]]
+    try:
+        torch.autograd.backward([out], [placeholder])
+    finally:
+        _MEMBERS = None
+
+
 class _LinearTanhFn(torch.autograd.Function):
+    """x0 [..., K0] (| x1 [..., K1]: the two read side by side, `adjacent_cat.DeferredCat`) -> tanh(Linear)"""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, head):
-        rows = x.reshape(-1, x.shape[-1])
-        if rows.stride(1) != 1:
-            rows = rows.contiguous()
-        y = torch.empty(rows.shape[0], weight.shape[0], dtype=x.dtype, device=x.device)
-        native.linear_tanh_forward(rows, weight.detach(), bias.detach(), y)
-        ctx.save_for_backward(rows, y)
-        ctx.weight, ctx.bias, ctx.head, ctx.x_shape = weight, bias, head, x.shape
-        return y.view(*x.shape[:-1], weight.shape[0])
+    def forward(ctx, x0, x1, weight, bias, head):
+        r0 = _as_rows(x0)
+        r1 = None if x1 is None else _as_rows(x1)
+        y = torch.empty(r0.shape[0], weight.shape[0], dtype=x0.dtype, device=x0.device)
+        native.linear_tanh_forward2(r0, r1, weight.detach(), bias.detach(), y)
+        ctx.save_for_backward(r0, y, *([] if r1 is None else [r1]))
+        ctx.weight, ctx.bias, ctx.head = weight, bias, head
+        ctx.x0_shape, ctx.x1_shape = x0.shape, None if x1 is None else x1.shape
+        return y.view(*x0.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, grad_y):
-        rows, y = ctx.saved_tensors
+        r0, y, *rest = ctx.saved_tensors
+        r1 = rest[0] if rest else None
         weight, bias = ctx.weight, ctx.bias
-        N, K = rows.shape
+        N, K0 = r0.shape
+        K = K0 + (0 if r1 is None else r1.shape[1])
         O = weight.shape[0]
-        gy = grad_y.reshape(N, O)
-        gy = gy if gy.is_contiguous() else gy.contiguous()
-        gx = torch.empty(N, K, dtype=rows.dtype, device=rows.device) if ctx.needs_input_grad[0] else None
-        ws = ctx.head._workspace(N, K, O, rows.device)
+        at = _MEMBERS if (_MEMBERS is not None and _MEMBERS[0] is ctx) else None
+        assert _MEMBERS is None or at is not None, 'backward_from_members: another node ran first'
+        if at is not None:
+            gy, members, window, position = at[1], at[1].shape[0], at[2], at[3]
+        else:
+            gy, members, window, position = grad_y.reshape(N, O), 1, 1, 0
+            gy = gy if gy.is_contiguous() else gy.contiguous()
+        empty = lambda k: torch.empty(N, k, dtype=r0.dtype, device=r0.device)  # noqa: E731
+        gx0 = empty(K0) if ctx.needs_input_grad[0] else None
+        gx1 = empty(K - K0) if (r1 is not None and ctx.needs_input_grad[1]) else None
+        ws = ctx.head._workspace(N, K, O, r0.device)
         flat = None
         if (direct_enabled() and weight.requires_grad and bias.requires_grad and weight.grad is not None
                 and bias.grad is not None):
             flat = _flat_alias([weight.grad, bias.grad])     # the learner's flat gradient buffer: add in place
         if flat is not None:
-            native.linear_tanh_backward(rows, weight.detach(), y, gy, gx, flat, True, ws)
+            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, flat, True, ws, members, window, position)
             gw = gb = None
         else:
-            g = torch.empty(O * K + O, dtype=rows.dtype, device=rows.device)
-            native.linear_tanh_backward(rows, weight.detach(), y, gy, gx, g, False, ws)
+            g = torch.empty(O * K + O, dtype=r0.dtype, device=r0.device)
+            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, g, False, ws, members, window, position)
             gw, gb = g[:O * K].view(O, K), g[O * K:]
-        return (None if gx is None else gx.view(ctx.x_shape)), gw, gb, None
+        return (None if gx0 is None else gx0.view(ctx.x0_shape), None if gx1 is None else gx1.view(ctx.x1_shape),
+                gw, gb, None)
 
 
 class LinearTanhHead(nn.Sequential):
@@ -67,10 +107,17 @@ class LinearTanhHead(nn.Sequential):
         return cache[key]
 
     def forward(self, x):
+        from .adjacent_cat import DeferredCat
         lin = self[0]
+        x1 = None
+        if isinstance(x, DeferredCat):
+            if FUSED_LINEAR_TANH and len(x.parts) == 2 and x.width == lin.in_features and lin.weight.dtype == torch.float32:
+                x, x1 = x.parts                 # the two blocks are read where they are
+            else:
+                x = x.materialize()
         if (FUSED_LINEAR_TANH and x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32
-                and x.shape[-1] == lin.in_features and x.numel() > 0):
-            return _LinearTanhFn.apply(x, lin.weight, lin.bias, self)
+                and x.shape[-1] + (0 if x1 is None else x1.shape[-1]) == lin.in_features and x.numel() > 0):
+            return _LinearTanhFn.apply(x, x1, lin.weight, lin.bias, self)
         return super().forward(x)
 
 

@@ -33,7 +33,7 @@ from torch.nn import functional
 
 from asac_amd import native
 
-from . import fused_gru
+from . import fused_gru, fused_linear
 from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls
 from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
@@ -236,6 +236,8 @@ class SAC_Base(AuxHeadsMixin):
         self._adjacent_cat = bool(hip_config.get('adjacent_cat', True))
         self._fold_rep_q_adam = bool(hip_config.get('fold_rep_q_adam', True))
         self._rep_grad_one_position = bool(hip_config.get('rep_grad_one_position', True))
+        self._deferred_cat = bool(hip_config.get('deferred_cat', True))
+        self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
         self._g_state_base = None
@@ -558,7 +560,8 @@ class SAC_Base(AuxHeadsMixin):
             # delivers the derived window inputs (index_x, padding_mask_x, pre_action) in its own launch
             from .adjacent_cat import AdjacentCat
             self.replay_buffer.join_vector_obs_with_pre_action(self.d_action_summed_size + self.c_action_size)
-            self._cat_mode = AdjacentCat
+            width = native.LINEAR_TANH_MAX_IN if (self._deferred_cat and self._fuse_linear_tanh) else 0
+            self._cat_mode = lambda: AdjacentCat(width)
         if self._dist is not None and self._dist_sampling == 'parity':
             # SURVEY 8e "parity": every batch is the reference's stratified sample over the UNION of the ranks' shards
             # (global batch = world_size * batch_size, this rank trains on batch_size rows of it)
@@ -1201,7 +1204,8 @@ class SAC_Base(AuxHeadsMixin):
                 if g_base is None or g_base.shape != base.shape:
                     g_base = self._g_state_base = torch.zeros_like(base)
                 at_position = self._gru_backward_at and fused_gru.is_fused_top(base)
-                if not at_position:
+                from_head = not at_position and self._head_sums_members and fused_linear.is_fused_head_output(base)
+                if not (at_position or from_head):
                     torch.sum(g0, dim=0, out=g_base[:, t])
             rep_stepped = False
             with direct_param_grads():
@@ -1211,6 +1215,9 @@ class SAC_Base(AuxHeadsMixin):
                     # where that GRU is all the representation has, the launch finishing its gradients steps it too
                     rep_stepped = fused_gru.backward_from_position(base, g0, t, g_base,
                                                                    adam=self._rep_adam_epilogue() if fold else None)
+                elif from_head:
+                    # the window is a fused Linear + Tanh head's output: its backward launch sums the members
+                    fused_linear.backward_from_members(base, g0, t, g_base)
                 else:
                     torch.autograd.backward([base], [g_base])
             if fold:

@@ -18,15 +18,21 @@ constexpr int kLinMaxO = ASAC_LINEAR_TANH_MAX_OUT;     // 16
 constexpr int kLinRows = 128;                          // rows (= lanes) per workgroup
 
 struct LinArgs {
-    const float* x;
-    int64_t x_stride;
+    const float* x;         // the input rows: x [N][K0] | x1 [N][K - K0] side by side (x1 NULL: K0 == K) — the
+    int64_t x_stride;       // concatenation `torch.cat([a, b], -1)` the reference's plugins feed their heads, read in place
+    const float* x1;
+    int64_t x1_stride;
+    int K0;
     const float* w;         // [O][K]
     const float* b;         // [O]
     int64_t N;
     int K, O;
     float* y;               // [N][O]
-    const float* gy;        // [N][O]
-    float* gx;              // [N][K] or null
+    const float* gy;        // [members][N / gy_window][O]: the output gradient of row r is sum_e gy[e][r / gy_window] when
+    int gy_members;         // r % gy_window == gy_position and zero otherwise (members 1, window 1: a dense [N][O])
+    int gy_window, gy_position;
+    float* gx;              // [N][K0] or null
+    float* gx1;             // [N][K - K0] or null
     float* gp;              // W | b gradients, O*K + O
     int accumulate;
     float* partial;         // [blocks][O*(K+1)]
@@ -53,8 +59,9 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_fwd(const LinArgs a) {
 #pragma unroll
     for (int o = 0; o < kLinMaxO; ++o) acc[o] = 0.f;
     const float* xr = a.x + r * a.x_stride;
+    const float* xr1 = a.x1 ? a.x1 + r * a.x1_stride - a.K0 : xr;      // (indexed by k like the first part)
     for (int k = 0; k < a.K; ++k) {
-        const float xv = xr[k];
+        const float xv = k < a.K0 ? xr[k] : xr1[k];
         const float4* w4 = reinterpret_cast<const float4*>(wt + k * kLinMaxO);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -82,12 +89,17 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
     const int64_t r = r0 + threadIdx.x;
     const bool live = (int)threadIdx.x < rows;
     float g[kLinMaxO];
+    const int64_t gy_row = live ? r / a.gy_window : 0;
+    const bool gy_on = live && (a.gy_window == 1 || (int)(r - gy_row * a.gy_window) == a.gy_position);
+    const int64_t gy_rows = a.N / a.gy_window;
 #pragma unroll
     for (int o = 0; o < kLinMaxO; ++o) {
         float v = 0.f;
-        if (live && o < a.O) {
+        if (gy_on && o < a.O) {
             const float yv = a.y[r * a.O + o];
-            v = a.gy[r * a.O + o] * (1.f - yv * yv);
+            float gsum = a.gy[gy_row * a.O + o];
+            for (int e = 1; e < a.gy_members; ++e) gsum += a.gy[(e * gy_rows + gy_row) * a.O + o];     // member order
+            v = gsum * (1.f - yv * yv);
         }
         g[o] = v;
         gs[threadIdx.x * kLinMaxO + o] = v;
@@ -95,13 +107,15 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
     const int XS = a.K + 1;
     {
         const float* xr = a.x + (live ? r : r0) * a.x_stride;
-        for (int k = 0; k < a.K; ++k) xs[threadIdx.x * XS + k] = live ? xr[k] : 0.f;
+        const float* xr1 = a.x1 ? a.x1 + (live ? r : r0) * a.x1_stride - a.K0 : xr;
+        for (int k = 0; k < a.K; ++k) xs[threadIdx.x * XS + k] = live ? (k < a.K0 ? xr[k] : xr1[k]) : 0.f;
         xs[threadIdx.x * XS + a.K] = 1.f;
     }
     __syncthreads();
-    if (a.gx && live) {
-        float* gxr = a.gx + r * a.K;
-        for (int k = 0; k < a.K; ++k) {
+    if ((a.gx || a.gx1) && live) {
+        float* gxr = a.gx ? a.gx + r * a.K0 : nullptr;
+        float* gxr1 = a.gx1 ? a.gx1 + r * (a.K - a.K0) - a.K0 : nullptr;
+        for (int k = a.gx ? 0 : a.K0; k < (a.gx1 ? a.K : a.K0); ++k) {
             const float4* w4 = reinterpret_cast<const float4*>(wt + k * kLinMaxO);
             float s = 0.f;
 #pragma unroll
@@ -112,7 +126,8 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
                 s += g[4 * q + 2] * w.z;
                 s += g[4 * q + 3] * w.w;
             }
-            gxr[k] = s;
+            if (k < a.K0) gxr[k] = s;
+            else gxr1[k] = s;
         }
     }
     // partial parameter gradients of this workgroup, G^T [O x rows] times (X | 1) [rows x (K + 1)] on the matrix
@@ -190,28 +205,50 @@ int64_t asac_linear_tanh_workspace(int64_t N, int K, int O) {
     return ((N + kLinRows - 1) / kLinRows) * (int64_t)O * (K + 1) + 1;      // partials + the arrival counter
 }
 
-int asac_linear_tanh_forward(const float* x, int64_t x_row_stride, const float* weight, const float* bias, int64_t N,
-                             int K, int O, float* y, void* stream) {
-    if (!lin_dims_ok(N, K, O) || !x || !weight || !bias || !y || x_row_stride < K) return bad_arg("asac_linear_tanh_forward");
+int asac_linear_tanh_forward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
+                              int K1, const float* weight, const float* bias, int64_t N, int O, float* y, void* stream) {
+    const int K = K0 + (x1 ? K1 : 0);
+    if (!lin_dims_ok(N, K, O) || !x0 || K0 <= 0 || !weight || !bias || !y || x0_row_stride < K0 ||
+        (x1 && (K1 <= 0 || x1_row_stride < K1)))
+        return bad_arg("asac_linear_tanh_forward");
     LinArgs a{};
-    a.x = x, a.x_stride = x_row_stride, a.w = weight, a.b = bias, a.N = N, a.K = K, a.O = O, a.y = y;
+    a.x = x0, a.x_stride = x0_row_stride, a.K0 = K0, a.x1 = x1, a.x1_stride = x1_row_stride;
+    a.w = weight, a.b = bias, a.N = N, a.K = K, a.O = O, a.y = y;
     ASAC_LAUNCH(k_linear_tanh_fwd, dim3((unsigned)((N + kLinRows - 1) / kLinRows)), dim3(kLinRows), 0, as_stream(stream), a);
     return finish_launch("asac_linear_tanh_forward");
+}
+
+int asac_linear_tanh_forward(const float* x, int64_t x_row_stride, const float* weight, const float* bias, int64_t N,
+                             int K, int O, float* y, void* stream) {
+    return asac_linear_tanh_forward2(x, x_row_stride, K, nullptr, 0, 0, weight, bias, N, O, y, stream);
+}
+
+int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
+                               int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
+                               int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,
+                               float* grad_params, int accumulate, float* workspace, void* stream) {
+    const int K = K0 + (x1 ? K1 : 0);
+    if (!lin_dims_ok(N, K, O) || !x0 || K0 <= 0 || !weight || !y || !grad_y || !grad_params || !workspace ||
+        x0_row_stride < K0 || (x1 && (K1 <= 0 || x1_row_stride < K1)) || (!x1 && grad_x1) || grad_members <= 0 ||
+        grad_window <= 0 || N % grad_window != 0 || grad_position < 0 || grad_position >= grad_window)
+        return bad_arg("asac_linear_tanh_backward");
+    const int64_t blocks = (N + kLinRows - 1) / kLinRows;
+    LinArgs a{};
+    a.x = x0, a.x_stride = x0_row_stride, a.K0 = K0, a.x1 = x1, a.x1_stride = x1_row_stride;
+    a.w = weight, a.N = N, a.K = K, a.O = O;
+    a.y = const_cast<float*>(y), a.gy = grad_y, a.gy_members = grad_members, a.gy_window = grad_window;
+    a.gy_position = grad_position, a.gx = grad_x0, a.gx1 = grad_x1, a.gp = grad_params, a.accumulate = accumulate;
+    a.partial = workspace;
+    a.counter = reinterpret_cast<unsigned int*>(workspace + blocks * (int64_t)O * (K + 1));
+    ASAC_LAUNCH(k_linear_tanh_bwd, dim3((unsigned)blocks), dim3(kLinRows), 0, as_stream(stream), a);
+    return finish_launch("asac_linear_tanh_backward");
 }
 
 int asac_linear_tanh_backward(const float* x, int64_t x_row_stride, const float* weight, const float* y,
                               const float* grad_y, int64_t N, int K, int O, float* grad_x, float* grad_params,
                               int accumulate, float* workspace, void* stream) {
-    if (!lin_dims_ok(N, K, O) || !x || !weight || !y || !grad_y || !grad_params || !workspace || x_row_stride < K)
-        return bad_arg("asac_linear_tanh_backward");
-    const int64_t blocks = (N + kLinRows - 1) / kLinRows;
-    LinArgs a{};
-    a.x = x, a.x_stride = x_row_stride, a.w = weight, a.N = N, a.K = K, a.O = O;
-    a.y = const_cast<float*>(y), a.gy = grad_y, a.gx = grad_x, a.gp = grad_params, a.accumulate = accumulate;
-    a.partial = workspace;
-    a.counter = reinterpret_cast<unsigned int*>(workspace + blocks * (int64_t)O * (K + 1));
-    ASAC_LAUNCH(k_linear_tanh_bwd, dim3((unsigned)blocks), dim3(kLinRows), 0, as_stream(stream), a);
-    return finish_launch("asac_linear_tanh_backward");
+    return asac_linear_tanh_backward2(x, x_row_stride, K, nullptr, 0, 0, weight, y, grad_y, 1, 1, 0, N, O, grad_x, nullptr,
+                                      grad_params, accumulate, workspace, stream);
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 51
+ABI_VERSION = 52
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -267,6 +267,11 @@ _SIGNATURES = {
                                            C.c_void_p, C.c_void_p]),
     'asac_linear_tanh_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_linear_tanh_forward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_linear_tanh_backward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_param_count': (C.c_int64, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_workspace': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
@@ -1104,6 +1109,34 @@ def linear_tanh_backward(x, weight, y, grad_y, grad_x, grad_params, accumulate, 
     _check(load().asac_linear_tanh_backward(px, sx, _p(weight), _p(y), _p(grad_y), x.shape[0], x.shape[1],
                                             weight.shape[0], _p(grad_x), _p(grad_params), int(bool(accumulate)),
                                             _p(workspace), _stream()), 'asac_linear_tanh_backward')
+
+
+@_profiled
+def linear_tanh_forward2(x0, x1, weight, bias, y):
+    """y[N, O] = tanh([x0 | x1][N, K0 + K1] weight^T + bias): the concatenation read in place (x1 may be None)"""
+    _dense_f32(weight, bias, y)
+    p0, s0 = _rows2(x0)
+    p1, s1 = _rows2(x1) if x1 is not None else (None, 0)
+    assert x1 is None or x1.shape[0] == x0.shape[0]
+    _check(load().asac_linear_tanh_forward2(p0, s0, x0.shape[1], p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
+                                            _p(bias), x0.shape[0], weight.shape[0], _p(y), _stream()),
+           'asac_linear_tanh_forward2')
+
+
+@_profiled
+def linear_tanh_backward2(x0, x1, weight, y, grad_y, grad_x0, grad_x1, grad_params, accumulate, workspace,
+                          members=1, window=1, position=0):
+    """`linear_tanh_backward` over the two-part input; grad_y [members, N / window, O]: row r's output gradient is
+    sum_e grad_y[e, r // window] when r % window == position, zero otherwise (1, 1, 0: dense [N, O])."""
+    _dense_f32(weight, y, grad_y, grad_x0, grad_x1, grad_params, workspace)
+    p0, s0 = _rows2(x0)
+    p1, s1 = _rows2(x1) if x1 is not None else (None, 0)
+    N, O = x0.shape[0], weight.shape[0]
+    assert grad_y.numel() == members * (N // window) * O and N % window == 0
+    _check(load().asac_linear_tanh_backward2(p0, s0, x0.shape[1], p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
+                                             _p(y), _p(grad_y), members, window, position, N, O, _p(grad_x0),
+                                             _p(grad_x1), _p(grad_params), int(bool(accumulate)), _p(workspace),
+                                             _stream()), 'asac_linear_tanh_backward2')
 
 
 def conv2_desc(channels, height, width, out1, kernel1, stride1, out2, kernel2, stride2) -> Conv2Desc:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 51
+#define ASAC_ABI_VERSION 52
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -914,6 +914,20 @@ int asac_linear_tanh_forward(const float* x, int64_t x_row_stride, const float* 
 int asac_linear_tanh_backward(const float* x, int64_t x_row_stride, const float* weight, const float* y,
                               const float* grad_y, int64_t N, int K, int O, float* grad_x, float* grad_params,
                               int accumulate, float* workspace, void* stream);
+/* The same head over an input that is the concatenation of two row blocks, x0 [N][K0] | x1 [N][K1] (x1 NULL: x0
+ * alone), read in place — `self.dense(torch.cat([vec, self.conv(img)], dim=-1))`, tests/nn_conv_vanilla.py:16-19 —
+ * with K = K0 + K1 <= ASAC_LINEAR_TANH_MAX_IN (weight [O][K]).  Backward: grad_x0 [N][K0], grad_x1 [N][K1] (each may be
+ * NULL); the output gradient is given as grad_y [grad_members][N / grad_window][O]: row r receives
+ * sum_e grad_y[e][r / grad_window] (member order) when r % grad_window == grad_position and zero otherwise — the
+ * critics' state gradients at the one window position the Q loss reads (sac_base.py:2104-2110), summed in the launch
+ * (grad_members = 1, grad_window = 1: a dense [N][O] gradient).  Values of asac_linear_tanh_forward / _backward on
+ * the materialised concatenation / gradient, bit for bit. */
+int asac_linear_tanh_forward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
+                              int K1, const float* weight, const float* bias, int64_t N, int O, float* y, void* stream);
+int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
+                               int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
+                               int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,
+                               float* grad_params, int accumulate, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

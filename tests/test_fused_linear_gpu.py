@@ -123,3 +123,81 @@ def test_reclassed_head_matches_module_path(flat_grads):
     clone = copy.deepcopy(rep)
     assert type(clone.dense) is fl.LinearTanhHead
     torch.testing.assert_close(clone(vec, extra), rep(vec, extra))
+
+
+@pytest.mark.parametrize('B,L,position,E,K0,K1,O', [(512, 1, 0, 4, 10, 8, 8), (100, 9, 5, 2, 8, 0, 8), (33, 4, 3, 3, 5, 7, 6),
+                                                    (257, 1, 0, 1, 40, 24, 16)])
+def test_two_block_input_and_member_gradients_equal_the_materialised_forms(B, L, position, E, K0, K1, O):
+    """`asac_linear_tanh_forward2 / _backward2`: the input read as two blocks side by side, the output gradient given as
+    E members at one window position and summed in the launch == the one-input launches on the concatenation and on the
+    dense gradient (sum_e members at the position, zero elsewhere): every output bit for bit."""
+    from asac_amd import native
+    torch.manual_seed(B + L)
+    dev, N = 'cuda:0', B * L
+    wide0 = torch.randn(N, K0 + 3, device=dev)
+    x0 = wide0[:, 1:1 + K0]                                   # (a row stride)
+    x1 = torch.randn(N, K1, device=dev) if K1 else None
+    w = torch.randn(O, K0 + K1, device=dev) * 0.3
+    b = torch.randn(O, device=dev) * 0.1
+    members = torch.randn(E, B, O, device=dev)
+    x = torch.cat([x0, x1], dim=-1) if K1 else x0.contiguous()
+    y, y2 = torch.empty(N, O, device=dev), torch.empty(N, O, device=dev)
+    native.linear_tanh_forward(x, w, b, y)
+    native.linear_tanh_forward2(x0, x1, w, b, y2)
+    assert torch.equal(y, y2)
+    dense = torch.zeros(B, L, O, device=dev)
+    acc = members[0].clone()
+    for e in range(1, E):
+        acc = acc + members[e]
+    dense[:, position] = acc
+    K = K0 + K1
+    ws = torch.zeros(native.linear_tanh_workspace(N, K, O), device=dev)
+    gx, g = torch.empty(N, K, device=dev), torch.empty(O * K + O, device=dev)
+    native.linear_tanh_backward(x, w, y, dense.view(N, O), gx, g, False, ws)
+    gx0, gx1 = torch.empty(N, K0, device=dev), (torch.empty(N, K1, device=dev) if K1 else None)
+    g2 = torch.empty(O * K + O, device=dev)
+    native.linear_tanh_backward2(x0, x1, w, y, members, gx0, gx1, g2, False, ws, members=E, window=L, position=position)
+    assert torch.equal(g, g2) and torch.equal(gx[:, :K0], gx0) and (not K1 or torch.equal(gx[:, K0:], gx1))
+    if K1:      # only the second block's gradient asked for (the first is data)
+        g3, gx1b = torch.empty(O * K + O, device=dev), torch.empty(N, K1, device=dev)
+        native.linear_tanh_backward2(x0, x1, w, y, members, None, gx1b, g3, False, ws, members=E, window=L, position=position)
+        assert torch.equal(g, g3) and torch.equal(gx1, gx1b)
+
+
+def test_deferred_concatenation_reaches_the_fused_head_in_two_blocks():
+    """Inside `AdjacentCat(defer_width)` the plugin's `self.dense(torch.cat([vec, features], -1))` runs the two-block
+    launch (no concatenation is formed), with the gradients of the module path; anything else done to the deferred
+    object gets the real concatenation."""
+    import asac_amd  # noqa: F401
+    from algorithm import fused_linear as fl
+    from algorithm.adjacent_cat import AdjacentCat, DeferredCat
+    torch.manual_seed(0)
+    dev = 'cuda:0'
+    head = nn.Sequential(nn.Linear(18, 8), nn.Tanh()).to(dev)
+    ref = nn.Sequential(nn.Linear(18, 8), nn.Tanh()).to(dev)
+    ref.load_state_dict(head.state_dict())
+    holder = nn.Module()
+    holder.dense = head
+    assert fl.fuse_linear_tanh_heads(holder) == 1
+    vec = torch.randn(64, 9, 10, device=dev)
+    feat = torch.randn(64, 9, 8, device=dev, requires_grad=True)
+    feat_ref = feat.detach().clone().requires_grad_(True)
+    gy = torch.randn(64, 9, 8, device=dev)
+    with AdjacentCat(64):
+        cat = torch.cat([vec, feat], dim=-1)
+        assert isinstance(cat, DeferredCat) and cat._value is None
+        out = holder.dense(cat)
+        assert cat._value is None                       # never materialised
+        other = torch.cat([vec, feat], dim=-1)
+        assert other.shape == (64, 9, 18) and other._value is not None          # an attribute: the real tensor
+        assert torch.equal(other + 0, torch.cat([vec.clone(), feat.detach()], -1))
+        assert torch.equal(torch.relu(torch.cat([vec, feat], -1)), torch.relu(torch.cat([vec.clone(), feat.detach()], -1)))
+        wide = torch.cat([torch.randn(4, 60, device=dev), torch.randn(4, 60, device=dev)], -1)
+        assert isinstance(wide, torch.Tensor)           # too wide for the head: ATen's concatenation
+    out.backward(gy)
+    want = ref(torch.cat([vec, feat_ref], dim=-1))
+    want.backward(gy)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(feat.grad, feat_ref.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(head[0].weight.grad, ref[0].weight.grad, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(head[0].bias.grad, ref[0].bias.grad, rtol=1e-4, atol=2e-4)
