@@ -110,6 +110,8 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_conv2_forward': 'asac::k_conv2_fwd', 'asac_conv2_backward': 'asac::k_conv2_bwd',
               'asac_attention_proj_forward': 'asac::k_attn_proj_fwd', 'asac_attention_proj_backward': 'asac::k_attn_proj_bwd',
               'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd',
+              'asac_linear_tanh_forward2': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward2': 'asac::k_linear_tanh_bwd',
+              'asac_gru_backward_at': 'asac::k_gru_bwd',
               'asac_adam_step_partials': 'asac::k_adam_partials', 'asac_adam_step': 'asac::k_adam',
               'asac_step_prologue': 'asac::k_noise_fill', 'asac_policy_sample_q_forward': 'asac::k_pi_sample_q',
               'asac_policy_step_fused': 'asac::k_policy_step', 'asac_rows_move': 'asac::k_rows_move',
