@@ -53,15 +53,21 @@ except Exception:  # pragma: no cover
     SummaryWriter = None
 
 
-def _masked_mse_backward(pred, target, padding_mask, loss_out):
+def _masked_mse_backward(pred, target, padding_mask, loss_out, fused=True):
     """loss = mean over ALL elements of (pred - target)^2 with padded rows zeroed (`mse_loss(reduction='none') *
     ~mask` then `mean`, reference sac_base.py:1962-1964) -> `loss_out`, and `loss.backward()` through `pred`:
     the loss is the root, so its gradient 2 d / N is handed to autograd directly (six launches in all)."""
     with torch.no_grad():
-        d = (pred - target).mul_((~padding_mask).unsqueeze(-1))
-        flat = d.reshape(-1)
-        torch.div(torch.dot(flat, flat), flat.numel(), out=loss_out)
-        d.mul_(2. / flat.numel())
+        if (fused and pred.is_cuda and pred.dim() == 3 and pred.dtype == torch.float32 and pred.is_contiguous()
+                and target.stride(-1) == 1 and pred.numel() <= native.MASKED_MSE_MAX and padding_mask.dtype == torch.bool
+                and (padding_mask.stride(1) == 1 or padding_mask.shape[1] == 1)):
+            d = torch.empty_like(pred)
+            native.masked_mse(pred.detach(), target, padding_mask, d, loss_out)       # one launch
+        else:
+            d = (pred - target).mul_((~padding_mask).unsqueeze(-1))
+            flat = d.reshape(-1)
+            torch.div(torch.dot(flat, flat), flat.numel(), out=loss_out)
+            d.mul_(2. / flat.numel())
     with direct_param_grads():      # detached inputs: the backward reaches the model's own parameters only
         pred.backward(d)
 
@@ -237,6 +243,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fold_rep_q_adam = bool(hip_config.get('fold_rep_q_adam', True))
         self._rep_grad_one_position = bool(hip_config.get('rep_grad_one_position', True))
         self._deferred_cat = bool(hip_config.get('deferred_cat', True))
+        self._fused_curiosity = bool(hip_config.get('fused_curiosity', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
@@ -949,11 +956,17 @@ class SAC_Base(AuxHeadsMixin):
         if self.curiosity is not None:   # 1333-1343: augments the sampled reward window in place
             n_states, next_n_states = nx_states[:, :-1], nx_states[:, 1:]
             if self.curiosity == CURIOSITY.FORWARD:
-                d = self.model_forward_dynamic(n_states, n_actions) - next_n_states
+                approx, actual = self.model_forward_dynamic(n_states, n_actions), next_n_states
             else:
-                d = self.model_inverse_dynamic(n_states, next_n_states) - n_actions
-            bonus = torch.sum(d.mul_(d), dim=-1).mul_(0.5)       # 0.5 * sum (approx - actual)^2
-            n_rewards.add_(bonus, alpha=self.curiosity_strength)
+                approx, actual = self.model_inverse_dynamic(n_states, next_n_states), n_actions
+            if (self._fused_curiosity and approx.is_cuda and approx.dim() == 3 and approx.dtype == torch.float32
+                    and actual.stride(-1) == 1 and n_rewards.dim() == 2 and n_rewards.dtype == torch.float32
+                    and (n_rewards.stride(1) == 1 or n_rewards.shape[1] == 1) and not torch.is_grad_enabled()):
+                native.curiosity_bonus(approx.contiguous(), actual, n_rewards, self.curiosity_strength)   # one launch
+            else:
+                d = approx - actual
+                bonus = torch.sum(d.mul_(d), dim=-1).mul_(0.5)       # 0.5 * sum (approx - actual)^2
+                n_rewards.add_(bonus, alpha=self.curiosity_strength)
 
         logp = None
         if self.c_action_size and sample is not None:
@@ -1570,7 +1583,7 @@ class SAC_Base(AuxHeadsMixin):
             pred, target = self.model_forward_dynamic(n_states, n_actions), next_n_states
         else:
             pred, target = self.model_inverse_dynamic(n_states, next_n_states), n_actions
-        _masked_mse_backward(pred, target, n_padding_masks, self._stats['loss_curiosity'])
+        _masked_mse_backward(pred, target, n_padding_masks, self._stats['loss_curiosity'], fused=self._fused_curiosity)
         if self._dist is not None:
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('curiosity'))
         self.optimizer_curiosity.step()

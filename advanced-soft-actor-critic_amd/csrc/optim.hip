@@ -142,7 +142,76 @@ __global__ __launch_bounds__(256) void k_gelu_eval(const float* __restrict__ z, 
     }
 }
 
+// Curiosity (reference sac_base.py:1333-1343): the sampled reward window is augmented in place by
+//   strength * 0.5 * sum_k (approx[b][t][k] - actual[b][t][k])^2
+// `approx` is the dynamics model's dense output, `actual` a strided view of the window (the next states for the
+// FORWARD model, the stored actions for the INVERSE one).  One lane per (b, t): one launch instead of ATen's five.
+__global__ __launch_bounds__(256) void k_curiosity_bonus(const float* __restrict__ approx, const float* __restrict__ actual,
+                                                         int64_t actual_sb, int64_t actual_st, float* __restrict__ reward,
+                                                         int64_t reward_sb, int B, int T, int K, float strength) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i - b * T;
+    const float* p = approx + (int64_t)i * K;
+    const float* q = actual + b * actual_sb + t * actual_st;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float d = p[k] - q[k];
+        s += d * d;
+    }
+    float* r = reward + b * reward_sb + t;
+    *r = *r + strength * (s * 0.5f);
+}
+
+// Loss of the curiosity model (reference sac_base.py:1951-1976): mean over ALL N = B T K elements of the squared
+// error with padded rows zeroed, and its gradient with respect to the prediction:
+//   d = (pred - target) * !mask[b][t];  loss = sum d^2 / N;  grad = d * 2 / N
+// One workgroup (the sum is one number; N is a few 10^4): lanes stride over the elements, fixed-order tree in LDS.
+constexpr int kMseThreads = 1024;
+__global__ __launch_bounds__(kMseThreads) void k_masked_mse(const float* __restrict__ pred, const float* __restrict__ target,
+                                                            int64_t target_sb, int64_t target_st,
+                                                            const uint8_t* __restrict__ mask, int64_t mask_sb, int B, int T,
+                                                            int K, float* __restrict__ grad, float* __restrict__ loss) {
+    __shared__ float red[kMseThreads];
+    const int64_t N = (int64_t)B * T * K;
+    const float scale = 2.f / (float)N;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += kMseThreads) {
+        const int64_t row = i / K;
+        const int k = (int)(i - row * K), b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+        const bool padded = mask && mask[b * mask_sb + t];
+        const float d = padded ? 0.f : pred[i] - target[b * target_sb + t * target_st + k];
+        s += d * d;
+        grad[i] = d * scale;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kMseThreads / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] / (float)N;
+}
+
 extern "C" {
+
+int asac_curiosity_bonus(const float* approx, const float* actual, int64_t actual_stride_b, int64_t actual_stride_t,
+                         float* reward, int64_t reward_stride_b, int B, int T, int K, float strength, void* stream) {
+    if (B <= 0 || T <= 0 || K <= 0 || !approx || !actual || !reward) return bad_arg("asac_curiosity_bonus");
+    ASAC_LAUNCH(k_curiosity_bonus, dim3((unsigned)((B * T + 255) / 256)), dim3(256), 0, as_stream(stream), approx, actual,
+                actual_stride_b, actual_stride_t, reward, reward_stride_b, B, T, K, strength);
+    return finish_launch("asac_curiosity_bonus");
+}
+
+int asac_masked_mse(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t,
+                    const uint8_t* padding_mask, int64_t mask_stride_b, int B, int T, int K, float* grad_out,
+                    float* loss_out, void* stream) {
+    if (B <= 0 || T <= 0 || K <= 0 || !pred || !target || !grad_out || !loss_out || (int64_t)B * T * K > ASAC_MASKED_MSE_MAX)
+        return bad_arg("asac_masked_mse");
+    ASAC_LAUNCH(k_masked_mse, dim3(1), dim3(kMseThreads), 0, as_stream(stream), pred, target, target_stride_b,
+                target_stride_t, padding_mask, mask_stride_b, B, T, K, grad_out, loss_out);
+    return finish_launch("asac_masked_mse");
+}
 
 int asac_gelu_eval(const float* z, float* value, float* deriv, int64_t n, void* stream) {
     if (n <= 0 || !z || !value || !deriv) return bad_arg("asac_gelu_eval");

@@ -272,6 +272,10 @@ _SIGNATURES = {
     'asac_linear_tanh_backward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_curiosity_bonus': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                       C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'asac_masked_mse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_param_count': (C.c_int64, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_workspace': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
@@ -1109,6 +1113,40 @@ def linear_tanh_backward(x, weight, y, grad_y, grad_x, grad_params, accumulate, 
     _check(load().asac_linear_tanh_backward(px, sx, _p(weight), _p(y), _p(grad_y), x.shape[0], x.shape[1],
                                             weight.shape[0], _p(grad_x), _p(grad_params), int(bool(accumulate)),
                                             _p(workspace), _stream()), 'asac_linear_tanh_backward')
+
+
+MASKED_MSE_MAX = 1 << 18
+
+
+def _window3(t):
+    """[B, T, K] f32 view with a dense last dim -> (pointer, batch stride, step stride)"""
+    assert t.dim() == 3 and t.dtype == torch.float32 and t.is_cuda and (t.stride(2) == 1 or t.shape[2] == 1)
+    return _p(t), t.stride(0), t.stride(1)
+
+
+@_profiled
+def curiosity_bonus(approx, actual, reward, strength):
+    """reward[B, T] += strength * 0.5 * sum_k (approx - actual)^2 in place (approx dense [B, T, K]; actual, reward views)"""
+    B, T, K = approx.shape
+    assert approx.is_contiguous() and actual.shape == approx.shape and reward.shape == (B, T)
+    assert reward.dtype == torch.float32 and (reward.stride(1) == 1 or T == 1)
+    pa, sb, st = _window3(actual)
+    _check(load().asac_curiosity_bonus(_p(approx), pa, sb, st, _p(reward), reward.stride(0), B, T, K, float(strength),
+                                       _stream()), 'asac_curiosity_bonus')
+
+
+@_profiled
+def masked_mse(pred, target, padding_mask, grad_out, loss_out):
+    """loss_out <- mean over all elements of ((pred - target) * ~mask)^2, grad_out <- its gradient w.r.t. pred"""
+    B, T, K = pred.shape
+    assert pred.is_contiguous() and grad_out.is_contiguous() and grad_out.shape == pred.shape and target.shape == pred.shape
+    pt, sb, st = _window3(target)
+    pm, ms = None, 0
+    if padding_mask is not None:
+        assert padding_mask.shape == (B, T) and padding_mask.element_size() == 1 and (padding_mask.stride(1) == 1 or T == 1)
+        pm, ms = _p(padding_mask), padding_mask.stride(0)
+    _check(load().asac_masked_mse(_p(pred), pt, sb, st, pm, ms, B, T, K, _p(grad_out), _p(loss_out), _stream()),
+           'asac_masked_mse')
 
 
 @_profiled

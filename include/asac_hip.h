@@ -896,6 +896,21 @@ int asac_alpha_adam_step(const float* logp, int B, float target, int slot, float
                          float* exp_avg, float* exp_avg_sq, int n, float lr, float beta1, float beta2,
                          float eps, int64_t* steps_done, int advance_counter, void* stream);
 
+/* Curiosity (SAC_Base._get_y, sac_base.py:1333-1343): reward[b][t] += strength * 0.5 * sum_k (approx - actual)^2 over
+ * the sampled window, in place.  approx [B][T][K] dense (the dynamics model's output); actual [B][T][K] with strides in
+ * floats (the next states of the window for the FORWARD model, the stored actions for the INVERSE one); reward [B][T]
+ * with batch stride reward_stride_b.  One launch for ATen's subtract, square, sum, scale and add. */
+int asac_curiosity_bonus(const float* approx, const float* actual, int64_t actual_stride_b, int64_t actual_stride_t,
+                         float* reward, int64_t reward_stride_b, int B, int T, int K, float strength, void* stream);
+/* Loss of the curiosity model and its gradient (SAC_Base._train_curiosity, sac_base.py:1951-1976):
+ *   d = (pred - target) * !padding_mask[b][t];  *loss_out = sum d^2 / N;  grad_out = d * 2 / N,  N = B T K
+ * pred / grad_out [B][T][K] dense, target strided like `actual` above, padding_mask u8 [B][T] or NULL.  One workgroup
+ * (fixed summation order): N <= ASAC_MASKED_MSE_MAX, larger problems return ASAC_ERR_BAD_ARG and keep ATen's chain. */
+#define ASAC_MASKED_MSE_MAX (1 << 18)
+int asac_masked_mse(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t,
+                    const uint8_t* padding_mask, int64_t mask_stride_b, int B, int T, int K, float* grad_out,
+                    float* loss_out, void* stream);
+
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with
  * `nn.Sequential(nn.Linear(n, 8), nn.Tanh())`: tests/nn_conv_vanilla.py:11-14, tests/nn_conv_attn.py:15-17,

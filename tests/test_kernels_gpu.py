@@ -739,3 +739,31 @@ def test_gelu_against_torch(nat):
     pu.check('kernels/gelu/derivative', deriv, want_d, rtol=0., atol=6e-7)
     # ... and ATen's own f32 evaluation for scale: how far IT is from the float64 value
     pu.check('kernels/gelu/aten_f32_value_for_scale', torch.nn.functional.gelu(z), want.detach(), rtol=3e-7, atol=6e-7, enforce=False)
+
+
+def test_curiosity_bonus_and_masked_mse_against_the_aten_chains(nat):
+    """`asac_curiosity_bonus` / `asac_masked_mse` == the elementwise chains of SAC_Base._get_y (reference
+    sac_base.py:1333-1343) and _train_curiosity (1951-1976) on strided window views; f32 rounding of a K-term sum
+    (rtol 1e-6) — the chains' own summation order is ATen's, not the reference's to pin."""
+    g = torch.Generator().manual_seed(4)
+    B, L, K = 70, 9, 8
+    states = torch.randn(B, L, K, generator=g).cuda()
+    rewards = torch.randn(B, L, generator=g).cuda()
+    approx = torch.randn(B, L - 1, K, generator=g).cuda()
+    nxt, r_view = states[:, 1:], rewards[:, :-1]
+    want_r = rewards.clone()
+    d = approx - nxt
+    want_r[:, :-1].add_(torch.sum(d * d, dim=-1).mul_(0.5), alpha=0.37)
+    nat.curiosity_bonus(approx, nxt, r_view, 0.37)
+    torch.testing.assert_close(rewards, want_r, rtol=1e-6, atol=1e-6)
+    assert torch.equal(rewards[:, -1], want_r[:, -1])
+
+    mask = (torch.rand(B, L - 1, generator=g) < 0.3).cuda()
+    dm = (approx - nxt) * (~mask).unsqueeze(-1)
+    want_loss = (dm * dm).double().sum() / dm.numel()
+    grad, loss = torch.empty_like(approx), torch.zeros((), device='cuda')
+    nat.masked_mse(approx, nxt, mask, grad, loss)
+    torch.testing.assert_close(grad, dm * (2. / dm.numel()), rtol=1e-6, atol=1e-9)
+    assert abs(float(loss) - float(want_loss)) <= 2e-6 * float(want_loss)
+    nat.masked_mse(approx, nxt, None, grad, loss)
+    torch.testing.assert_close(grad, (approx - nxt) * (2. / dm.numel()), rtol=1e-6, atol=1e-9)
