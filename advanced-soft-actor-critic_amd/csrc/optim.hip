@@ -119,29 +119,6 @@ __global__ __launch_bounds__(256) void k_adam_partials(float* __restrict__ param
     }
 }
 
-inline int stream_grid(int64_t n_vec) {
-    int64_t b = (n_vec + 255) / 256;
-    if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
-    return (int)b;
-}
-
-}  // namespace asac
-
-using namespace asac;
-
-// The activation of every fused MLP / convolution kernel, element by element (asac_gelu.h), so that its distance from
-// torch.nn.functional.gelu can be measured through the C ABI (tests/test_kernels_gpu.py::test_gelu_against_torch).
-__global__ __launch_bounds__(256) void k_gelu_eval(const float* __restrict__ z, float* __restrict__ value,
-                                                   float* __restrict__ deriv, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float v, d;
-        gelu_parts(z[i], v, d);
-        value[i] = v;
-        deriv[i] = d;
-    }
-}
-
 // Curiosity (reference sac_base.py:1333-1343): the sampled reward window is augmented in place by
 //   strength * 0.5 * sum_k (approx[b][t][k] - actual[b][t][k])^2
 // `approx` is the dynamics model's dense output, `actual` a strided view of the window (the next states for the
@@ -166,31 +143,86 @@ __global__ __launch_bounds__(256) void k_curiosity_bonus(const float* __restrict
 // Loss of the curiosity model (reference sac_base.py:1951-1976): mean over ALL N = B T K elements of the squared
 // error with padded rows zeroed, and its gradient with respect to the prediction:
 //   d = (pred - target) * !mask[b][t];  loss = sum d^2 / N;  grad = d * 2 / N
-// One workgroup (the sum is one number; N is a few 10^4): lanes stride over the elements, fixed-order tree in LDS.
-constexpr int kMseThreads = 1024;
+// Eight elements per lane; the workgroups' sums are added in workgroup order by the last one to arrive.
+constexpr int kMseThreads = 256, kMsePerLane = 8;
 __global__ __launch_bounds__(kMseThreads) void k_masked_mse(const float* __restrict__ pred, const float* __restrict__ target,
                                                             int64_t target_sb, int64_t target_st,
                                                             const uint8_t* __restrict__ mask, int64_t mask_sb, int B, int T,
-                                                            int K, float* __restrict__ grad, float* __restrict__ loss) {
+                                                            int K, float* __restrict__ grad, float* __restrict__ loss,
+                                                            float* __restrict__ partial, unsigned int* __restrict__ counter) {
     __shared__ float red[kMseThreads];
-    const int64_t N = (int64_t)B * T * K;
+    __shared__ bool last;
+    const int N = B * T * K;                         // (N <= 2^20: 32-bit index arithmetic)
     const float scale = 2.f / (float)N;
-    float s = 0.f;
-    for (int64_t i = threadIdx.x; i < N; i += kMseThreads) {
-        const int64_t row = i / K;
-        const int k = (int)(i - row * K), b = (int)(row / T), t = (int)(row - (int64_t)b * T);
-        const bool padded = mask && mask[b * mask_sb + t];
-        const float d = padded ? 0.f : pred[i] - target[b * target_sb + t * target_st + k];
-        s += d * d;
-        grad[i] = d * scale;
+    const int base = blockIdx.x * kMseThreads * kMsePerLane;
+    // eight elements per lane, their loads requested together (a rolled loop waits for every pair in turn)
+    float pv[kMsePerLane], qv[kMsePerLane], s = 0.f;
+    bool pad[kMsePerLane];
+#pragma unroll
+    for (int u = 0; u < kMsePerLane; ++u) {
+        const int i = min(base + u * kMseThreads + (int)threadIdx.x, N - 1);
+        const int row = i / K, k = i - row * K, b = row / T, t = row - b * T;
+        pv[u] = pred[i];
+        qv[u] = target[b * target_sb + t * target_st + k];
+        pad[u] = mask && mask[b * mask_sb + t];
+    }
+#pragma unroll
+    for (int u = 0; u < kMsePerLane; ++u) {
+        const int i = base + u * kMseThreads + (int)threadIdx.x;
+        if (i < N) {
+            const float d = pad[u] ? 0.f : pv[u] - qv[u];
+            s += d * d;
+            grad[i] = d * scale;
+        }
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int w = kMseThreads / 2; w > 0; w >>= 1) {
+    for (int w = kMseThreads / 2; w >= 64; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = red[0] / (float)N;
+    if (threadIdx.x < 64) {                          // the last strides inside wave 0
+        float v = red[threadIdx.x];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (threadIdx.x == 0) partial[blockIdx.x] = v;
+    }
+    // the last workgroup to arrive adds the workgroups' sums in workgroup order (deterministic)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+        for (unsigned int w = 0; w < gridDim.x; ++w) v += partial[w];
+        *loss = v / (float)N;
+        *counter = 0u;                               // ready for the next launch
+    }
+}
+
+inline int stream_grid(int64_t n_vec) {
+    int64_t b = (n_vec + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace asac
+
+using namespace asac;
+
+// The activation of every fused MLP / convolution kernel, element by element (asac_gelu.h), so that its distance from
+// torch.nn.functional.gelu can be measured through the C ABI (tests/test_kernels_gpu.py::test_gelu_against_torch).
+__global__ __launch_bounds__(256) void k_gelu_eval(const float* __restrict__ z, float* __restrict__ value,
+                                                   float* __restrict__ deriv, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v, d;
+        gelu_parts(z[i], v, d);
+        value[i] = v;
+        deriv[i] = d;
+    }
 }
 
 extern "C" {
@@ -203,13 +235,21 @@ int asac_curiosity_bonus(const float* approx, const float* actual, int64_t actua
     return finish_launch("asac_curiosity_bonus");
 }
 
+int64_t asac_masked_mse_workspace(int64_t n) {
+    if (n <= 0 || n > ASAC_MASKED_MSE_MAX) return -1;
+    return (n + kMseThreads * kMsePerLane - 1) / (kMseThreads * kMsePerLane) + 1;      // workgroup sums + arrival counter
+}
+
 int asac_masked_mse(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t,
                     const uint8_t* padding_mask, int64_t mask_stride_b, int B, int T, int K, float* grad_out,
-                    float* loss_out, void* stream) {
-    if (B <= 0 || T <= 0 || K <= 0 || !pred || !target || !grad_out || !loss_out || (int64_t)B * T * K > ASAC_MASKED_MSE_MAX)
+                    float* loss_out, float* workspace, void* stream) {
+    const int64_t n = (int64_t)B * T * K;
+    if (B <= 0 || T <= 0 || K <= 0 || !pred || !target || !grad_out || !loss_out || !workspace || n > ASAC_MASKED_MSE_MAX)
         return bad_arg("asac_masked_mse");
-    ASAC_LAUNCH(k_masked_mse, dim3(1), dim3(kMseThreads), 0, as_stream(stream), pred, target, target_stride_b,
-                target_stride_t, padding_mask, mask_stride_b, B, T, K, grad_out, loss_out);
+    const int64_t blocks = asac_masked_mse_workspace(n) - 1;
+    ASAC_LAUNCH(k_masked_mse, dim3((unsigned)blocks), dim3(kMseThreads), 0, as_stream(stream), pred, target, target_stride_b,
+                target_stride_t, padding_mask, mask_stride_b, B, T, K, grad_out, loss_out, workspace,
+                reinterpret_cast<unsigned int*>(workspace + blocks));
     return finish_launch("asac_masked_mse");
 }
 

@@ -275,7 +275,8 @@ _SIGNATURES = {
     'asac_curiosity_bonus': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                        C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'asac_masked_mse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
-                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_masked_mse_workspace': (C.c_int64, [C.c_int64]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_param_count': (C.c_int64, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_workspace': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
@@ -1115,7 +1116,8 @@ def linear_tanh_backward(x, weight, y, grad_y, grad_x, grad_params, accumulate, 
                                             _p(workspace), _stream()), 'asac_linear_tanh_backward')
 
 
-MASKED_MSE_MAX = 1 << 18
+MASKED_MSE_MAX = 1 << 20
+_MSE_WS = {}
 
 
 def _window3(t):
@@ -1145,8 +1147,11 @@ def masked_mse(pred, target, padding_mask, grad_out, loss_out):
     if padding_mask is not None:
         assert padding_mask.shape == (B, T) and padding_mask.element_size() == 1 and (padding_mask.stride(1) == 1 or T == 1)
         pm, ms = _p(padding_mask), padding_mask.stride(0)
-    _check(load().asac_masked_mse(_p(pred), pt, sb, st, pm, ms, B, T, K, _p(grad_out), _p(loss_out), _stream()),
-           'asac_masked_mse')
+    key = (pred.numel(), pred.device)
+    if key not in _MSE_WS:      # zero before first use, left zero by every launch
+        _MSE_WS[key] = torch.zeros(int(load().asac_masked_mse_workspace(pred.numel())), dtype=torch.float32, device=pred.device)
+    _check(load().asac_masked_mse(_p(pred), pt, sb, st, pm, ms, B, T, K, _p(grad_out), _p(loss_out), _p(_MSE_WS[key]),
+                                  _stream()), 'asac_masked_mse')
 
 
 @_profiled

@@ -904,12 +904,15 @@ int asac_curiosity_bonus(const float* approx, const float* actual, int64_t actua
                          float* reward, int64_t reward_stride_b, int B, int T, int K, float strength, void* stream);
 /* Loss of the curiosity model and its gradient (SAC_Base._train_curiosity, sac_base.py:1951-1976):
  *   d = (pred - target) * !padding_mask[b][t];  *loss_out = sum d^2 / N;  grad_out = d * 2 / N,  N = B T K
- * pred / grad_out [B][T][K] dense, target strided like `actual` above, padding_mask u8 [B][T] or NULL.  One workgroup
- * (fixed summation order): N <= ASAC_MASKED_MSE_MAX, larger problems return ASAC_ERR_BAD_ARG and keep ATen's chain. */
-#define ASAC_MASKED_MSE_MAX (1 << 18)
+ * pred / grad_out [B][T][K] dense, target strided like `actual` above, padding_mask u8 [B][T] or NULL.  The
+ * workgroups' sums are added in workgroup order by the last workgroup to arrive (fixed summation order).
+ * workspace: asac_masked_mse_workspace(N) floats, ZERO before its first use (the launch leaves its arrival counter at
+ * zero again); N <= ASAC_MASKED_MSE_MAX, larger problems return ASAC_ERR_BAD_ARG and keep ATen's chain. */
+#define ASAC_MASKED_MSE_MAX (1 << 20)
+int64_t asac_masked_mse_workspace(int64_t n);
 int asac_masked_mse(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t,
                     const uint8_t* padding_mask, int64_t mask_stride_b, int B, int T, int K, float* grad_out,
-                    float* loss_out, void* stream);
+                    float* loss_out, float* workspace, void* stream);
 
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with
