@@ -27,7 +27,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tm
 python $R/tools/summarize_pmc.py $(find /tmp/spmc_r -name "*counter_collection.csv" | head -1) $(find /tmp/spmc_w -name "*counter_collection.csv" | head -1) $O/kernel_sweep_pmc.json --by-grid > $O/kernel_sweep_pmc_all.txt
 f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_sequence.py $f > $O/cfg2_step_sequence.txt
-for c in cfg3 cfg4 cfg5; do
+for c in cfg3 cfg4 cfg5 cfg5_without_prediction; do
   rm -rf /tmp/prof_$c
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --profile-steps 0 --steps 200 --warmup 20 --fill 20000 --run-length 0 > /tmp/prof_$c.log 2>&1
   python $R/tools/step_sequence.py $(find /tmp/prof_$c -name "*kernel_trace.csv" | head -1) > $O/${c}_step_sequence.txt
