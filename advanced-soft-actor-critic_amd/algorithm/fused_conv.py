@@ -46,15 +46,24 @@ def conv_stack_desc(conv_layers, x):
 
 class _ConvStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, desc, w1, b1, w2, b2):
+    def forward(ctx, x, desc, w1, b1, w2, b2, windows=None, grad_mode=True):
         N = x.shape[0]
-        x = x.contiguous()
+        # (`needs_input_grad` mirrors `requires_grad` whatever the caller's grad mode, and inside `forward` the mode is
+        # always off: the caller's mode is handed in, so that a no-grad pass over trainable parameters saves nothing)
+        train = grad_mode and any(ctx.needs_input_grad[2:6])
+        if windows is not None and not train:
+            # `windows` [B, T, C, H, W]: the frames as a slice of the sampled windows (x is its reshape: a copy the
+            # caller has NOT made yet when it is lazy — here x is only consulted for its shape)
+            y = torch.empty(N, _out_width(desc), dtype=windows.dtype, device=windows.device)
+            wd = [t.detach().contiguous() for t in (w1, b1, w2, b2)]
+            native.conv2_forward_windows(desc, windows, *wd, y)
+            return y
+        x = (x if windows is None else windows.reshape(N, *x.shape[1:])).contiguous()
         h1 = (desc.height - desc.kernel1) // desc.stride1 + 1
         w1o = (desc.width - desc.kernel1) // desc.stride1 + 1
         h2, w2o = (h1 - desc.kernel2) // desc.stride2 + 1, (w1o - desc.kernel2) // desc.stride2 + 1
         out = desc.out2 * h2 * w2o
         y = torch.empty(N, out, dtype=x.dtype, device=x.device)
-        train = any(ctx.needs_input_grad[2:])
         z1 = torch.empty(N, h1 * w1o, desc.out1, dtype=x.dtype, device=x.device) if train else None
         z2 = torch.empty(N, out, dtype=x.dtype, device=x.device) if train else None
         wd = [t.detach().contiguous() for t in (w1, b1, w2, b2)]
@@ -78,7 +87,7 @@ class _ConvStackFn(torch.autograd.Function):
             flat = _flat_alias([p.grad for p in params])
         if flat is not None:
             native.conv2_backward(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws, True)
-            return (None, None, None, None, None, None)
+            return (None, None, None, None, None, None, None, None)
         g = torch.empty(native.conv2_param_count(desc), dtype=x.dtype, device=x.device)
         native.conv2_backward(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws)
         grads, off = [], 0
@@ -86,10 +95,27 @@ class _ConvStackFn(torch.autograd.Function):
             k = p.numel()
             grads.append(g[off:off + k].view(p.shape) if p.requires_grad else None)
             off += k
-        return (None, None, *grads)
+        return (None, None, *grads, None, None)
 
 
-def fused_conv_stack(x, desc, conv_layers):
-    """x [N, C, H, W] -> [N, out2*H2*W2]: what `conv_layers(x).reshape(N, -1)` returns"""
+def _out_width(desc):
+    h1 = (desc.height - desc.kernel1) // desc.stride1 + 1
+    w1o = (desc.width - desc.kernel1) // desc.stride1 + 1
+    return desc.out2 * ((h1 - desc.kernel2) // desc.stride2 + 1) * ((w1o - desc.kernel2) // desc.stride2 + 1)
+
+
+def window_slice(x5, desc):
+    """x5 [B, T, C, H, W] -> x5 itself when it is a slice of sampled windows the forward can read in place (dense
+    frames, a sample's T frames consecutive, T whole workgroup groups, no gradient pass to save a copy for), else None"""
+    if (x5.dim() == 5 and not x5.is_contiguous() and x5[0].is_contiguous() and x5.stride(0) % 4 == 0
+            and x5.shape[1] % native.conv2_group_frames(desc) == 0 and x5.data_ptr() % 16 == 0
+            and not torch.is_grad_enabled()):
+        return x5
+    return None
+
+
+def fused_conv_stack(x, desc, conv_layers, windows=None):
+    """x [N, C, H, W] -> [N, out2*H2*W2]: what `conv_layers(x).reshape(N, -1)` returns.  `windows`: see `window_slice`
+    (then x may be a non-materialised stand-in of the right shape)"""
     c1, _, c2, _ = list(conv_layers)
-    return _ConvStackFn.apply(x, desc, c1.weight, c1.bias, c2.weight, c2.bias)
+    return _ConvStackFn.apply(x, desc, c1.weight, c1.bias, c2.weight, c2.bias, windows, torch.is_grad_enabled())

@@ -139,6 +139,10 @@ def backward_from_position(top, members, position, placeholder, adam=None) -> bo
 class _GruFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, padding_mask, desc, twin, *weights):
+        # `desc` may come as (desc, the caller's grad mode): inside `forward` the mode is always off, and
+        # `needs_input_grad` mirrors `requires_grad` whatever the mode — a no-grad pass over trainable cells must not
+        # save its gate activations
+        desc, grad_mode = desc if isinstance(desc, tuple) else (desc, True)
         B, L, _ = x.shape
         H, layers = desc.hidden, desc.layers
         ctx.set_materialize_grads(False)      # an unused output (usually hn) arrives as None, not as a zero-fill
@@ -152,7 +156,7 @@ class _GruFn(torch.autograd.Function):
             if mask.stride(1) != 1:
                 mask = mask.contiguous()
         w = [tuple(t.detach() for t in weights[4 * l:4 * l + 4]) for l in range(layers)]
-        need_grad = any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[5:])
+        need_grad = grad_mode and (any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[5:]))
         hn = torch.empty(B, L, layers, H, dtype=x.dtype, device=x.device)
         out = torch.empty(B, L, H, dtype=x.dtype, device=x.device)
         gates = torch.empty(B, L, layers, 5 * H, dtype=x.dtype, device=x.device) if need_grad else None
@@ -235,14 +239,14 @@ def fused_gru(x, h0, padding_mask, cells, layer=None):
     weights = _cell_weights(cells)
     tp = TwinPass._active
     if tp is not None and layer is not None:
-        got = tp.claim(layer, x, h0, padding_mask, lambda: _GruFn.apply(x, h0, padding_mask, desc, None, *weights))
+        got = tp.claim(layer, x, h0, padding_mask, lambda: _GruFn.apply(x, h0, padding_mask, (desc, torch.is_grad_enabled()), None, *weights))
         if got is not None:
             return got
         other = tp.wants(layer, x, h0)
         if other is not None and len(other._grus) == layers and other._fusable \
                 and (other._grus[0].input_size, other._grus[0].hidden_size) == (desc.input, desc.hidden):
             twin = [_cell_weights(other._grus)]
-            res = _GruFn.apply(x, h0, padding_mask, desc, twin, *weights)
+            res = _GruFn.apply(x, h0, padding_mask, (desc, torch.is_grad_enabled()), twin, *weights)
             tp.parked[id(other)] = (x, h0, padding_mask, twin[1], twin[2])
             return res
-    return _GruFn.apply(x, h0, padding_mask, desc, None, *weights)
+    return _GruFn.apply(x, h0, padding_mask, (desc, torch.is_grad_enabled()), None, *weights)

@@ -129,6 +129,15 @@ class ConvLayers(nn.Module):
 
     def forward(self, x):
         assert x.dim() >= 4, 'The dimension of input should be greater than or equal to 4'
+        if x.is_cuda and x.dim() == 5 and not x.is_contiguous():
+            # a slice of the sampled windows ([B, T, C, H, W] views such as frames[:, b:]): the fused stack reads it in
+            # place instead of from the copy `reshape` would make
+            from algorithm.fused_conv import conv_stack_desc, fused_conv_stack, window_slice
+            desc = conv_stack_desc(self.conv_layers, x[0])
+            if desc is not None and window_slice(x, desc) is not None:
+                stand_in = x.new_empty(1).as_strided((x.shape[0] * x.shape[1], *x.shape[2:]), (0, 0, 0, 0))   # (shape only)
+                y = fused_conv_stack(stand_in, desc, self.conv_layers, windows=x)
+                return self.dense(y.reshape(*x.shape[:2], self.conv_output_size))
         lead, x = _flatten_lead(x, 3)
         if x.is_cuda:
             from algorithm.fused_conv import conv_stack_desc, fused_conv_stack   # lazy: avoids an import cycle

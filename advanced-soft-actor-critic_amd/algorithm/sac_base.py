@@ -243,6 +243,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fold_rep_q_adam = bool(hip_config.get('fold_rep_q_adam', True))
         self._rep_grad_one_position = bool(hip_config.get('rep_grad_one_position', True))
         self._deferred_cat = bool(hip_config.get('deferred_cat', True))
+        self._rep_from_burn_in = bool(hip_config.get('rep_from_burn_in', True))
         self._fused_curiosity = bool(hip_config.get('fused_curiosity', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
@@ -1742,12 +1743,23 @@ class SAC_Base(AuxHeadsMixin):
         # backward of a convolution stack shrinks L-fold) beside a no-grad pass over the window.
         one_position = (self._rep_grad_one_position and self.seq_encoder is None and w.rep_trainable and not with_aux
                         and type(self.model_rep) is not ModelSimpleRep and w.bnx_actions.shape[1] > 1)
+        # ... and the burn-in positions of the window feed nothing before the update (a sequence encoder would carry them
+        # forward; here states[:, b:] is all `_train_rep_q`, the return and the TD error read): the two passes in front of
+        # the update run on the positions from b on — (n + 1) / L of the frames, read in place (`asac_conv2_forward_windows`)
+        from_b = (self._rep_from_burn_in and self.seq_encoder is None and b > 0 and w.rep_trainable
+                  and type(self.model_rep) is not ModelSimpleRep)     # (a fixed representation's one pass serves the whole step)
+        rep_in, pb = w.rep_in, b
+        if from_b:
+            tail = lambda x: None if x is None else x[:, b:]  # noqa: E731
+            idx, pad, obs, pre, hidden = w.rep_in
+            rep_in, pb = (tail(idx), tail(pad), [o[:, b:] for o in obs], tail(pre), tail(hidden)), 0
         with (self._rep_twin if self._rep_twin else contextlib.nullcontext()), cat_mode():
             with torch.no_grad() if one_position else contextlib.nullcontext():
-                bnx_states, next_hidden = self.get_l_states(*w.rep_in, is_target=False)
+                bnx_states, next_hidden = self.get_l_states(*rep_in, is_target=False)
             with torch.no_grad():
-                w.bnx_target_states, _ = self.get_l_states(*w.rep_in, is_target=True)
-        state_base = (bnx_states, b)
+                w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
+        w.nx_target_states = w.bnx_target_states[:, pb:]
+        state_base = (bnx_states, pb)
         if one_position:
             at = lambda x: None if x is None else x[:, b:b + 1]  # noqa: E731
             idx, pad, obs, pre, hidden = w.rep_in
@@ -1759,8 +1771,8 @@ class SAC_Base(AuxHeadsMixin):
         if with_aux:
             aux = dict(n_indexes=w.bn_indexes[:, b:],
                        n_pre_actions=w.bn_actions[:, b - 1:-1] if b > 0 else w.bn_actions[:, 0:0],
-                       n_pre_seq_hidden_states=w.bnx_hidden[:, b:-1], nx_target_states=w.bnx_target_states[:, b:])
-        self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bnx_states[:, b:], w.bnx_actions[:, b:],
+                       n_pre_seq_hidden_states=w.bnx_hidden[:, b:-1], nx_target_states=w.nx_target_states)
+        self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bnx_states[:, pb:], w.bnx_actions[:, b:],
                           w.bn_rewards[:, b:], w.bn_dones[:, b:], w.bn_mu_probs[:, b:], w.priority_is, aux,
                           policy_sample=w.stock and not w.rep_trainable,
                           state_base=state_base)
@@ -1852,7 +1864,7 @@ class SAC_Base(AuxHeadsMixin):
         td_own = self.use_priority and not same_states
         td_rows = sc_elect = None
         if td_own:
-            td_rows = StockMLP._rows_in_place(w.bnx_target_states[:, b:], self.state_size)
+            td_rows = StockMLP._rows_in_place(w.nx_target_states, self.state_size)
             job_win, ls_out = self._fpi.job(rows_win, None)
             job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
             native.mlp_forward_multi([job_win, job_pi_td])
@@ -1946,7 +1958,7 @@ class SAC_Base(AuxHeadsMixin):
             self._td_update_with = (rb, ids) if merged else None
             own_td_policy = post.td_pi is not None     # the TD target's policy ran over the target states
             td = self._get_td_error(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bn_states[:, b],
-                                    w.bnx_target_states[:, b:], w.bnx_actions[:, b:], w.bn_rewards[:, b:],
+                                    w.nx_target_states, w.bnx_actions[:, b:], w.bn_rewards[:, b:],
                                     w.bn_dones[:, b:], pi_probs[:, b:] if self.use_n_step_is else None,
                                     ls=None if post.td_sample is None else (post.ls_td if own_td_policy else post.ls_win),
                                     sample=post.td_sample,

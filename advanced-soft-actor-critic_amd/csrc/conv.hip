@@ -59,7 +59,18 @@ struct ConvArgs {
     const float* gy;                            // backward: gradient of y
     float* partial;                             // backward: [blocks][param_count]
     int64_t N, n_groups;
+    // forward over a SLICE of sampled windows (x[:, b:] of [B][L][C][H][W], read in place): a sample's frames are
+    // consecutive, samples x_sample_stride floats apart, x_sample_groups whole groups per sample (0: dense [N])
+    int64_t x_sample_stride;
+    int32_t x_sample_groups;
 };
+
+// first frame of group g in memory
+__device__ __forceinline__ const float* group_frames(const ConvArgs& a, int64_t g) {
+    if (a.x_sample_groups == 0) return a.x + g * a.d.G * a.d.CHW;
+    const int64_t s = g / a.x_sample_groups;
+    return a.x + s * a.x_sample_stride + (g - s * a.x_sample_groups) * a.d.G * a.d.CHW;
+}
 
 // LDS plan (floats).  fwd: frames | a1 | index tables | reduction slabs
 struct ConvFwdPlan { int img, a1, ktab, koff2, rowx, rowa, ktq, w1q, red, total; };
@@ -96,8 +107,8 @@ __device__ __forceinline__ void stage_frames(const ConvArgs& a, int64_t g, float
     const int64_t first = g * d.G;
     const int n_img = (int)min((int64_t)d.G, a.N - first);
     const int count = n_img * d.CHW, total = d.G * d.CHW;
-    const float* src = a.x + first * d.CHW;
-    if ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+    const float* src = group_frames(a, g);
+    if ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
         float4* d4 = reinterpret_cast<float4*>(img);
         const int c4 = count >> 2, t4 = total >> 2;
@@ -137,7 +148,7 @@ __device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float
     const ConvDims& d = a.d;
     const int64_t first = g * d.G;
     const int n_img = (int)min((int64_t)d.G, a.N - first);
-    async_copy_kib(a.x + first * d.CHW, img, (n_img * d.CHW) >> 2, (d.G * d.CHW + 255) >> 8, wave, lane);
+    async_copy_kib(group_frames(a, g), img, (n_img * d.CHW) >> 2, (d.G * d.CHW + 255) >> 8, wave, lane);
 }
 
 // Two parameter arrays global -> LDS (dst, then dst + nA) by the whole workgroup: each element is fetched once per
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
-    const bool dma = (d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+    const bool dma = (d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0;
     if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames(a, blockIdx.x, img, wave, lane);
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         const int n_img = (int)min((int64_t)d.G, a.N - g * d.G);
@@ -786,6 +797,11 @@ int asac_conv2_supported(const asac_conv2_desc_t* desc) {
     return desc && conv_dims(*desc, d) ? 1 : 0;
 }
 
+int asac_conv2_group_frames(const asac_conv2_desc_t* desc) {
+    ConvDims d;
+    return desc && conv_dims(*desc, d) ? d.G : -1;
+}
+
 int64_t asac_conv2_param_count(const asac_conv2_desc_t* desc) {
     ConvDims d;
     if (!desc || !conv_dims(*desc, d)) return -1;
@@ -801,9 +817,22 @@ int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc, int64_t N) 
 
 int asac_conv2_forward(const asac_conv2_desc_t* desc, const float* x, int64_t N, const float* w1, const float* b1,
                        const float* w2, const float* b2, float* y, float* z1_out, float* z2_out, void* stream) {
+    return asac_conv2_forward_windows(desc, x, N, 0, 0, w1, b1, w2, b2, y, z1_out, z2_out, stream);
+}
+
+int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, int64_t N, int frames_per_sample,
+                               int64_t sample_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* y, float* z1_out, float* z2_out, void* stream) {
     ConvArgs a{};
     if (!desc || !conv_dims(*desc, a.d) || N <= 0 || !x || !w1 || !b1 || !w2 || !b2 || !y || (!z1_out != !z2_out))
         return bad_arg("asac_conv2_forward");
+    if (frames_per_sample) {
+        if (frames_per_sample < 0 || frames_per_sample % a.d.G != 0 || N % frames_per_sample != 0 ||
+            sample_stride < (int64_t)frames_per_sample * a.d.CHW)
+            return bad_arg("asac_conv2_forward_windows");
+        a.x_sample_groups = frames_per_sample / a.d.G;
+        a.x_sample_stride = sample_stride;
+    }
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.y = y; a.z1 = z1_out; a.z2 = z2_out;
     a.N = N;

@@ -278,6 +278,10 @@ _SIGNATURES = {
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_masked_mse_workspace': (C.c_int64, [C.c_int64]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_forward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p]),
     'asac_conv2_param_count': (C.c_int64, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_workspace': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
     'asac_conv2_forward': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -1223,6 +1227,23 @@ def conv2_forward(desc, x, w1, b1, w2, b2, y, z1_out=None, z2_out=None):
     _dense_f32(x, w1, b1, w2, b2, y, z1_out, z2_out)
     _check(load().asac_conv2_forward(C.byref(desc), _p(x), x.shape[0], _p(w1), _p(b1), _p(w2), _p(b2), _p(y),
                                      _p(z1_out), _p(z2_out), _stream()), 'asac_conv2_forward')
+
+
+def conv2_group_frames(desc) -> int:
+    return int(load().asac_conv2_group_frames(C.byref(desc)))
+
+
+@_profiled
+def conv2_forward_windows(desc, x, w1, b1, w2, b2, y, z1_out=None, z2_out=None):
+    """`conv2_forward` over x [B, T, C, H, W] = a slice of the sampled windows (dense frames, samples x.stride(0)
+    floats apart, T a multiple of `conv2_group_frames`), read in place -> y [B * T, out]"""
+    global _last_work
+    B, T = x.shape[:2]
+    _last_work = conv2_flops(desc, B * T)
+    _dense_f32(w1, b1, w2, b2, y, z1_out, z2_out)
+    assert x.dtype == torch.float32 and x.is_cuda and x[0].is_contiguous()
+    _check(load().asac_conv2_forward_windows(C.byref(desc), _p(x), B * T, T, x.stride(0), _p(w1), _p(b1), _p(w2), _p(b2),
+                                             _p(y), _p(z1_out), _p(z2_out), _stream()), 'asac_conv2_forward_windows')
 
 
 @_profiled

@@ -770,6 +770,16 @@ int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc_host, int64_
 int asac_conv2_forward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w1,
                        const float* b1, const float* w2, const float* b2, float* y, float* z1_out, float* z2_out,
                        void* stream);
+/* The same forward over a SLICE of the sampled windows read where it lies: x points at frame [0][b] of a
+ * [B][L][C][H][W] batch, a sample's frames_per_sample frames are consecutive, samples sample_stride floats apart
+ * (N = B * frames_per_sample).  A representation without a sequence encoder only needs the states of the positions
+ * behind the burn-in before its update (sac_base.py:2066-2103: `m_states[:, burn_in_step:]`), so those two passes skip
+ * the burn-in frames without a copy.  frames_per_sample must be a multiple of asac_conv2_group_frames(desc) (a
+ * workgroup's frames then never straddle two samples); anything else returns ASAC_ERR_BAD_ARG (callers copy). */
+int asac_conv2_group_frames(const asac_conv2_desc_t* desc_host);
+int asac_conv2_forward_windows(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, int frames_per_sample,
+                               int64_t sample_stride, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* y, float* z1_out, float* z2_out, void* stream);
 int asac_conv2_backward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w2,
                         const float* z1, const float* z2, const float* grad_y, float* grad_params, int accumulate,
                         float* workspace, void* stream);

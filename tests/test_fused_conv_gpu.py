@@ -105,3 +105,40 @@ def test_conv_stack_adds_parameter_gradients_in_place_inside_flat_buffers():
     (fused_conv_stack(x, desc, dev) * gy).sum().backward()
     for pf, pd in zip(free.parameters(), dev.parameters()):
         np.testing.assert_allclose(pd.grad.cpu().numpy(), 1.0 + pf.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,L,b', [(64, 9, 5), (7, 12, 4), (33, 8, 0)])
+def test_forward_over_a_window_slice_read_in_place(B, L, b):
+    """`asac_conv2_forward_windows` on frames[:, b:] of a [B, L, C, H, W] batch == `asac_conv2_forward` on its
+    contiguous copy, bit for bit; through `ConvLayers` a no-grad call on the slice takes that launch (no copy)."""
+    import asac_amd  # noqa: F401
+    import algorithm.nn_models as m
+    from asac_amd import native
+    torch.manual_seed(B)
+    conv = m.ConvLayers(30, 30, 3, 'simple', out_dense_depth=1, output_size=8).cuda()
+    frames = torch.rand(B, L, 3, 30, 30, device='cuda')
+    view = frames[:, b:]
+    desc = native.conv2_desc(3, 30, 30, 16, 8, 4, 32, 4, 2)
+    G = native.conv2_group_frames(desc)
+    assert G == 4
+    c1, _, c2, _ = list(conv.conv_layers)
+    wd = [t.detach().contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias)]
+    T = L - b
+    want = torch.empty(B * T, 128, device='cuda')
+    native.conv2_forward(desc, view.reshape(B * T, 3, 30, 30).contiguous(), *wd, want)
+    if T % G == 0 and b > 0:
+        got = torch.empty(B * T, 128, device='cuda')
+        native.conv2_forward_windows(desc, view, *wd, got)
+        assert torch.equal(got, want)
+        with native.LaunchProfiler() as prof, torch.no_grad():
+            out = conv(view)
+        assert prof.summary()['asac_conv2_forward_windows']['calls'] == 1 and 'asac_conv2_forward' not in prof.summary()
+    else:
+        with torch.no_grad():
+            out = conv(view)
+    with torch.no_grad():
+        ref = conv(view.contiguous())
+    assert out.shape == (B, T, 8) and torch.equal(out, ref)
+    if T % G == 0 and b > 0:
+        with pytest.raises(native.AsacNativeError):        # a slice whose samples do not hold whole groups
+            native.conv2_forward_windows(desc, frames[:, 1:4], *wd, torch.empty(B * 3, 128, device='cuda'))

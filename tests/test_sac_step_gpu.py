@@ -199,7 +199,7 @@ def test_full_step_unaligned_drift(golden_dir, case):
 # against the fused forms ("cover each surviving switch with one step-parity run").
 SWITCHES = ('sidecars', 'fused_policy_step', 'fused_forward_chain', 'fused_td_chain', 'fused_td_update', 'fused_q_return',
             'fused_q_state_grads', 'twin_rep', 'fused_linear_tanh', 'gru_backward_at', 'adjacent_cat', 'fold_rep_q_adam', 'rep_grad_one_position', 'deferred_cat',
-            'head_sums_members')
+            'head_sums_members', 'rep_from_burn_in')
 
 
 @pytest.mark.parametrize('switch', SWITCHES)

@@ -108,7 +108,8 @@ def test_fused_visual_encoder_matches_module_path(monkeypatch):
     seen = prof.summary()
     # (per step: online window pass, target pass, the differentiable pass over the one position the loss reads, the pass
     # under the updated representation)
-    assert seen['asac_conv2_forward']['calls'] == 12 and seen['asac_conv2_backward']['calls'] == 3
+    assert seen['asac_conv2_forward']['calls'] + seen['asac_conv2_forward_windows']['calls'] == 12
+    assert seen['asac_conv2_backward']['calls'] == 3
     assert seen['asac_linear_tanh_forward2']['calls'] == 12 and seen['asac_linear_tanh_backward2']['calls'] == 3
     torch.cuda.synchronize()
     assert torch.equal(fused.replay_buffer._ids, plain.replay_buffer._ids)
