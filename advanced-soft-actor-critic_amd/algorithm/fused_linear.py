@@ -50,7 +50,16 @@ class _LinearTanhFn(torch.autograd.Function):
     """x0 [..., K0] (| x1 [..., K1]: the two read side by side, `adjacent_cat.DeferredCat`) -> tanh(Linear)"""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, head):
+    def forward(ctx, x0, x1, weight, bias, head, grad_mode=True):
+        train = grad_mode and any(ctx.needs_input_grad[:4])
+        if (not train and x0.dim() == 3 and x0.stride(2) == 1 and not x0.is_contiguous()
+                and x0.stride(0) != x0.stride(1) * x0.shape[1]):
+            # a slice of the sampled windows that does not collapse to uniform rows (vec[:, b:]): read in place by a
+            # pass that saves nothing (the saved rows of a training pass are a copy either way)
+            r1 = None if x1 is None else _as_rows(x1)
+            y = torch.empty(x0.shape[0] * x0.shape[1], weight.shape[0], dtype=x0.dtype, device=x0.device)
+            native.linear_tanh_forward2(native.WindowRows(x0), r1, weight.detach(), bias.detach(), y)
+            return y.view(*x0.shape[:-1], weight.shape[0])
         r0 = _as_rows(x0)
         r1 = None if x1 is None else _as_rows(x1)
         y = torch.empty(r0.shape[0], weight.shape[0], dtype=x0.dtype, device=x0.device)
@@ -91,7 +100,7 @@ class _LinearTanhFn(torch.autograd.Function):
             native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, g, False, ws, members, window, position)
             gw, gb = g[:O * K].view(O, K), g[O * K:]
         return (None if gx0 is None else gx0.view(ctx.x0_shape), None if gx1 is None else gx1.view(ctx.x1_shape),
-                gw, gb, None)
+                gw, gb, None, None)
 
 
 class LinearTanhHead(nn.Sequential):
@@ -117,7 +126,7 @@ class LinearTanhHead(nn.Sequential):
                 x = x.materialize()
         if (FUSED_LINEAR_TANH and x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32
                 and x.shape[-1] + (0 if x1 is None else x1.shape[-1]) == lin.in_features and x.numel() > 0):
-            return _LinearTanhFn.apply(x, x1, lin.weight, lin.bias, self)
+            return _LinearTanhFn.apply(x, x1, lin.weight, lin.bias, self, torch.is_grad_enabled())
         return super().forward(x)
 
 

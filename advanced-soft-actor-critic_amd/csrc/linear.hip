@@ -23,6 +23,8 @@ struct LinArgs {
     const float* x1;
     int64_t x1_stride;
     int K0;
+    int x_T;                // > 0 (forward only): x row r lies at (r / x_T) * x_sb + (r % x_T) * x_stride — a
+    int64_t x_sb;           // [samples][T][K0] slice of the sampled windows (obs[:, b:]) read in place
     const float* w;         // [O][K]
     const float* b;         // [O]
     int64_t N;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_fwd(const LinArgs a) {
     float acc[kLinMaxO];
 #pragma unroll
     for (int o = 0; o < kLinMaxO; ++o) acc[o] = 0.f;
-    const float* xr = a.x + r * a.x_stride;
+    const float* xr = a.x + (a.x_T ? (r / a.x_T) * a.x_sb + (r % a.x_T) * a.x_stride : r * a.x_stride);
     const float* xr1 = a.x1 ? a.x1 + r * a.x1_stride - a.K0 : xr;      // (indexed by k like the first part)
     for (int k = 0; k < a.K; ++k) {
         const float xv = k < a.K0 ? xr[k] : xr1[k];
@@ -207,11 +209,18 @@ int64_t asac_linear_tanh_workspace(int64_t N, int K, int O) {
 
 int asac_linear_tanh_forward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
                               int K1, const float* weight, const float* bias, int64_t N, int O, float* y, void* stream) {
+    return asac_linear_tanh_forward2w(x0, x0_row_stride, 0, 0, K0, x1, x1_row_stride, K1, weight, bias, N, O, y, stream);
+}
+
+int asac_linear_tanh_forward2w(const float* x0, int64_t x0_row_stride, int x0_window_T, int64_t x0_sample_stride, int K0,
+                               const float* x1, int64_t x1_row_stride, int K1, const float* weight, const float* bias,
+                               int64_t N, int O, float* y, void* stream) {
     const int K = K0 + (x1 ? K1 : 0);
     if (!lin_dims_ok(N, K, O) || !x0 || K0 <= 0 || !weight || !bias || !y || x0_row_stride < K0 ||
-        (x1 && (K1 <= 0 || x1_row_stride < K1)))
+        (x1 && (K1 <= 0 || x1_row_stride < K1)) || x0_window_T < 0 || (x0_window_T && N % x0_window_T != 0))
         return bad_arg("asac_linear_tanh_forward");
     LinArgs a{};
+    a.x_T = x0_window_T, a.x_sb = x0_sample_stride;
     a.x = x0, a.x_stride = x0_row_stride, a.K0 = K0, a.x1 = x1, a.x1_stride = x1_row_stride;
     a.w = weight, a.b = bias, a.N = N, a.K = K, a.O = O, a.y = y;
     ASAC_LAUNCH(k_linear_tanh_fwd, dim3((unsigned)((N + kLinRows - 1) / kLinRows)), dim3(kLinRows), 0, as_stream(stream), a);

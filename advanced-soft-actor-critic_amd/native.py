@@ -269,6 +269,8 @@ _SIGNATURES = {
                                             C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_linear_tanh_forward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_linear_tanh_forward2w': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                             C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_linear_tanh_backward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -1162,11 +1164,16 @@ def masked_mse(pred, target, padding_mask, grad_out, loss_out):
 def linear_tanh_forward2(x0, x1, weight, bias, y):
     """y[N, O] = tanh([x0 | x1][N, K0 + K1] weight^T + bias): the concatenation read in place (x1 may be None)"""
     _dense_f32(weight, bias, y)
-    p0, s0 = _rows2(x0)
+    if isinstance(x0, WindowRows):      # [samples, T, K0] slice of the sampled windows, read in place
+        t = x0.t
+        assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32
+        p0, s0, T, sb, N, K0 = _p(t), t.stride(1), t.shape[1], t.stride(0), t.shape[0] * t.shape[1], t.shape[2]
+    else:
+        (p0, s0), T, sb, N, K0 = _rows2(x0), 0, 0, x0.shape[0], x0.shape[1]
     p1, s1 = _rows2(x1) if x1 is not None else (None, 0)
-    assert x1 is None or x1.shape[0] == x0.shape[0]
-    _check(load().asac_linear_tanh_forward2(p0, s0, x0.shape[1], p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
-                                            _p(bias), x0.shape[0], weight.shape[0], _p(y), _stream()),
+    assert x1 is None or x1.shape[0] == N
+    _check(load().asac_linear_tanh_forward2w(p0, s0, T, sb, K0, p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
+                                             _p(bias), N, weight.shape[0], _p(y), _stream()),
            'asac_linear_tanh_forward2')
 
 

@@ -952,6 +952,11 @@ int asac_linear_tanh_backward(const float* x, int64_t x_row_stride, const float*
  * the materialised concatenation / gradient, bit for bit. */
 int asac_linear_tanh_forward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
                               int K1, const float* weight, const float* bias, int64_t N, int O, float* y, void* stream);
+/* ... forward with x0 a [samples][x0_window_T][K0] slice of the sampled windows (`vec[:, burn_in_step:]`) read in place:
+ * row r lies at (r / x0_window_T) * x0_sample_stride + (r % x0_window_T) * x0_row_stride (x0_window_T = 0: uniform rows) */
+int asac_linear_tanh_forward2w(const float* x0, int64_t x0_row_stride, int x0_window_T, int64_t x0_sample_stride, int K0,
+                               const float* x1, int64_t x1_row_stride, int K1, const float* weight, const float* bias,
+                               int64_t N, int O, float* y, void* stream);
 int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
                                int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
                                int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,

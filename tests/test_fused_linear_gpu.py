@@ -201,3 +201,33 @@ def test_deferred_concatenation_reaches_the_fused_head_in_two_blocks():
     torch.testing.assert_close(feat.grad, feat_ref.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(head[0].weight.grad, ref[0].weight.grad, rtol=1e-4, atol=2e-4)
     torch.testing.assert_close(head[0].bias.grad, ref[0].bias.grad, rtol=1e-4, atol=2e-4)
+
+
+def test_no_grad_head_reads_a_window_slice_in_place():
+    """A no-grad call of the fused head on [vec[:, b:] | features] (vec a non-collapsible slice of the sampled windows)
+    == the same call on contiguous copies, without a copy launch (`asac_linear_tanh_forward2w`)."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm import fused_linear as fl
+    from algorithm.adjacent_cat import AdjacentCat
+    torch.manual_seed(1)
+    dev = 'cuda:0'
+    holder = nn.Module()
+    holder.dense = nn.Sequential(nn.Linear(18, 8), nn.Tanh()).to(dev)
+    assert fl.fuse_linear_tanh_heads(holder) == 1
+    joint = torch.randn(33, 9, 14, device=dev)
+    vec = joint[:, 5:, :10]                                   # [33, 4, 10], rows 14 apart, samples 126 apart
+    feat = torch.randn(33, 4, 8, device=dev)
+    with torch.no_grad():
+        want = holder.dense(torch.cat([vec.contiguous(), feat], dim=-1))
+        with AdjacentCat(64), native.LaunchProfiler() as prof:
+            got = holder.dense(torch.cat([vec, feat], dim=-1))
+        assert torch.equal(got, want) and prof.summary()['asac_linear_tanh_forward2']['calls'] == 1
+        assert torch.equal(holder.dense(vec.expand(33, 4, 10)[..., :10].new_zeros(33, 4, 18)), holder.dense(torch.zeros(33, 4, 18, device=dev)))
+    # with gradients wanted the rows are saved: the ordinary (copying) path, same values
+    feat_g = feat.clone().requires_grad_(True)
+    with AdjacentCat(64):
+        out = holder.dense(torch.cat([vec, feat_g], dim=-1))
+    assert torch.equal(out, want)
+    out.sum().backward()
+    assert feat_g.grad is not None and holder.dense[0].weight.grad is not None
