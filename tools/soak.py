@@ -31,7 +31,7 @@ def main():
             assert torch.isfinite(flat).all(), f'non-finite parameters at step {step}'
             g = getattr(agent, '_g_state_base', None)
             if g is not None:      # the state-gradient buffer must stay zero outside the slice the Q step writes
-                b = agent.burn_in_step
+                b = agent.burn_in_step if g.shape[1] > 1 else 0      # (a one-position differentiable pass: [B, 1, S])
                 assert float(g[:, :b].abs().sum()) == 0.0 and float(g[:, b + 1:].abs().sum()) == 0.0, 'state-gradient buffer'
             print(step, 'ok; |theta| =', float(flat.norm()), 'graph' if agent._graph is not None else 'eager', flush=True)
     agent.close()
