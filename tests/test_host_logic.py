@@ -130,3 +130,29 @@ def test_adjacent_cat_returns_views_only_for_side_by_side_blocks():
         assert torch.equal(out, base[..., :6])
         assert torch.equal(torch.cat([a, b], dim=1), torch.cat([a.clone(), b.clone()], 1)) if a.shape[-1] == b.shape[-1] else True
         assert torch.equal(torch.stack([a, a]).sum(0), 2 * a)
+
+
+def test_deferred_cat_behaves_like_the_concatenation_for_every_other_consumer():
+    """`adjacent_cat.DeferredCat`: whatever touches the object — a torch function, a method, an operator, an attribute,
+    `nn.Linear` — sees `torch.cat(parts, -1)`, formed once; gradients reach the parts."""
+    import torch
+    from torch import nn
+    import asac_amd  # noqa: F401
+    from algorithm.adjacent_cat import DeferredCat, deferrable
+    a = torch.randn(5, 3, 4)
+    b = torch.randn(5, 3, 2, requires_grad=True)
+    want = torch.cat([a, b], dim=-1)
+    d = DeferredCat([a, b])
+    assert d.width == 6 and d._value is None
+    assert torch.equal(torch.relu(d), torch.relu(want)) and d._value is not None
+    first = d._value
+    assert torch.equal(d + 1, want + 1) and torch.equal(2 * d, 2 * want) and torch.equal(-d, -want)
+    assert d.shape == want.shape and d.dim() == 3 and len(d) == 5 and torch.equal(d[1], want[1])
+    assert torch.equal(d.reshape(15, 6), want.reshape(15, 6)) and torch.equal(torch.stack([d, d]), torch.stack([want, want]))
+    assert d._value is first                                   # materialised once
+    lin = nn.Linear(6, 2)
+    out = lin(DeferredCat([a, b]))
+    out.sum().backward()
+    assert b.grad is not None and torch.equal(out, lin(want))
+    assert not deferrable([a, b], -1, 64)                      # host tensors are never deferred
+    assert not deferrable([a], -1, 64) and not deferrable([a, b, a], -1, 64)
