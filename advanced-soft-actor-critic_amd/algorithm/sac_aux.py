@@ -133,9 +133,19 @@ class AuxHeadsMixin:
             aux = [autograd.grad(loss, params, allow_unused=True, retain_graph=True) for loss in loss_list]
         aux = [[ga if ga is not None else torch.zeros_like(gm) for gm, ga in zip(grads_main, gs)] for gs in aux]
         flat_main = torch.cat([g.reshape(1, -1) for g in grads_main], dim=1)
+        # inside the learner the gradients are consecutive views of ONE buffer: the gated sum is then two launches per
+        # loss over that buffer instead of two per parameter tensor (same products, same sums, entry by entry)
+        flat_grad = None
+        if all(p.grad is not None for p in params) and params[0].is_cuda:
+            from .fused_mlp import _flat_alias
+            flat_grad = _flat_alias([p.grad for p in params])
         for gs in aux:
-            cos = functional.cosine_similarity(flat_main, torch.cat([g.reshape(1, -1) for g in gs], dim=1))
+            flat_aux = torch.cat([g.reshape(1, -1) for g in gs], dim=1)
+            cos = functional.cosine_similarity(flat_main, flat_aux)
             gate = torch.sign(cos).clamp(min=0)
+            if flat_grad is not None and flat_aux.numel() == flat_grad.numel():
+                flat_grad.add_(flat_aux.view(-1).mul_(gate))
+                continue
             for p, g in zip(params, gs):
                 p.grad += gate * g
 
@@ -240,9 +250,21 @@ class AuxHeadsMixin:
         if grads_rep_main:
             self.calculate_adaptive_weights(grads_rep_main, [loss_transition, loss_reward, loss_obs], self.model_rep)
         loss = loss_transition + loss_reward + loss_obs
-        self.optimizer_prediction.zero_grad()
-        loss.backward(inputs=list(chain(self.model_transition.parameters(), self.model_reward.parameters(),
-                                        self.model_observation.parameters())))
+        pred_params = list(chain(self.model_transition.parameters(), self.model_reward.parameters(),
+                                 self.model_observation.parameters()))
+        flat_grad = None
+        if pred_params and pred_params[0].is_cuda and all(p.grad is not None for p in pred_params):
+            from .fused_mlp import _flat_alias
+            flat_grad = _flat_alias([p.grad for p in pred_params])
+        if flat_grad is not None:
+            # the models' gradients are consecutive views of one buffer: written there by ONE concatenation instead of a
+            # zero fill and an accumulation launch per parameter tensor (0 + g = g)
+            gs = autograd.grad(loss, pred_params, allow_unused=True)
+            torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, pred_params)],
+                      out=flat_grad)
+        else:
+            self.optimizer_prediction.zero_grad()
+            loss.backward(inputs=pred_params)
         if self._dist is not None:
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('prediction'))
         self.optimizer_prediction.step()
