@@ -36,6 +36,7 @@ class ModelTransition(ModelBaseTransition):
                 raise Exception('use_extra_data is True but extra_size is zero')
             n_in += extra_size
         self.dense = LinearLayers(n_in, dense_n, dense_depth, self.state_size * 2)
+        self.dense.fuse = True     # one launch per pass when the stack fits (fused_mlp.describe_dense)
 
     def forward(self, obs_list, state, action):
         if self.use_extra_data:
@@ -60,6 +61,7 @@ class ModelBaseReward(nn.Module):
 class ModelReward(ModelBaseReward):
     def _build_model(self, dense_n=64, dense_depth=0):
         self.dense = LinearLayers(self.state_size, dense_n, dense_depth, 1)
+        self.dense.fuse = True
 
     def forward(self, state):
         return self.dense(state)
