@@ -19,6 +19,36 @@ from .utils.enums import SEQ_ENCODER, SIAMESE
 from .utils.operators import get_last_false_indexes
 
 
+class _NormalNllKlFn(autograd.Function):
+    """-mean(log N(x; loc, scale)) + w mean(KL(N(loc, scale) || N(0, 1))) and the mean entropy as ONE launch that also
+    leaves d loss / d loc and d loss / d scale (`asac_normal_nll_kl`); the backward scales them."""
+
+    @staticmethod
+    def forward(ctx, loc, scale, target, w):
+        from asac_amd import native
+        g_loc, g_scale = torch.empty(loc.shape, device=loc.device), torch.empty(loc.shape, device=loc.device)
+        out = torch.empty(2, device=loc.device)
+        native.normal_nll_kl(loc.detach(), scale.detach(), target.detach(), w, g_loc, g_scale, out)
+        ctx.save_for_backward(g_loc, g_scale)
+        entropy = out[1]
+        ctx.mark_non_differentiable(entropy)
+        return out[0], entropy
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_entropy):
+        g_loc, g_scale = ctx.saved_tensors
+        return g_loss * g_loc, g_loss * g_scale, None, None
+
+
+def _normal_nll_kl_ok(dist, target) -> bool:
+    from asac_amd import native
+    loc, scale = dist.loc, dist.scale
+    return (type(dist) is distributions.Normal and loc.is_cuda and loc.dim() == 3 and loc.dtype == torch.float32
+            and scale.shape == loc.shape and target.shape == loc.shape and target.dtype == torch.float32
+            and loc.stride(-1) == 1 and scale.stride(-1) == 1 and target.stride(-1) == 1
+            and 0 < loc.numel() <= native.MASKED_MSE_MAX and not target.requires_grad)
+
+
 class AuxHeadsMixin:
     # ------------------------------------------------------------------------------------------
     # construction
@@ -240,11 +270,16 @@ class AuxHeadsMixin:
         (`retain_graph` on the Q loss) so the head runs."""
         n_obs = [o[:, :-1] for o in nx_obses_list]
         dist_next = self.model_transition(n_obs, nx_states[:, :-1], n_actions)
-        loss_transition = -torch.mean(dist_next.log_prob(nx_target_states[:, 1:]))
-        std_normal = distributions.Normal(torch.zeros_like(dist_next.loc), torch.ones_like(dist_next.scale),
-                                          validate_args=False)
-        loss_transition = loss_transition + self.transition_kl * torch.mean(
-            distributions.kl.kl_divergence(dist_next, std_normal))
+        entropy_next = None
+        if self._fused_rpm_loss and _normal_nll_kl_ok(dist_next, nx_target_states[:, 1:]):
+            loss_transition, entropy_next = _NormalNllKlFn.apply(dist_next.loc, dist_next.scale, nx_target_states[:, 1:],
+                                                                 float(self.transition_kl))
+        else:
+            loss_transition = -torch.mean(dist_next.log_prob(nx_target_states[:, 1:]))
+            std_normal = distributions.Normal(torch.zeros_like(dist_next.loc), torch.ones_like(dist_next.scale),
+                                              validate_args=False)
+            loss_transition = loss_transition + self.transition_kl * torch.mean(
+                distributions.kl.kl_divergence(dist_next, std_normal))
         loss_reward = functional.mse_loss(self.model_reward(nx_states[:, 1:]), n_rewards.unsqueeze(2)) / self.n_step
         loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
         if grads_rep_main:
@@ -268,7 +303,9 @@ class AuxHeadsMixin:
         if self._dist is not None:
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('prediction'))
         self.optimizer_prediction.step()
-        return torch.mean(dist_next.entropy()).detach(), loss_reward.detach(), loss_obs.detach()
+        if entropy_next is None:
+            entropy_next = torch.mean(dist_next.entropy())
+        return entropy_next.detach(), loss_reward.detach(), loss_obs.detach()
 
     def _train_rnd(self, n_padding_masks, n_states, n_actions):
         """Distil the frozen random target network on visited (state, action) pairs (1978-2025)."""

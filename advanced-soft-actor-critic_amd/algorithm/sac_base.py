@@ -245,6 +245,7 @@ class SAC_Base(AuxHeadsMixin):
         self._deferred_cat = bool(hip_config.get('deferred_cat', True))
         self._rep_from_burn_in = bool(hip_config.get('rep_from_burn_in', True))
         self._fused_curiosity = bool(hip_config.get('fused_curiosity', True))
+        self._fused_rpm_loss = bool(hip_config.get('fused_rpm_loss', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None

@@ -202,6 +202,80 @@ __global__ __launch_bounds__(kMseThreads) void k_masked_mse(const float* __restr
     }
 }
 
+// Transition model's loss (SAC_Base._train_rpm, reference sac_base.py:1798-1816): for the model's Normal(loc, scale)
+// over the next state and the target representation's state x,
+//   loss = -mean(log N(x; loc, scale)) + w * mean(KL(N(loc, scale) || N(0, 1))),  entropy = mean(H(N(loc, scale)))
+// with torch.distributions' formulas, and d loss / d loc, d loss / d scale — the forward AND the backward of ATen's
+// ~25 + ~35 elementwise launches over [B, n, S] tensors as one launch.  Sums over several workgroups, added in workgroup
+// order by the last to arrive.
+__global__ __launch_bounds__(kMseThreads) void k_normal_nll_kl(const float* __restrict__ loc, int64_t loc_sb, int64_t loc_st,
+                                                               const float* __restrict__ scale, int64_t scale_sb,
+                                                               int64_t scale_st, const float* __restrict__ target,
+                                                               int64_t target_sb, int64_t target_st, int B, int T, int K,
+                                                               float w, float* __restrict__ grad_loc,
+                                                               float* __restrict__ grad_scale, float* __restrict__ out,
+                                                               float* __restrict__ partial, unsigned int* __restrict__ counter) {
+    __shared__ float red[3][kMseThreads];
+    __shared__ bool last;
+    const int N = B * T * K;
+    const float inv_n = 1.f / (float)N;
+    const float c_lp = 0.918938533204672742f;        // log(sqrt(2 pi))
+    const float c_ent = 1.418938533204672742f;       // 0.5 + 0.5 log(2 pi)
+    const int base = blockIdx.x * kMseThreads * kMsePerLane;
+    float mu[kMsePerLane], sg[kMsePerLane], xv[kMsePerLane], s_lp = 0.f, s_kl = 0.f, s_ent = 0.f;
+#pragma unroll
+    for (int u = 0; u < kMsePerLane; ++u) {
+        const int i = min(base + u * kMseThreads + (int)threadIdx.x, N - 1);
+        const int row = i / K, k = i - row * K, b = row / T, t = row - b * T;
+        mu[u] = loc[b * loc_sb + t * loc_st + k];
+        sg[u] = scale[b * scale_sb + t * scale_st + k];
+        xv[u] = target[b * target_sb + t * target_st + k];
+    }
+#pragma unroll
+    for (int u = 0; u < kMsePerLane; ++u) {
+        const int i = base + u * kMseThreads + (int)threadIdx.x;
+        if (i < N) {
+            const float d = xv[u] - mu[u], var = sg[u] * sg[u], ls = logf(sg[u]), inv_s = 1.f / sg[u];
+            s_lp += -(d * d) / (2.f * var) - ls - c_lp;
+            s_kl += 0.5f * (var + mu[u] * mu[u] - 1.f - logf(var));
+            s_ent += c_ent + ls;
+            grad_loc[i] = (-(d / var) + w * mu[u]) * inv_n;
+            grad_scale[i] = (-((d * d) / (var * sg[u])) + inv_s + w * (sg[u] - inv_s)) * inv_n;
+        }
+    }
+    red[0][threadIdx.x] = s_lp, red[1][threadIdx.x] = s_kl, red[2][threadIdx.x] = s_ent;
+    __syncthreads();
+    for (int h = kMseThreads / 2; h >= 64; h >>= 1) {
+        if ((int)threadIdx.x < h) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + h];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float v = red[q][threadIdx.x];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+            if (threadIdx.x == 0) partial[blockIdx.x * 3 + q] = v;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b2 = 0.f, e = 0.f;
+        for (unsigned int g = 0; g < gridDim.x; ++g) a += partial[g * 3], b2 += partial[g * 3 + 1], e += partial[g * 3 + 2];
+        out[0] = -(a * inv_n) + w * (b2 * inv_n);
+        out[1] = e * inv_n;
+        *counter = 0u;
+    }
+}
+
 inline int stream_grid(int64_t n_vec) {
     int64_t b = (n_vec + 255) / 256;
     if (b < 1) b = 1;
@@ -251,6 +325,27 @@ int asac_masked_mse(const float* pred, const float* target, int64_t target_strid
                 target_stride_t, padding_mask, mask_stride_b, B, T, K, grad_out, loss_out, workspace,
                 reinterpret_cast<unsigned int*>(workspace + blocks));
     return finish_launch("asac_masked_mse");
+}
+
+int64_t asac_normal_nll_kl_workspace(int64_t n) {
+    if (n <= 0 || n > ASAC_MASKED_MSE_MAX) return -1;
+    return 3 * ((n + kMseThreads * kMsePerLane - 1) / (kMseThreads * kMsePerLane)) + 1;
+}
+
+int asac_normal_nll_kl(const float* loc, int64_t loc_stride_b, int64_t loc_stride_t, const float* scale,
+                       int64_t scale_stride_b, int64_t scale_stride_t, const float* target, int64_t target_stride_b,
+                       int64_t target_stride_t, int B, int T, int K, float kl_weight, float* grad_loc, float* grad_scale,
+                       float* loss_entropy_out, float* workspace, void* stream) {
+    const int64_t n = (int64_t)B * T * K;
+    if (B <= 0 || T <= 0 || K <= 0 || !loc || !scale || !target || !grad_loc || !grad_scale || !loss_entropy_out ||
+        !workspace || n > ASAC_MASKED_MSE_MAX)
+        return bad_arg("asac_normal_nll_kl");
+    const int64_t blocks = (asac_normal_nll_kl_workspace(n) - 1) / 3;
+    ASAC_LAUNCH(k_normal_nll_kl, dim3((unsigned)blocks), dim3(kMseThreads), 0, as_stream(stream), loc, loc_stride_b,
+                loc_stride_t, scale, scale_stride_b, scale_stride_t, target, target_stride_b, target_stride_t, B, T, K,
+                kl_weight, grad_loc, grad_scale, loss_entropy_out, workspace,
+                reinterpret_cast<unsigned int*>(workspace + 3 * blocks));
+    return finish_launch("asac_normal_nll_kl");
 }
 
 int asac_gelu_eval(const float* z, float* value, float* deriv, int64_t n, void* stream) {

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 52
+ABI_VERSION = 53
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -279,6 +279,10 @@ _SIGNATURES = {
     'asac_masked_mse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_masked_mse_workspace': (C.c_int64, [C.c_int64]),
+    'asac_normal_nll_kl_workspace': (C.c_int64, [C.c_int64]),
+    'asac_normal_nll_kl': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_forward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -1158,6 +1162,26 @@ def masked_mse(pred, target, padding_mask, grad_out, loss_out):
         _MSE_WS[key] = torch.zeros(int(load().asac_masked_mse_workspace(pred.numel())), dtype=torch.float32, device=pred.device)
     _check(load().asac_masked_mse(_p(pred), pt, sb, st, pm, ms, B, T, K, _p(grad_out), _p(loss_out), _p(_MSE_WS[key]),
                                   _stream()), 'asac_masked_mse')
+
+
+_NLL_WS = {}
+
+
+@_profiled
+def normal_nll_kl(loc, scale, target, kl_weight, grad_loc, grad_scale, out):
+    """out[0] <- -mean(log N(target; loc, scale)) + kl_weight * mean(KL(N(loc, scale) || N(0, 1))), out[1] <- mean
+    entropy, grad_loc / grad_scale <- d out[0] / d loc, / d scale ([B, T, K] views in, dense gradients out)"""
+    B, T, K = loc.shape
+    assert scale.shape == loc.shape and target.shape == loc.shape and grad_loc.is_contiguous() and grad_scale.is_contiguous()
+    assert grad_loc.numel() == loc.numel() == grad_scale.numel() and out.numel() == 2 and out.is_contiguous()
+    pl, lb, lt = _window3(loc)
+    ps, sb, st = _window3(scale)
+    pt, tb, tt = _window3(target)
+    key = (loc.numel(), loc.device)
+    if key not in _NLL_WS:
+        _NLL_WS[key] = torch.zeros(int(load().asac_normal_nll_kl_workspace(loc.numel())), dtype=torch.float32, device=loc.device)
+    _check(load().asac_normal_nll_kl(pl, lb, lt, ps, sb, st, pt, tb, tt, B, T, K, float(kl_weight), _p(grad_loc),
+                                     _p(grad_scale), _p(out), _p(_NLL_WS[key]), _stream()), 'asac_normal_nll_kl')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 52
+#define ASAC_ABI_VERSION 53
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -923,6 +923,20 @@ int64_t asac_masked_mse_workspace(int64_t n);
 int asac_masked_mse(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t,
                     const uint8_t* padding_mask, int64_t mask_stride_b, int B, int T, int K, float* grad_out,
                     float* loss_out, float* workspace, void* stream);
+
+/* Loss of the recurrent prediction model's transition head and its gradient (SAC_Base._train_rpm,
+ * sac_base.py:1798-1816; torch/distributions/normal.py log_prob / entropy, kl.py _kl_normal_normal):
+ *   out[0] = -mean(log N(target; loc, scale)) + kl_weight * mean(KL(N(loc, scale) || N(0, 1)))
+ *   out[1] = mean entropy of N(loc, scale)
+ *   grad_loc / grad_scale [B][T][K] dense = d out[0] / d loc, / d scale
+ * loc / scale / target [B][T][K] views with strides in floats (the two halves of the model's output, a slice of the
+ * target representation's window).  One launch for ~60 elementwise ATen launches forward and backward; sums in
+ * workgroup order (last to arrive); workspace asac_normal_nll_kl_workspace(N) floats, zero before first use. */
+int64_t asac_normal_nll_kl_workspace(int64_t n);
+int asac_normal_nll_kl(const float* loc, int64_t loc_stride_b, int64_t loc_stride_t, const float* scale,
+                       int64_t scale_stride_b, int64_t scale_stride_t, const float* target, int64_t target_stride_b,
+                       int64_t target_stride_t, int B, int T, int K, float kl_weight, float* grad_loc, float* grad_scale,
+                       float* loss_entropy_out, float* workspace, void* stream);
 
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with

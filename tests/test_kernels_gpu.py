@@ -767,3 +767,31 @@ def test_curiosity_bonus_and_masked_mse_against_the_aten_chains(nat):
     assert abs(float(loss) - float(want_loss)) <= 2e-6 * float(want_loss)
     nat.masked_mse(approx, nxt, None, grad, loss)
     torch.testing.assert_close(grad, (approx - nxt) * (2. / dm.numel()), rtol=1e-6, atol=1e-9)
+
+
+def test_normal_nll_kl_against_torch_distributions(nat):
+    """`asac_normal_nll_kl` == the transition head's loss of SAC_Base._train_rpm written with torch.distributions
+    (reference sac_base.py:1798-1816), its entropy statistic and autograd's gradients w.r.t. loc / scale, on strided
+    views (the two halves of a model output, a slice of a window); f32 rounding of N-term sums (rtol 2e-6 on the loss,
+    1e-5 on gradient entries)."""
+    from torch import distributions as D
+    g = torch.Generator().manual_seed(9)
+    B, L, S, w = 64, 4, 8, 0.37
+    raw = torch.randn(B, L - 1, 2 * S, generator=g).cuda().requires_grad_(True)
+    window = torch.randn(B, L, S, generator=g).cuda()
+    loc, logstd = torch.chunk(raw, 2, dim=-1)
+    scale = torch.clamp(torch.exp(logstd), 0.1, 1.0)
+    target = window[:, 1:]
+    dist = D.Normal(loc, scale, validate_args=False)
+    std = D.Normal(torch.zeros_like(loc), torch.ones_like(scale), validate_args=False)
+    want = -torch.mean(dist.log_prob(target)) + w * torch.mean(D.kl.kl_divergence(dist, std))
+    want_loc, want_scale = torch.autograd.grad(want, [loc, scale])
+    g_loc, g_scale = torch.empty(B, L - 1, S, device='cuda'), torch.empty(B, L - 1, S, device='cuda')
+    out = torch.empty(2, device='cuda')
+    nat.normal_nll_kl(loc.detach(), scale.detach(), target, w, g_loc, g_scale, out)
+    torch.testing.assert_close(out[0], want.detach(), rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(out[1], dist.entropy().mean().detach(), rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(g_loc, want_loc, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(g_scale, want_scale, rtol=1e-5, atol=1e-9)
+    nat.normal_nll_kl(loc.detach(), scale.detach(), target, w, g_loc, g_scale, out)      # the workspace is clean again
+    torch.testing.assert_close(out[0], want.detach(), rtol=2e-6, atol=1e-6)
