@@ -91,8 +91,9 @@ def test_optional_heads_vs_reference_golden(golden_dir, case):
     agent.close()
 
 
+@pytest.mark.parametrize('fused_loss', [True, False], ids=['one_launch_loss', 'aten_loss'])
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
-def test_rpm_vs_reference_golden(golden_dir, tag):
+def test_rpm_vs_reference_golden(golden_dir, tag, fused_loss):
     """`use_prediction` (BASELINE configs[4]): the product's `_train_rpm` — transition / reward / observation losses,
     the cosine-sign gating of their gradients into the representation (`calculate_adaptive_weights`), the prediction
     models' Adam step — against the reference's OWN `_train_rpm` called on the same inputs (`f11_rpm.npz`).  The
@@ -106,7 +107,7 @@ def test_rpm_vs_reference_golden(golden_dir, tag):
     torch.manual_seed(0)
     agent = SAC_Base(['vector'], [(6,)], [], 2, None, nn_vec_full, device='cuda:0', batch_size=int(B), n_step=int(n),
                      replay_config={'capacity': 256}, use_prediction=True, transition_kl=float(kl),
-                     use_extra_data=bool(extra), hip_config={'use_graph': False})
+                     use_extra_data=bool(extra), hip_config={'use_graph': False, 'fused_rpm_loss': fused_loss})
     heads = ('model_rep', 'model_target_rep', 'model_transition', 'model_reward', 'model_observation')
     with torch.no_grad():
         for name in heads:
@@ -117,7 +118,7 @@ def test_rpm_vs_reference_golden(golden_dir, tag):
     nx_states, _ = agent.model_rep(obs, None, None)
     with torch.no_grad():
         nx_target_states, _ = agent.model_target_rep(obs, None, None)
-    K = f'aux/rpm_{tag}'
+    K = f'aux/rpm_{tag}' if fused_loss else f'aux/rpm_{tag}_aten_loss'
     pu.check(f'{K}/nx_states', nx_states, g[f'{tag}/nx_states'], rtol=1e-5, atol=1e-6)
     main = float(g[f'{tag}/flip']) * torch.mean(torch.square(torch.sum(nx_states * cu('coef'), dim=-1)))
     agent._params.grad.zero_()
