@@ -246,6 +246,7 @@ class SAC_Base(AuxHeadsMixin):
         self._rep_from_burn_in = bool(hip_config.get('rep_from_burn_in', True))
         self._fused_curiosity = bool(hip_config.get('fused_curiosity', True))
         self._fused_rpm_loss = bool(hip_config.get('fused_rpm_loss', True))
+        self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
@@ -1260,14 +1261,21 @@ class SAC_Base(AuxHeadsMixin):
             if self.clip_epsilon > 0:
                 with torch.no_grad():
                     t_q = self._c_q_values(True, state.detach(), c_action, obs_list)
-                if losses is None and aux is None:
-                    # loss value and d(sum_e l_e)/dq from one launch; back-propagation starts at q
+                if losses is None and (aux is None or self._fused_q_loss_with_aux):
+                    # loss value and d(sum_e l_e)/dq from one launch; back-propagation starts at q (with auxiliary heads
+                    # too: they only need the graph kept for the prediction models' second pass and the main gradients
+                    # in place before they gate theirs)
                     w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                     native.q_loss_fwd_bwd(c_q.detach().contiguous(), t_q.contiguous(), c_y.reshape(-1), w,
                                           self.clip_epsilon, self._loss_q_e, self._grad_q)
                     with direct_param_grads():
-                        torch.autograd.backward([c_q], [self._grad_q])
-                    return self._finish_rep_q(None, None)
+                        torch.autograd.backward([c_q], [self._grad_q],
+                                                retain_graph=aux is not None and self.use_prediction)
+                    if aux is None:
+                        return self._finish_rep_q(None, None)
+                    return self._finish_rep_q(None, None, aux,
+                                              dict(n_padding_masks=n_padding_masks, nx_obses_list=nx_obses_list,
+                                                   nx_states=nx_states, nx_actions=nx_actions, n_rewards=n_rewards))
                 clipped = t_q + torch.clamp(c_q - t_q, -self.clip_epsilon, self.clip_epsilon)
                 yv = c_y.reshape(1, -1)
                 c_loss = torch.maximum((clipped - yv) ** 2, (c_q - yv) ** 2).unsqueeze(-1)
