@@ -51,14 +51,26 @@ class _ConvStackFn(torch.autograd.Function):
         # (`needs_input_grad` mirrors `requires_grad` whatever the caller's grad mode, and inside `forward` the mode is
         # always off: the caller's mode is handed in, so that a no-grad pass over trainable parameters saves nothing)
         train = grad_mode and any(ctx.needs_input_grad[2:6])
-        if windows is not None and not train:
-            # `windows` [B, T, C, H, W]: the frames as a slice of the sampled windows (x is its reshape: a copy the
-            # caller has NOT made yet when it is lazy — here x is only consulted for its shape)
+        if windows is not None:
+            # `windows` [B, T, C, H, W]: the frames as a slice of the sampled windows, read in place forward and backward
+            # (x is a stand-in consulted for its shape only; the slice lives in the step's static batch, which outlasts
+            # the backward)
             y = torch.empty(N, _out_width(desc), dtype=windows.dtype, device=windows.device)
             wd = [t.detach().contiguous() for t in (w1, b1, w2, b2)]
-            native.conv2_forward_windows(desc, windows, *wd, y)
+            z1 = z2 = None
+            if train:
+                h1 = (desc.height - desc.kernel1) // desc.stride1 + 1
+                w1o = (desc.width - desc.kernel1) // desc.stride1 + 1
+                z1 = torch.empty(N, h1 * w1o, desc.out1, dtype=windows.dtype, device=windows.device)
+                z2 = torch.empty_like(y)
+            native.conv2_forward_windows(desc, windows, *wd, y, z1, z2)
+            if train:
+                ctx.desc, ctx.windows = desc, True
+                ctx.save_for_backward(windows, z1, z2, w2)
+                ctx.params = (w1, b1, w2, b2)
             return y
-        x = (x if windows is None else windows.reshape(N, *x.shape[1:])).contiguous()
+        ctx.windows = False
+        x = x.contiguous()
         h1 = (desc.height - desc.kernel1) // desc.stride1 + 1
         w1o = (desc.width - desc.kernel1) // desc.stride1 + 1
         h2, w2o = (h1 - desc.kernel2) // desc.stride2 + 1, (w1o - desc.kernel2) // desc.stride2 + 1
@@ -78,7 +90,9 @@ class _ConvStackFn(torch.autograd.Function):
     def backward(ctx, grad_y):
         desc = ctx.desc
         x, z1, z2, w2 = ctx.saved_tensors
-        ws = torch.empty(native.conv2_backward_workspace(desc, x.shape[0]), dtype=x.dtype, device=x.device)
+        n_frames = x.shape[0] * x.shape[1] if ctx.windows else x.shape[0]
+        run = native.conv2_backward_windows if ctx.windows else native.conv2_backward
+        ws = torch.empty(native.conv2_backward_workspace(desc, n_frames), dtype=x.dtype, device=x.device)
         params = ctx.params
         # the four gradients as one packed block: inside the learner they are consecutive views of the flat
         # gradient buffer, and the reduction kernel adds into them directly (no AccumulateGrad launches)
@@ -86,10 +100,10 @@ class _ConvStackFn(torch.autograd.Function):
         if DIRECT_PARAM_GRADS and direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
         if flat is not None:
-            native.conv2_backward(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws, True)
+            run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws, True)
             return (None, None, None, None, None, None, None, None)
         g = torch.empty(native.conv2_param_count(desc), dtype=x.dtype, device=x.device)
-        native.conv2_backward(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws)
+        run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws)
         grads, off = [], 0
         for p in params:
             k = p.numel()
@@ -106,10 +120,9 @@ def _out_width(desc):
 
 def window_slice(x5, desc):
     """x5 [B, T, C, H, W] -> x5 itself when it is a slice of sampled windows the forward can read in place (dense
-    frames, a sample's T frames consecutive, T whole workgroup groups, no gradient pass to save a copy for), else None"""
+    frames, a sample's T frames consecutive, T whole workgroup groups), else None"""
     if (x5.dim() == 5 and not x5.is_contiguous() and x5[0].is_contiguous() and x5.stride(0) % 4 == 0
-            and x5.shape[1] % native.conv2_group_frames(desc) == 0 and x5.data_ptr() % 16 == 0
-            and not torch.is_grad_enabled()):
+            and x5.shape[1] % native.conv2_group_frames(desc) == 0 and x5.data_ptr() % 16 == 0):
         return x5
     return None
 

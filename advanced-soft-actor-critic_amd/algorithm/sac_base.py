@@ -1750,8 +1750,12 @@ class SAC_Base(AuxHeadsMixin):
         # acting), and the Q loss reads the state of ONE window position — everything else of the window only feeds
         # detached targets.  The differentiable pass then covers that position's rows alone (B of B L frames: the
         # backward of a convolution stack shrinks L-fold) beside a no-grad pass over the window.
+        # (where the pass in front of the update already covers only a few positions — `from_b` below, n + 1 <= 8 — the
+        # extra forward's small-launch floors cost more than the backward over those few positions saves: cfg4, n + 1 = 4,
+        # 2 755 with it against 2 787 steps/s without)
         one_position = (self._rep_grad_one_position and self.seq_encoder is None and w.rep_trainable and not with_aux
-                        and type(self.model_rep) is not ModelSimpleRep and w.bnx_actions.shape[1] > 1)
+                        and type(self.model_rep) is not ModelSimpleRep and w.bnx_actions.shape[1] > 1
+                        and not (self._rep_from_burn_in and b > 0 and self.n_step + 1 <= 8))
         # ... and the burn-in positions of the window feed nothing before the update (a sequence encoder would carry them
         # forward; here states[:, b:] is all `_train_rep_q`, the return and the TD error read): the two passes in front of
         # the update run on the positions from b on — (n + 1) / L of the frames, read in place (`asac_conv2_forward_windows`)

@@ -515,12 +515,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     }
     // frames and saved z1 rows travel by LDS-DMA when 16-byte granular; the output-side operands (two elements of gy
     // and z2 per thread) are fetched into registers one group ahead
-    const bool dma = (d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 &&
+    const bool dma = (d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 && (a.x_sample_stride & 3) == 0 &&
                      ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0;
     auto request = [&](int64_t g, int buf) {
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
-        async_copy_kib(a.x + first * d.CHW, lds + p.img + buf * p.img_size, (n_img * d.CHW) >> 2, p.img_size >> 8, wave,
+        async_copy_kib(group_frames(a, g), lds + p.img + buf * p.img_size, (n_img * d.CHW) >> 2, p.img_size >> 8, wave,
                        lane);
     };
     auto request_z = [&](int64_t g) {
@@ -850,9 +850,22 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, in
 int asac_conv2_backward(const asac_conv2_desc_t* desc, const float* x, int64_t N, const float* w2, const float* z1,
                         const float* z2, const float* grad_y, float* grad_params, int accumulate, float* workspace,
                         void* stream) {
+    return asac_conv2_backward_windows(desc, x, N, 0, 0, w2, z1, z2, grad_y, grad_params, accumulate, workspace, stream);
+}
+
+int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, int64_t N, int frames_per_sample,
+                                int64_t sample_stride, const float* w2, const float* z1, const float* z2,
+                                const float* grad_y, float* grad_params, int accumulate, float* workspace, void* stream) {
     ConvArgs a{};
     if (!desc || !conv_dims(*desc, a.d) || N <= 0 || !x || !w2 || !z1 || !z2 || !grad_y || !grad_params || !workspace)
         return bad_arg("asac_conv2_backward");
+    if (frames_per_sample) {
+        if (frames_per_sample < 0 || frames_per_sample % a.d.G != 0 || N % frames_per_sample != 0 ||
+            sample_stride < (int64_t)frames_per_sample * a.d.CHW)
+            return bad_arg("asac_conv2_backward_windows");
+        a.x_sample_groups = frames_per_sample / a.d.G;
+        a.x_sample_stride = sample_stride;
+    }
     a.x = x; a.w2 = w2;
     a.z1 = const_cast<float*>(z1); a.z2 = const_cast<float*>(z2);
     a.gy = grad_y;

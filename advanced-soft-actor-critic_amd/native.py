@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 53
+ABI_VERSION = 54
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -285,6 +285,9 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_backward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p]),
     'asac_conv2_forward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
@@ -1275,6 +1278,19 @@ def conv2_forward_windows(desc, x, w1, b1, w2, b2, y, z1_out=None, z2_out=None):
     assert x.dtype == torch.float32 and x.is_cuda and x[0].is_contiguous()
     _check(load().asac_conv2_forward_windows(C.byref(desc), _p(x), B * T, T, x.stride(0), _p(w1), _p(b1), _p(w2), _p(b2),
                                              _p(y), _p(z1_out), _p(z2_out), _stream()), 'asac_conv2_forward_windows')
+
+
+@_profiled
+def conv2_backward_windows(desc, x, w2, z1, z2, grad_y, grad_params, workspace, accumulate=False):
+    """`conv2_backward` with x [B, T, C, H, W] a slice of the sampled windows read in place (see `conv2_forward_windows`)"""
+    global _last_work
+    B, T = x.shape[:2]
+    _last_work = conv2_flops(desc, B * T, backward=True)
+    _dense_f32(w2, z1, z2, grad_y, grad_params, workspace)
+    assert x.dtype == torch.float32 and x.is_cuda and x[0].is_contiguous()
+    _check(load().asac_conv2_backward_windows(C.byref(desc), _p(x), B * T, T, x.stride(0), _p(w2), _p(z1), _p(z2),
+                                              _p(grad_y), _p(grad_params), int(bool(accumulate)), _p(workspace),
+                                              _stream()), 'asac_conv2_backward_windows')
 
 
 @_profiled

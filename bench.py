@@ -108,7 +108,7 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_squash_sample_fwd': 'asac::k_squash_sample_fwd', 'asac_gru_forward': 'asac::k_gru_fwd',
               'asac_gru_backward': 'asac::k_gru_bwd', 'asac_scatter_rows_if_id_match': 'asac::k_scatter_write',
               'asac_conv2_forward': 'asac::k_conv2_fwd', 'asac_conv2_backward': 'asac::k_conv2_bwd',
-              'asac_conv2_forward_windows': 'asac::k_conv2_fwd',
+              'asac_conv2_forward_windows': 'asac::k_conv2_fwd', 'asac_conv2_backward_windows': 'asac::k_conv2_bwd',
               'asac_attention_proj_forward': 'asac::k_attn_proj_fwd', 'asac_attention_proj_backward': 'asac::k_attn_proj_bwd',
               'asac_linear_tanh_forward': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward': 'asac::k_linear_tanh_bwd',
               'asac_linear_tanh_forward2': 'asac::k_linear_tanh_fwd', 'asac_linear_tanh_backward2': 'asac::k_linear_tanh_bwd',

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 53
+#define ASAC_ABI_VERSION 54
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -780,6 +780,10 @@ int asac_conv2_group_frames(const asac_conv2_desc_t* desc_host);
 int asac_conv2_forward_windows(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, int frames_per_sample,
                                int64_t sample_stride, const float* w1, const float* b1, const float* w2, const float* b2,
                                float* y, float* z1_out, float* z2_out, void* stream);
+/* ... and the backward of such a pass: x addressed the same way, z1 / z2 / grad_y dense over the N frames. */
+int asac_conv2_backward_windows(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, int frames_per_sample,
+                                int64_t sample_stride, const float* w2, const float* z1, const float* z2,
+                                const float* grad_y, float* grad_params, int accumulate, float* workspace, void* stream);
 int asac_conv2_backward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w2,
                         const float* z1, const float* z2, const float* grad_y, float* grad_params, int accumulate,
                         float* workspace, void* stream);

@@ -140,5 +140,14 @@ def test_forward_over_a_window_slice_read_in_place(B, L, b):
         ref = conv(view.contiguous())
     assert out.shape == (B, T, 8) and torch.equal(out, ref)
     if T % G == 0 and b > 0:
+        # ... and with gradients: the slice is read in place forward and backward, same parameter gradients as on a copy
+        grads = []
+        for src in (view, view.contiguous()):
+            conv.zero_grad(set_to_none=True)
+            with native.LaunchProfiler() as prof:
+                conv(src).square().sum().backward()
+            grads.append([p.grad.clone() for p in conv.parameters()])
+            assert ('asac_conv2_backward_windows' in prof.summary()) == (src is view)
+        assert all(torch.equal(a, c) for a, c in zip(*grads))
         with pytest.raises(native.AsacNativeError):        # a slice whose samples do not hold whole groups
             native.conv2_forward_windows(desc, frames[:, 1:4], *wd, torch.empty(B * 3, 128, device='cuda'))

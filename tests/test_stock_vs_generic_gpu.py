@@ -106,11 +106,11 @@ def test_fused_visual_encoder_matches_module_path(monkeypatch):
         for _ in range(3):
             fused.train()
     seen = prof.summary()
-    # (per step: online window pass, target pass, the differentiable pass over the one position the loss reads, the pass
-    # under the updated representation)
-    assert seen['asac_conv2_forward']['calls'] + seen['asac_conv2_forward_windows']['calls'] == 12
-    assert seen['asac_conv2_backward']['calls'] == 3
-    assert seen['asac_linear_tanh_forward2']['calls'] == 12 and seen['asac_linear_tanh_backward2']['calls'] == 3
+    # (per step: the online and the target pass over the positions behind the burn-in, the pass over the window under the
+    # updated representation; with n + 1 = 4 positions the online pass is the differentiable one)
+    assert seen['asac_conv2_forward']['calls'] + seen.get('asac_conv2_forward_windows', {'calls': 0})['calls'] == 9
+    assert seen.get('asac_conv2_backward', {'calls': 0})['calls'] + seen.get('asac_conv2_backward_windows', {'calls': 0})['calls'] == 3
+    assert seen['asac_linear_tanh_forward2']['calls'] == 9 and seen['asac_linear_tanh_backward2']['calls'] == 3
     torch.cuda.synchronize()
     assert torch.equal(fused.replay_buffer._ids, plain.replay_buffer._ids)
     np.testing.assert_allclose(fused._params.flat.cpu().numpy(), plain._params.flat.cpu().numpy(), rtol=3e-3, atol=5e-5)
