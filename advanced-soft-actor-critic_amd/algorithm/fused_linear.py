@@ -52,14 +52,20 @@ class _LinearTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, head, grad_mode=True):
         train = grad_mode and any(ctx.needs_input_grad[:4])
-        if (not train and x0.dim() == 3 and x0.stride(2) == 1 and not x0.is_contiguous()
+        if (x0.dim() == 3 and x0.stride(2) == 1 and not x0.is_contiguous() and not ctx.needs_input_grad[0]
                 and x0.stride(0) != x0.stride(1) * x0.shape[1]):
-            # a slice of the sampled windows that does not collapse to uniform rows (vec[:, b:]): read in place by a
-            # pass that saves nothing (the saved rows of a training pass are a copy either way)
+            # a slice of the sampled windows that does not collapse to uniform rows (vec[:, b:], data): read in place,
+            # forward and backward, by (sample, step) addressing
             r1 = None if x1 is None else _as_rows(x1)
             y = torch.empty(x0.shape[0] * x0.shape[1], weight.shape[0], dtype=x0.dtype, device=x0.device)
             native.linear_tanh_forward2(native.WindowRows(x0), r1, weight.detach(), bias.detach(), y)
+            if train:
+                ctx.window = True
+                ctx.save_for_backward(x0, y, *([] if r1 is None else [r1]))
+                ctx.weight, ctx.bias, ctx.head = weight, bias, head
+                ctx.x0_shape, ctx.x1_shape = x0.shape, None if x1 is None else x1.shape
             return y.view(*x0.shape[:-1], weight.shape[0])
+        ctx.window = False
         r0 = _as_rows(x0)
         r1 = None if x1 is None else _as_rows(x1)
         y = torch.empty(r0.shape[0], weight.shape[0], dtype=x0.dtype, device=x0.device)
@@ -74,7 +80,13 @@ class _LinearTanhFn(torch.autograd.Function):
         r0, y, *rest = ctx.saved_tensors
         r1 = rest[0] if rest else None
         weight, bias = ctx.weight, ctx.bias
-        N, K0 = r0.shape
+        if ctx.window:
+            N, K0 = r0.shape[0] * r0.shape[1], r0.shape[2]
+            r0 = native.WindowRows(r0)
+            dev, dt = y.device, y.dtype
+        else:
+            N, K0 = r0.shape
+            dev, dt = r0.device, r0.dtype
         K = K0 + (0 if r1 is None else r1.shape[1])
         O = weight.shape[0]
         at = _MEMBERS if (_MEMBERS is not None and _MEMBERS[0] is ctx) else None
@@ -84,10 +96,10 @@ class _LinearTanhFn(torch.autograd.Function):
         else:
             gy, members, window, position = grad_y.reshape(N, O), 1, 1, 0
             gy = gy if gy.is_contiguous() else gy.contiguous()
-        empty = lambda k: torch.empty(N, k, dtype=r0.dtype, device=r0.device)  # noqa: E731
+        empty = lambda k: torch.empty(N, k, dtype=dt, device=dev)  # noqa: E731
         gx0 = empty(K0) if ctx.needs_input_grad[0] else None
         gx1 = empty(K - K0) if (r1 is not None and ctx.needs_input_grad[1]) else None
-        ws = ctx.head._workspace(N, K, O, r0.device)
+        ws = ctx.head._workspace(N, K, O, dev)
         flat = None
         if (direct_enabled() and weight.requires_grad and bias.requires_grad and weight.grad is not None
                 and bias.grad is not None):
@@ -96,7 +108,7 @@ class _LinearTanhFn(torch.autograd.Function):
             native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, flat, True, ws, members, window, position)
             gw = gb = None
         else:
-            g = torch.empty(O * K + O, dtype=r0.dtype, device=r0.device)
+            g = torch.empty(O * K + O, dtype=dt, device=dev)
             native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, g, False, ws, members, window, position)
             gw, gb = g[:O * K].view(O, K), g[O * K:]
         return (None if gx0 is None else gx0.view(ctx.x0_shape), None if gx1 is None else gx1.view(ctx.x1_shape),

@@ -23,7 +23,7 @@ struct LinArgs {
     const float* x1;
     int64_t x1_stride;
     int K0;
-    int x_T;                // > 0 (forward only): x row r lies at (r / x_T) * x_sb + (r % x_T) * x_stride — a
+    int x_T;                // > 0: x row r lies at (r / x_T) * x_sb + (r % x_T) * x_stride — a
     int64_t x_sb;           // [samples][T][K0] slice of the sampled windows (obs[:, b:]) read in place
     const float* w;         // [O][K]
     const float* b;         // [O]
@@ -108,8 +108,9 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
     }
     const int XS = a.K + 1;
     {
-        const float* xr = a.x + (live ? r : r0) * a.x_stride;
-        const float* xr1 = a.x1 ? a.x1 + (live ? r : r0) * a.x1_stride - a.K0 : xr;
+        const int64_t rs = live ? r : r0;
+        const float* xr = a.x + (a.x_T ? (rs / a.x_T) * a.x_sb + (rs % a.x_T) * a.x_stride : rs * a.x_stride);
+        const float* xr1 = a.x1 ? a.x1 + rs * a.x1_stride - a.K0 : xr;
         for (int k = 0; k < a.K; ++k) xs[threadIdx.x * XS + k] = live ? (k < a.K0 ? xr[k] : xr1[k]) : 0.f;
         xs[threadIdx.x * XS + a.K] = 1.f;
     }
@@ -236,13 +237,25 @@ int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, c
                                int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
                                int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,
                                float* grad_params, int accumulate, float* workspace, void* stream) {
+    return asac_linear_tanh_backward2w(x0, x0_row_stride, 0, 0, K0, x1, x1_row_stride, K1, weight, y, grad_y, grad_members,
+                                       grad_window, grad_position, N, O, grad_x0, grad_x1, grad_params, accumulate,
+                                       workspace, stream);
+}
+
+int asac_linear_tanh_backward2w(const float* x0, int64_t x0_row_stride, int x0_window_T, int64_t x0_sample_stride, int K0,
+                                const float* x1, int64_t x1_row_stride, int K1, const float* weight, const float* y,
+                                const float* grad_y, int grad_members, int grad_window, int grad_position, int64_t N, int O,
+                                float* grad_x0, float* grad_x1, float* grad_params, int accumulate, float* workspace,
+                                void* stream) {
     const int K = K0 + (x1 ? K1 : 0);
+    if (x0_window_T < 0 || (x0_window_T && N % x0_window_T != 0)) return bad_arg("asac_linear_tanh_backward");
     if (!lin_dims_ok(N, K, O) || !x0 || K0 <= 0 || !weight || !y || !grad_y || !grad_params || !workspace ||
         x0_row_stride < K0 || (x1 && (K1 <= 0 || x1_row_stride < K1)) || (!x1 && grad_x1) || grad_members <= 0 ||
         grad_window <= 0 || N % grad_window != 0 || grad_position < 0 || grad_position >= grad_window)
         return bad_arg("asac_linear_tanh_backward");
     const int64_t blocks = (N + kLinRows - 1) / kLinRows;
     LinArgs a{};
+    a.x_T = x0_window_T, a.x_sb = x0_sample_stride;
     a.x = x0, a.x_stride = x0_row_stride, a.K0 = K0, a.x1 = x1, a.x1_stride = x1_row_stride;
     a.w = weight, a.N = N, a.K = K, a.O = O;
     a.y = const_cast<float*>(y), a.gy = grad_y, a.gy_members = grad_members, a.gy_window = grad_window;

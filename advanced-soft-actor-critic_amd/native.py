@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 54
+ABI_VERSION = 55
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -271,6 +271,10 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_linear_tanh_forward2w': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                              C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_linear_tanh_backward2w': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p]),
     'asac_linear_tanh_backward2': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -1210,14 +1214,19 @@ def linear_tanh_backward2(x0, x1, weight, y, grad_y, grad_x0, grad_x1, grad_para
     """`linear_tanh_backward` over the two-part input; grad_y [members, N / window, O]: row r's output gradient is
     sum_e grad_y[e, r // window] when r % window == position, zero otherwise (1, 1, 0: dense [N, O])."""
     _dense_f32(weight, y, grad_y, grad_x0, grad_x1, grad_params, workspace)
-    p0, s0 = _rows2(x0)
+    if isinstance(x0, WindowRows):      # [samples, T, K0] slice of the sampled windows, read in place
+        t = x0.t
+        assert t.dim() == 3 and t.stride(2) == 1 and t.dtype == torch.float32
+        p0, s0, T, sb, N, K0 = _p(t), t.stride(1), t.shape[1], t.stride(0), t.shape[0] * t.shape[1], t.shape[2]
+    else:
+        (p0, s0), T, sb, N, K0 = _rows2(x0), 0, 0, x0.shape[0], x0.shape[1]
     p1, s1 = _rows2(x1) if x1 is not None else (None, 0)
-    N, O = x0.shape[0], weight.shape[0]
+    O = weight.shape[0]
     assert grad_y.numel() == members * (N // window) * O and N % window == 0
-    _check(load().asac_linear_tanh_backward2(p0, s0, x0.shape[1], p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
-                                             _p(y), _p(grad_y), members, window, position, N, O, _p(grad_x0),
-                                             _p(grad_x1), _p(grad_params), int(bool(accumulate)), _p(workspace),
-                                             _stream()), 'asac_linear_tanh_backward2')
+    _check(load().asac_linear_tanh_backward2w(p0, s0, T, sb, K0, p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
+                                              _p(y), _p(grad_y), members, window, position, N, O, _p(grad_x0),
+                                              _p(grad_x1), _p(grad_params), int(bool(accumulate)), _p(workspace),
+                                              _stream()), 'asac_linear_tanh_backward2')
 
 
 def conv2_desc(channels, height, width, out1, kernel1, stride1, out2, kernel2, stride2) -> Conv2Desc:

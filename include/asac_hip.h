@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 54
+#define ASAC_ABI_VERSION 55
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -970,11 +970,16 @@ int asac_linear_tanh_backward(const float* x, int64_t x_row_stride, const float*
  * the materialised concatenation / gradient, bit for bit. */
 int asac_linear_tanh_forward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
                               int K1, const float* weight, const float* bias, int64_t N, int O, float* y, void* stream);
-/* ... forward with x0 a [samples][x0_window_T][K0] slice of the sampled windows (`vec[:, burn_in_step:]`) read in place:
+/* ... forward / backward (`2w`) with x0 a [samples][x0_window_T][K0] slice of the sampled windows (`vec[:, burn_in_step:]`) read in place:
  * row r lies at (r / x0_window_T) * x0_sample_stride + (r % x0_window_T) * x0_row_stride (x0_window_T = 0: uniform rows) */
 int asac_linear_tanh_forward2w(const float* x0, int64_t x0_row_stride, int x0_window_T, int64_t x0_sample_stride, int K0,
                                const float* x1, int64_t x1_row_stride, int K1, const float* weight, const float* bias,
                                int64_t N, int O, float* y, void* stream);
+int asac_linear_tanh_backward2w(const float* x0, int64_t x0_row_stride, int x0_window_T, int64_t x0_sample_stride, int K0,
+                                const float* x1, int64_t x1_row_stride, int K1, const float* weight, const float* y,
+                                const float* grad_y, int grad_members, int grad_window, int grad_position, int64_t N, int O,
+                                float* grad_x0, float* grad_x1, float* grad_params, int accumulate, float* workspace,
+                                void* stream);
 int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, const float* x1, int64_t x1_row_stride,
                                int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
                                int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,

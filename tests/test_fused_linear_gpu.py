@@ -224,10 +224,14 @@ def test_no_grad_head_reads_a_window_slice_in_place():
             got = holder.dense(torch.cat([vec, feat], dim=-1))
         assert torch.equal(got, want) and prof.summary()['asac_linear_tanh_forward2']['calls'] == 1
         assert torch.equal(holder.dense(vec.expand(33, 4, 10)[..., :10].new_zeros(33, 4, 18)), holder.dense(torch.zeros(33, 4, 18, device=dev)))
-    # with gradients wanted the rows are saved: the ordinary (copying) path, same values
+    # with gradients wanted: the same slice addressing forward and backward (asac_linear_tanh_backward2w), same values
     feat_g = feat.clone().requires_grad_(True)
     with AdjacentCat(64):
         out = holder.dense(torch.cat([vec, feat_g], dim=-1))
     assert torch.equal(out, want)
     out.sum().backward()
-    assert feat_g.grad is not None and holder.dense[0].weight.grad is not None
+    got_w, got_f = holder.dense[0].weight.grad.clone(), feat_g.grad.clone()
+    holder.zero_grad(set_to_none=True)
+    feat_c = feat.clone().requires_grad_(True)
+    holder.dense(torch.cat([vec.contiguous(), feat_c], dim=-1)).sum().backward()
+    assert torch.equal(got_w, holder.dense[0].weight.grad) and torch.equal(got_f, feat_c.grad)
