@@ -116,11 +116,12 @@ def deferrable(tensors, dim, max_width) -> bool:
 
 class AdjacentCat(TorchFunctionMode):
     """`defer_width` > 0: a two-block last-dim concatenation up to that width that is not already a view comes back as a
-    `DeferredCat`"""
+    `DeferredCat`; `widths` (a set) restricts that to the total widths some consumer is known to take in two blocks
+    (the input widths of the representation's fused Linear + Tanh heads)"""
 
-    def __init__(self, defer_width: int = 0):
+    def __init__(self, defer_width: int = 0, widths=None):
         super().__init__()
-        self.defer_width = defer_width
+        self.defer_width, self.widths = defer_width, widths
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -130,6 +131,7 @@ class AdjacentCat(TorchFunctionMode):
                 view = joined_view(args[0], dim)
                 if view is not None:
                     return view
-                if self.defer_width and deferrable(args[0], dim, self.defer_width):
+                if (self.defer_width and deferrable(args[0], dim, self.defer_width)
+                        and (self.widths is None or args[0][0].shape[-1] + args[0][1].shape[-1] in self.widths)):
                     return DeferredCat(args[0])
         return func(*args, **kwargs)

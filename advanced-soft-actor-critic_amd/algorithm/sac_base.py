@@ -571,7 +571,10 @@ class SAC_Base(AuxHeadsMixin):
             from .adjacent_cat import AdjacentCat
             self.replay_buffer.join_vector_obs_with_pre_action(self.d_action_summed_size + self.c_action_size)
             width = native.LINEAR_TANH_MAX_IN if (self._deferred_cat and self._fuse_linear_tanh) else 0
-            self._cat_mode = lambda: AdjacentCat(width)
+            # (deferred only at the widths a fused head of this representation takes: nothing else can use the two blocks)
+            from .fused_linear import LinearTanhHead
+            widths = {m[0].in_features for m in self.model_rep.modules() if isinstance(m, LinearTanhHead)}
+            self._cat_mode = lambda: AdjacentCat(width if widths else 0, widths)
         if self._dist is not None and self._dist_sampling == 'parity':
             # SURVEY 8e "parity": every batch is the reference's stratified sample over the UNION of the ranks' shards
             # (global batch = world_size * batch_size, this rank trains on batch_size rows of it)
