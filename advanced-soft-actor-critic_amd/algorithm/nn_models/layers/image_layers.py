@@ -158,6 +158,11 @@ class ConvTransposeLayers(nn.Module):
 
     def forward(self, x):
         assert x.dim() >= 2, 'The dimension of input should be greater than or equal to 2'
+        if x.is_cuda:
+            from algorithm.fused_decoder import fused_obs_decoder      # lazy: avoids an import cycle
+            vis = fused_obs_decoder(self, x)      # the reference plugins' 2x2x32 -> 30x30x3 decoder on MFMA (csrc/decoder.hip)
+            if vis is not None:
+                return vis
         x = self.dense(x)
         lead = x.shape[:-1]
         vis = self.conv_transpose(x.reshape(-1, self._channels, self._height, self._width))

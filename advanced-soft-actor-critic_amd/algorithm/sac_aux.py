@@ -161,6 +161,11 @@ class AuxHeadsMixin:
         params = list(model.parameters())
         with torch.enable_grad():
             aux = [autograd.grad(loss, params, allow_unused=True, retain_graph=True) for loss in loss_list]
+        self._add_gated_gradients(grads_main, aux, params)
+
+    @torch.no_grad()
+    def _add_gated_gradients(self, grads_main, aux, params) -> None:
+        """The second half of `calculate_adaptive_weights` (reference 1619-1631): `aux` = one gradient list per loss"""
         aux = [[ga if ga is not None else torch.zeros_like(gm) for gm, ga in zip(grads_main, gs)] for gs in aux]
         flat_main = torch.cat([g.reshape(1, -1) for g in grads_main], dim=1)
         # inside the learner the gradients are consecutive views of ONE buffer: the gated sum is then two launches per
@@ -282,11 +287,30 @@ class AuxHeadsMixin:
                 distributions.kl.kl_divergence(dist_next, std_normal))
         loss_reward = functional.mse_loss(self.model_reward(nx_states[:, 1:]), n_rewards.unsqueeze(2)) / self.n_step
         loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
-        if grads_rep_main:
-            self.calculate_adaptive_weights(grads_rep_main, [loss_transition, loss_reward, loss_obs], self.model_rep)
+        model_params = [list(mod.parameters()) for mod in (self.model_transition, self.model_reward, self.model_observation)]
+        pred_params = list(chain(*model_params))
+        losses = [loss_transition, loss_reward, loss_obs]
+        if grads_rep_main and self._rpm_single_backward and nx_states.requires_grad:
+            # Every loss reaches the representation through `nx_states` alone and only its own model's parameters, so
+            # ONE walk through each model yields both what the reference's two walks do (1827: d loss_i / d rep for the
+            # gates; 1831-1834: d (sum of losses) / d model_i = d loss_i / d model_i): the walk stops at `nx_states`,
+            # the representation's graph is entered from there once per loss as in `calculate_adaptive_weights`.
+            rep_params = list(self.model_rep.parameters())
+            aux, gs = [], []
+            for loss_i, params_i in zip(losses, model_params):
+                got = autograd.grad(loss_i, [nx_states, *params_i], allow_unused=True, retain_graph=True)
+                gs += got[1:]
+                if got[0] is None:
+                    aux.append([None] * len(rep_params))
+                else:
+                    aux.append(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
+                                             retain_graph=True))
+            self._add_gated_gradients(grads_rep_main, aux, rep_params)
+        else:
+            if grads_rep_main:
+                self.calculate_adaptive_weights(grads_rep_main, losses, self.model_rep)
+            gs = None
         loss = loss_transition + loss_reward + loss_obs
-        pred_params = list(chain(self.model_transition.parameters(), self.model_reward.parameters(),
-                                 self.model_observation.parameters()))
         flat_grad = None
         if pred_params and pred_params[0].is_cuda and all(p.grad is not None for p in pred_params):
             from .fused_mlp import _flat_alias
@@ -294,9 +318,15 @@ class AuxHeadsMixin:
         if flat_grad is not None:
             # the models' gradients are consecutive views of one buffer: written there by ONE concatenation instead of a
             # zero fill and an accumulation launch per parameter tensor (0 + g = g)
-            gs = autograd.grad(loss, pred_params, allow_unused=True)
+            if gs is None:
+                gs = autograd.grad(loss, pred_params, allow_unused=True)
             torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, pred_params)],
                       out=flat_grad)
+        elif gs is not None:
+            self.optimizer_prediction.zero_grad()
+            for p, g in zip(pred_params, gs):
+                if g is not None:
+                    p.grad = g if p.grad is None else p.grad.copy_(g)
         else:
             self.optimizer_prediction.zero_grad()
             loss.backward(inputs=pred_params)

@@ -246,6 +246,8 @@ class SAC_Base(AuxHeadsMixin):
         self._rep_from_burn_in = bool(hip_config.get('rep_from_burn_in', True))
         self._fused_curiosity = bool(hip_config.get('fused_curiosity', True))
         self._fused_rpm_loss = bool(hip_config.get('fused_rpm_loss', True))
+        # one backward walk per prediction model (gates and model gradients from it): sac_aux._train_rpm
+        self._rpm_single_backward = bool(hip_config.get('rpm_single_backward', True))
         self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)

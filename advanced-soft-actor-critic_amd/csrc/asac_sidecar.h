@@ -178,6 +178,9 @@ __device__ __forceinline__ bool scatter_target(const ScatterArgs& a, int flat, i
     const int s = flat / a.count;
     const int j = flat - s * a.count;
     if (a.padding_mask && a.padding_mask[(int64_t)s * a.mask_sample_stride + j]) return false;
+    // a negative sample id marks a sample another replay shard owns (sharded "parity" sampling, algorithm/parallel.py):
+    // none of its window rows is this shard's to write, whatever id + offset comes to
+    if (a.ids[s] < 0) return false;
     const int64_t tid = a.ids[s] + a.first_off + j;
     const int slot = ring_slot(tid, a.capacity);
     *slot_out = slot;

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 55
+ABI_VERSION = 56
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -142,6 +142,12 @@ class Conv2Desc(C.Structure):
 
 GRU_MAX_LAYERS, GRU_MAX_DIM = 2, 16
 _PtrArray = C.c_void_p * GRU_MAX_LAYERS
+
+class ObsDecoderParams(C.Structure):
+    """`asac_obs_decoder_params_t`: the ten parameter tensors of the observation decoder (or their gradients)"""
+    _fields_ = [(n, C.c_void_p) for n in ('dense1_w', 'dense1_b', 'dense2_w', 'dense2_b', 'ct1_w', 'ct1_b', 'ct2_w',
+                                          'ct2_b', 'ct3_w', 'ct3_b')]
+
 
 _SIGNATURES = {
     'asac_version': (C.c_int, []),
@@ -338,6 +344,14 @@ _SIGNATURES = {
     'asac_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     'asac_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'asac_obs_decoder_packed_floats': (C.c_int64, []),
+    'asac_obs_decoder_saved_floats': (C.c_int64, [C.c_int64]),
+    'asac_obs_decoder_workspace_floats': (C.c_int64, [C.c_int64]),
+    'asac_obs_decoder_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(ObsDecoderParams),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_obs_decoder_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.POINTER(ObsDecoderParams), C.c_int, C.c_void_p,
+                                            C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -1566,3 +1580,60 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, steps_don
     assert steps_done.dtype == torch.int64
     _check(load().asac_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr,
                                  beta1, beta2, eps, _p(steps_done), _stream()), 'asac_adam_step')
+
+
+# ------------------------------------------------------------------------------------------------
+# observation decoder of the prediction models (csrc/decoder.hip)
+# ------------------------------------------------------------------------------------------------
+OBS_DECODER_SHAPES = ((64, None), (64,), (128, 64), (128,), (32, 32, 4, 4), (32,), (32, 16, 8, 8), (16,), (16, 3, 3, 3), (3,))
+# multiply-adds of one state's pass through the three transposed convolutions and the dense head
+OBS_DECODER_MACS = 64 * 16 + 128 * 64 + 4 * 16 * 32 * 32 + 36 * 64 * 32 * 16 + 784 * 9 * 16 * 3
+
+
+def _obs_decoder_params(tensors, state_size) -> ObsDecoderParams:
+    assert len(tensors) == 10
+    for t, shape in zip(tensors, OBS_DECODER_SHAPES):
+        want = tuple(state_size if d is None else d for d in shape)
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == want, (t.shape, want)
+    ps = ObsDecoderParams(*[t.data_ptr() for t in tensors])
+    ps._keep = tuple(tensors)
+    return ps
+
+
+def obs_decoder_packed_floats() -> int:
+    return int(load().asac_obs_decoder_packed_floats())
+
+
+def obs_decoder_saved_floats(N) -> int:
+    return int(load().asac_obs_decoder_saved_floats(N))
+
+
+def obs_decoder_workspace_floats(N) -> int:
+    return int(load().asac_obs_decoder_workspace_floats(N))
+
+
+@_profiled
+def obs_decoder_forward(state, params, packed, saved, frames):
+    """state [N, S] -> frames [N, 3, 30, 30]; `packed` / `saved`: see include/asac_hip.h"""
+    global _last_work
+    N, S = state.shape
+    _last_work = 2.0 * N * OBS_DECODER_MACS
+    _dense_f32(packed, saved, frames)
+    assert state.is_cuda and state.dtype == torch.float32 and state.stride(1) == 1 and frames.shape == (N, 3, 30, 30)
+    ps = _obs_decoder_params(params, S)
+    _check(load().asac_obs_decoder_forward(_p(state), state.stride(0), N, S, C.byref(ps), _p(packed), _p(saved),
+                                           _p(frames), _stream()), 'asac_obs_decoder_forward')
+
+
+@_profiled
+def obs_decoder_backward(state, packed, saved, frames, grad_frames, grad_state, grad_params, workspace, accumulate=False):
+    """grad_frames [N, 3, 30, 30] -> grad_state [N, S] (or None) and the ten parameter gradients"""
+    global _last_work
+    N, S = state.shape
+    _last_work = 4.0 * N * OBS_DECODER_MACS
+    _dense_f32(packed, saved, frames, grad_frames, grad_state, workspace)
+    assert state.is_cuda and state.dtype == torch.float32 and state.stride(1) == 1
+    gs = _obs_decoder_params(grad_params, S)
+    _check(load().asac_obs_decoder_backward(_p(state), state.stride(0), N, S, _p(packed), _p(saved), _p(frames),
+                                            _p(grad_frames), _p(grad_state), C.byref(gs), int(bool(accumulate)),
+                                            _p(workspace), _stream()), 'asac_obs_decoder_backward')

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 55
+#define ASAC_ABI_VERSION 56
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -787,6 +787,46 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc_host, const float*
 int asac_conv2_backward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w2,
                         const float* z1, const float* z2, const float* grad_y, float* grad_params, int accumulate,
                         float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Observation decoder of the recurrent prediction models (`use_prediction`): `ConvTransposeLayers`
+ * (nn_models/layers/image_layers.py:231-253) with the decoder every reference plugin with an image observation
+ * model builds (envs/roller/nn_visual_hard_attn.py:64-96, envs/roller/nn_visual_hard.py:47-57,
+ * envs/pyramid/nn_visual.py:50-60), called from `_train_rpm` (sac_base.py:1798-1839) through the plugin's
+ * `ModelObservation.get_loss`:
+ *   state [N, S <= 16] -> Linear(S, 64) GELU -> Linear(64, 128) -> [32, 2, 2] -> ConvTranspose2d(32, 32, 4, 2) LeakyReLU
+ *   -> ConvTranspose2d(32, 16, 8, 4) LeakyReLU -> ConvTranspose2d(16, 3, 3, 1) LeakyReLU -> frames [N, 3, 30, 30]
+ * as f32 MFMA products with the states as the N dimension (csrc/decoder.hip).  Parameters in PyTorch's layouts
+ * (Linear [out, in]; ConvTranspose2d [in, out, kh, kw]).
+ *   forward : packs the weights into operand order (`packed`, asac_obs_decoder_packed_floats floats), keeps the
+ *             layers' activations in `saved` (asac_obs_decoder_saved_floats(N) floats) for the backward, writes `frames`
+ *   backward: grad_frames [N, 3, 30, 30] -> grad_state [N, S] (or NULL) and the ten parameter gradients (written, or
+ *             added with accumulate != 0; per-group partial sums added in group order: deterministic);
+ *             `workspace` asac_obs_decoder_workspace_floats(N) floats; `packed` / `saved` / `frames` as the forward left them
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    float* dense1_w;  /* [64, S]  */
+    float* dense1_b;  /* [64]     */
+    float* dense2_w;  /* [128, 64] */
+    float* dense2_b;  /* [128]    */
+    float* ct1_w;     /* [32, 32, 4, 4] */
+    float* ct1_b;     /* [32]     */
+    float* ct2_w;     /* [32, 16, 8, 8] */
+    float* ct2_b;     /* [16]     */
+    float* ct3_w;     /* [16, 3, 3, 3]  */
+    float* ct3_b;     /* [3]      */
+} asac_obs_decoder_params_t;
+
+int64_t asac_obs_decoder_packed_floats(void);
+int64_t asac_obs_decoder_saved_floats(int64_t N);
+int64_t asac_obs_decoder_workspace_floats(int64_t N);
+int asac_obs_decoder_forward(const float* state, int64_t state_stride, int64_t N, int state_size,
+                             const asac_obs_decoder_params_t* params_host, float* packed, float* saved, float* frames,
+                             void* stream);
+int asac_obs_decoder_backward(const float* state, int64_t state_stride, int64_t N, int state_size, const float* packed,
+                              const float* saved, const float* frames, const float* grad_frames, float* grad_state,
+                              const asac_obs_decoder_params_t* grad_params_host, int accumulate, float* workspace,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core for short windows: the scores / mask / softmax / weighted-sum part of
