@@ -64,7 +64,8 @@ constexpr int OFF_PAT_C2 = 59392;     // [tap 64][mt 2][64][4]
 constexpr int OFF_PAT_C1 = 92160;     // [tap 16][mt 2][kt 2][64][4]
 constexpr int OFF_PAT_D2 = 108544;    // [mt 4][p 4][t 2][64][4]
 constexpr int OFF_PAT_D1 = 116736;    // [kt 4][64][4]
-constexpr int kPackedFloats = 117760;
+constexpr int OFF_PA_C3X = 117760;    // [mt 3][64][4]   rows m' = 4 (oc, ky) + kx (kx = 3: zero)
+constexpr int kPackedFloats = 118528;
 
 // ---- per-group partial gradients (floats) ---------------------------------------------------------------------------
 constexpr int POFF_W2 = 0;            // [w 4][dy 2][kx 8][mt 2][64][4]
@@ -150,6 +151,12 @@ __global__ void __launch_bounds__(256) k_dec_pack(const Params P, int S, float* 
         const int j = i - OFF_PAT_C3, s = j >> 6, l = j & 63, q = l >> 4, x = l & 15, m = 4 * s + q;
         if (s < 7 && m < 27) v = P.w3[x * 27 + m];
         packed[i] = v;
+        return;
+    }
+    if (i >= OFF_PA_C3X) {
+        const int j0 = i - OFF_PA_C3X, r = j0 & 3, l = (j0 >> 2) & 63, mt = j0 >> 8, q = l >> 4, x = l & 15;
+        const int mrow = 16 * mt + x, grp = mrow >> 2, kx = mrow & 3;
+        packed[i] = (grp < 9 && kx < 3) ? P.w3[(4 * q + r) * 27 + grp * 3 + kx] : 0.f;
         return;
     }
     int sec_off;
@@ -355,7 +362,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_fwd12(const Fwd12Args a) {
 constexpr int kRingRows = 5, kPitch = 20;
 constexpr int kRowFloats = 3 * 30 * kPitch;              // 1800
 constexpr int kRingFloats = kRingRows * kRowFloats;      // 9000 (36 KB) per wave
-constexpr int kTailLds = (4 * kRingFloats + 4 * 256) * 4;   // rings + one transposition scratch per wave: 148 KB
+constexpr int kTailLds = (4 * kRingFloats + 4 * 4 * 256) * 4;   // rings + four transposition tiles per wave: 156.6 KB
 
 struct Fwd3Args {
     const float* packed;
@@ -370,64 +377,93 @@ __global__ void __launch_bounds__(kThreads) k_dec_fwd3(const Fwd3Args a) {
     const int g = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
     float* ring = lds + w * kRingFloats;
     const f32x4* __restrict__ pk = reinterpret_cast<const f32x4*>(a.packed);
-    const f32x4 pa0 = pk[OFF_PA_C3 / 4 + l], pa1 = pk[OFF_PA_C3 / 4 + 64 + l];
+    // operand rows m' = 4 j + kx, j = (oc, ky): a lane's accumulator registers r = 0..2 ARE the three kx of ITS group
+    // j = 4 mt + q, so the sum over kx (output pixel X takes kx from input pixel X - kx) is a running sum in registers
+    // along the row and only the sum over ky goes through the ring
+    f32x4 pa[3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) pa[mt] = pk[OFF_PA_C3X / 4 + mt * 64 + l];
     // output rows owned by the waves: [0, 9) [9, 16) [16, 23) [23, 30); input rows two above
     const int R0 = w == 0 ? 0 : 2 + 7 * w, R1 = w == 3 ? 30 : 9 + 7 * w;
     const int in0 = max(R0 - 2, 0), in1 = min(R1, 28);
     for (int i = l; i < kRingFloats / 4; i += 64) reinterpret_cast<f32x4*>(ring)[i] = zero4();
-    // where this lane's accumulator rows go: m = 16 mt + 4 q + r -> (oc, ky, kx)
-    int cst[2][4], kyv[2][4];
-    bool valid[2][4];
+    int cst[3], kyv[3];
+    bool valid[3];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mt + 4 * q + r, mm = min(m, 26), oc = mm / 9, tap = mm % 9;
-            valid[mt][r] = m < 27;
-            kyv[mt][r] = tap / 3;
-            cst[mt][r] = (oc * 30 + tap % 3) * kPitch + tpos(x);
-        }
+    for (int mt = 0; mt < 3; ++mt) {
+        const int j = 4 * mt + q, jj = min(j, 8);
+        valid[mt] = j < 9;
+        kyv[mt] = jj % 3;
+        cst[mt] = (jj / 3) * 30 * kPitch + tpos(x);
+    }
     const float b3v[3] = {a.b3[0], a.b3[1], a.b3[2]};
     const f32x4* __restrict__ src = a.act2 + (int64_t)g * kA2Tiles * 64 + l;
     wave_sync();
+    f32x4 vt[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) vt[j] = src[(int64_t)(in0 * 28 + j) * 64];
     for (int y = in0; y < in1; ++y) {
-        if (y != in0) {    // the slot row y + 2 takes over held a row that is done
-            f32x4* z = reinterpret_cast<f32x4*>(ring + ((y + 2) % kRingRows) * kRowFloats);
-            for (int i = l; i < kRowFloats / 4; i += 64) z[i] = zero4();
-            wave_sync();
-        }
-        int base[2][4];
+        int base[3];
         {
             const int rb0 = (y % kRingRows) * kRowFloats, rb1 = ((y + 1) % kRingRows) * kRowFloats,
                       rb2 = ((y + 2) % kRingRows) * kRowFloats;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    base[mt][r] = cst[mt][r] + (kyv[mt][r] == 0 ? rb0 : kyv[mt][r] == 1 ? rb1 : rb2);
+            for (int mt = 0; mt < 3; ++mt) base[mt] = cst[mt] + (kyv[mt] == 0 ? rb0 : kyv[mt] == 1 ? rb1 : rb2);
         }
-        for (int c0 = 0; c0 < 28; c0 += 7) {
-            f32x4 vt[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) vt[j] = src[(int64_t)(y * 28 + c0 + j) * 64];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const f32x4 acc0 = mfma4(pa0, vt[j], zero4()), acc1 = mfma4(pa1, vt[j], zero4());
-                const int xo = (c0 + j) * kPitch;
-                // read - add - write of 27 distinct addresses per lane quarter; pixels follow each other in program order
-                // (the LDS serves a wave's requests in order; the fences keep the compiler from reordering them)
-                float cur[2][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cur[0][r] = ring[base[0][r] + xo];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cur[1][r] = valid[1][r] ? ring[base[1][r] + xo] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ring[base[0][r] + xo] = cur[0][r] + acc0[r];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (valid[1][r]) ring[base[1][r] + xo] = cur[1][r] + acc1[r];
-                wave_sync();
+        // ky = 2 opens an output row (plain store: what the slot held is done), ky = 1 / 0 add to it
+        auto emit = [&](int mt, int X, float v) {
+            if (valid[mt]) {
+                float* dst = ring + base[mt] + X * kPitch;
+                float cur = 0.f;
+                if (kyv[mt] != 2) cur = *dst;
+                *dst = cur + v;
             }
+        };
+        float p1[3] = {0.f, 0.f, 0.f}, p2[3] = {0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < 28; c0 += 7) {
+            f32x4 acc[7][3];
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) acc[j][mt] = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 3; ++mt) acc[j][mt] = ASAC_MF(pa[mt][r], vt[j][r], acc[j][mt]);
+            // the next chunk's tiles travel under this chunk's sums and ring traffic
+            {
+                const int nc = c0 + 7 < 28 ? c0 + 7 : 0, ny = c0 + 7 < 28 ? y : min(y + 1, 27);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) vt[j] = src[(int64_t)(ny * 28 + nc + j) * 64];
+            }
+            float e[7][3];
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) {
+                    e[j][mt] = acc[j][mt][0] + p1[mt];
+                    p1[mt] = acc[j][mt][1] + p2[mt];
+                    p2[mt] = acc[j][mt][2];
+                }
+            // every output pixel of the row is touched once per input row: the chunk's read - add - writes are independent
+            float cur[7][3];
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+                    cur[j][mt] = (valid[mt] && kyv[mt] != 2) ? ring[base[mt] + (c0 + j) * kPitch] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt)
+                    if (valid[mt]) ring[base[mt] + (c0 + j) * kPitch] = cur[j][mt] + e[j][mt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) {
+            emit(mt, 28, p1[mt]);
+            emit(mt, 29, p2[mt]);
         }
         wave_sync();
         // rows that are complete now
@@ -448,6 +484,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_fwd3(const Fwd3Args a) {
                     }
                 }
         }
+        wave_sync();
     }
 }
 
@@ -465,7 +502,7 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd3(const Bwd3Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
     float* ring = lds + w * kRingFloats;
-    float* scratch = lds + 4 * kRingFloats + w * 256;
+    float* scratch = lds + 4 * kRingFloats + w * (4 * 256);      // four tiles turned at a time
     const float* __restrict__ pk = a.packed;
     float pat[7];
 #pragma unroll
@@ -486,35 +523,51 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd3(const Bwd3Args a) {
         cw[nt] = (oc * 30 + tap % 3) * kPitch + 4 * q;
     }
     float b3acc[3] = {0.f, 0.f, 0.f};
-    auto load_row = [&](int yy) {      // d z3 of output row yy -> ring
-        float* row = ring + (yy % kRingRows) * kRowFloats;
-        const bool own = w == 3 || yy < Q1;
-        const int xx = l & 31;
+    // d z3 of one output row: 24 (oc, state pair) items per lane, requested as one batch and put into the ring later
+    const int xx = l & 31, sth = l >> 5;
+    float rg[24], ro[24];
+    auto row_request = [&](int yy) {
 #pragma unroll
         for (int oc = 0; oc < 3; ++oc)
-#pragma unroll 4
+#pragma unroll
             for (int i8 = 0; i8 < 8; ++i8) {
-                const int st = 2 * i8 + (l >> 5);
-                const int64_t state = (int64_t)g * 16 + st;
+                const int64_t state = (int64_t)g * 16 + 2 * i8 + sth;
+                const bool live = xx < 30 && state < a.N;
+                const int64_t idx = live ? (state * 3 + oc) * 900 + yy * 30 + xx : 0;
+                rg[oc * 8 + i8] = live ? a.gout[idx] : 0.f;
+                ro[oc * 8 + i8] = live ? a.out[idx] : 1.f;
+            }
+    };
+    auto row_store = [&](int yy) {
+        float* row = ring + (yy % kRingRows) * kRowFloats;
+        const bool own = w == 3 || yy < Q1;
+#pragma unroll
+        for (int oc = 0; oc < 3; ++oc)
+#pragma unroll
+            for (int i8 = 0; i8 < 8; ++i8) {
                 if (xx < 30) {
-                    float d = 0.f;
-                    if (state < a.N) {
-                        const int64_t idx = (state * 3 + oc) * 900 + yy * 30 + xx;
-                        d = a.gout[idx] * leaky_grad_from_out(a.out[idx]);
-                    }
-                    row[(oc * 30 + xx) * kPitch + tpos(st)] = d;
+                    const float d = rg[oc * 8 + i8] * leaky_grad_from_out(ro[oc * 8 + i8]);
+                    row[(oc * 30 + xx) * kPitch + tpos(2 * i8 + sth)] = d;
                     if (own) b3acc[oc] += d;
                 }
             }
     };
-    load_row(Q0);
-    load_row(Q0 + 1);
+    row_request(Q0);
+    row_store(Q0);
+    row_request(Q0 + 1);
+    row_store(Q0 + 1);
+    row_request(Q0 + 2);
+    row_store(Q0 + 2);
     f32x4 acc3[2] = {zero4(), zero4()};
     const f32x4* __restrict__ src = a.act2 + (int64_t)g * kA2Tiles * 64 + l;
     f32x4* __restrict__ dst = a.dz2 + (int64_t)g * kA2Tiles * 64 + l;
+    f32x4 vt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vt[j] = src[(int64_t)(Q0 * 28 + j) * 64];
+    wave_sync();
     for (int y = Q0; y < Q1; ++y) {
-        load_row(y + 2);
-        wave_sync();
+        const bool more = y + 1 < Q1;          // row y + 3 is needed by the next iteration
+        if (more) row_request(y + 3);
         int bx[7], bw[2];
         {
             const int rb0 = (y % kRingRows) * kRowFloats, rb1 = ((y + 1) % kRingRows) * kRowFloats,
@@ -524,26 +577,59 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd3(const Bwd3Args a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) bw[nt] = cw[nt] + (kw_[nt] == 0 ? rb0 : kw_[nt] == 1 ? rb1 : rb2);
         }
-        for (int c0 = 0; c0 < 28; c0 += 7) {
-            f32x4 vt[7];
+        for (int c0 = 0; c0 < 28; c0 += 4) {
+            f32x4 cur[4];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) vt[j] = src[(int64_t)(y * 28 + c0 + j) * 64];
+            for (int j = 0; j < 4; ++j) cur[j] = vt[j];
+            {   // next chunk's tiles (next row's first at the end of a row)
+                const int nc = c0 + 4 < 28 ? c0 + 4 : 0, ny = c0 + 4 < 28 ? y : min(y + 1, 27);
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int xo = (c0 + j) * kPitch;
-                f32x4 acc = zero4();
+                for (int j = 0; j < 4; ++j) vt[j] = src[(int64_t)(ny * 28 + nc + j) * 64];
+            }
+            // d act2 of four pixels: four independent accumulator chains
+            float bv[7][4];
 #pragma unroll
-                for (int s = 0; s < 7; ++s) acc = ASAC_MF(pat[s], ring[bx[s] + xo], acc);
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[s][j] = ring[bx[s] + (c0 + j) * kPitch];
+            f32x4 acc[4] = {zero4(), zero4(), zero4(), zero4()};
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = ASAC_MF(pat[s], bv[s][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 f32x4 dz;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[r] = acc[r] * leaky_grad_from_out(vt[j][r]);
+                for (int r = 0; r < 4; ++r) dz[r] = acc[j][r] * leaky_grad_from_out(cur[j][r]);
                 dst[(int64_t)(y * 28 + c0 + j) * 64] = dz;
-                const f32x4 u = transpose_tile(scratch, vt[j], q, x);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    acc3[nt] = mfma4(u, *reinterpret_cast<const f32x4*>(ring + bw[nt] + xo), acc3[nt]);
             }
+            // layer-3 weight gradient: the four tiles turned through LDS together
+            const int px = tpos(x);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[j * 256 + (4 * q + r) * 16 + px] = cur[j][r];
+            wave_sync();
+            f32x4 u[4], wv[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4*>(scratch + j * 256 + x * 16 + 4 * q);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    wv[nt][j] = *reinterpret_cast<const f32x4*>(ring + bw[nt] + (c0 + j) * kPitch);
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc3[0] = ASAC_MF(u[j][r], wv[0][j][r], acc3[0]);
+                    acc3[1] = ASAC_MF(u[j][r], wv[1][j][r], acc3[1]);
+                }
         }
+        wave_sync();
+        if (more) row_store(y + 3);
         wave_sync();
     }
     float* part = a.partial + (int64_t)g * kPartialFloats;
@@ -631,23 +717,34 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd2dx(const Bwd2dxArgs a) {
     // ---- d act1 = ConvTranspose2^T d z2: per input pixel, every wave its 16 taps, summed in wave order -------------
     const f32x4* __restrict__ dz2 = a.dz2 + (int64_t)g * kA2Tiles * 64 + l;
     f32x4 b1acc = zero4();
+    f32x4 bt[2][8];      // the 16 tiles under the wave's taps of the NEXT input pixel: requested a pixel ahead
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) bt[dy][kx] = dz2[(int64_t)((w + 4 * dy) * 28 + kx) * 64];
     for (int p = 0; p < 36; ++p) {
-        const int iy = p / 6, ix = p - iy * 6;
+        f32x4 cur[2][8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) cur[dy][kx] = bt[dy][kx];
+        {
+            const int pn = min(p + 1, 35), iy = pn / 6, ix = pn - iy * 6;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx) bt[dy][kx] = dz2[(int64_t)((4 * iy + w + 4 * dy) * 28 + 4 * ix + kx) * 64];
+        }
         f32x4 acc[2] = {zero4(), zero4()};
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            f32x4 bt[8];
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int kx = 0; kx < 8; ++kx) bt[kx] = dz2[(int64_t)((4 * iy + w + 4 * dy) * 28 + 4 * ix + kx) * 64];
-#pragma unroll
-            for (int kx = 0; kx < 8; ++kx) {
+            for (int kx = 0; kx < 8; ++kx)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[0] = ASAC_MF(wt[dy][kx][0][r], bt[kx][r], acc[0]);
-                    acc[1] = ASAC_MF(wt[dy][kx][1][r], bt[kx][r], acc[1]);
+                    acc[0] = ASAC_MF(wt[dy][kx][0][r], cur[dy][kx][r], acc[0]);
+                    acc[1] = ASAC_MF(wt[dy][kx][1][r], cur[dy][kx][r], acc[1]);
                 }
-            }
-        }
         f32x4* red = s_red + (p & 1) * 8 * 64;
         red[(w * 2 + 0) * 64 + l] = acc[0];
         red[(w * 2 + 1) * 64 + l] = acc[1];
@@ -773,12 +870,12 @@ struct Bwd2dwArgs {
     const f32x4* dz2;
     float* partial;
 };
-constexpr int kDwLds = (kA1Tiles * 256 + 4 * 256) * 4;
+constexpr int kDwLds = (kA1Tiles * 256 + 4 * 4 * 256) * 4;
 
 __global__ void __launch_bounds__(kThreads) k_dec_bwd2dw(const Bwd2dwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* s_a1T = lds;                                    // [72][256] TT16
-    float* scratch = lds + kA1Tiles * 256 + (threadIdx.x >> 6) * 256;
+    float* scratch = lds + kA1Tiles * 256 + (threadIdx.x >> 6) * (4 * 256);
     const int g = blockIdx.x, l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
     for (int i = w; i < kA1Tiles; i += 4) {
         const f32x4 v = a.act1[((int64_t)g * kA1Tiles + i) * 64 + l];
@@ -793,34 +890,48 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd2dw(const Bwd2dwArgs a) {
         for (int kx = 0; kx < 8; ++kx) acc[dy][kx][0] = acc[dy][kx][1] = zero4();
     f32x4 bsum = zero4();
     const f32x4* __restrict__ dz2 = a.dz2 + (int64_t)g * kA2Tiles * 64 + l;
-    for (int by = 0; by < 7; ++by) {
-        const int oy = 4 * by + w;
-        for (int bx = 0; bx < 7; ++bx) {
-            f32x4 vt[4];
+    f32x4 vt[4];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) vt[px] = dz2[(int64_t)(oy * 28 + 4 * bx + px) * 64];
+    for (int px = 0; px < 4; ++px) vt[px] = dz2[(int64_t)(w * 28 + px) * 64];
+    const int tp = tpos(x);
+    for (int blk = 0; blk < 49; ++blk) {
+        const int by = blk / 7, bx = blk - by * 7;
+        // the block's four tiles turned through LDS together; the next block's requested meanwhile
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                const f32x4 u = transpose_tile(scratch, vt[px], q, x);
-                bsum += u;
+        for (int px = 0; px < 4; ++px)
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int iy = by - dy;
-                    if (iy < 0 || iy > 5) continue;
+            for (int r = 0; r < 4; ++r) scratch[px * 256 + (4 * q + r) * 16 + tp] = vt[px][r];
+        {
+            const int nb = min(blk + 1, 48), nby = nb / 7, nbx = nb - nby * 7;
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int ix = bx - dx;
-                        if (ix < 0 || ix > 5) continue;
-                        const int p = iy * 6 + ix;
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_a1T + (p * 2 + 0) * 256 + x * 16 + 4 * q);
-                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a1T + (p * 2 + 1) * 256 + x * 16 + 4 * q);
+            for (int px = 0; px < 4; ++px) vt[px] = dz2[(int64_t)((4 * nby + w) * 28 + 4 * nbx + px) * 64];
+        }
+        wave_sync();
+        f32x4 u[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            acc[dy][px + 4 * dx][0] = ASAC_MF(a0[r], u[r], acc[dy][px + 4 * dx][0]);
-                            acc[dy][px + 4 * dx][1] = ASAC_MF(a1[r], u[r], acc[dy][px + 4 * dx][1]);
-                        }
+        for (int px = 0; px < 4; ++px) {
+            u[px] = *reinterpret_cast<const f32x4*>(scratch + px * 256 + x * 16 + 4 * q);
+            bsum += u[px];
+        }
+        wave_sync();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int iy = by - dy;
+            if (iy < 0 || iy > 5) continue;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ix = bx - dx;
+                if (ix < 0 || ix > 5) continue;
+                const int p = iy * 6 + ix;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_a1T + (p * 2 + 0) * 256 + x * 16 + 4 * q);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(s_a1T + (p * 2 + 1) * 256 + x * 16 + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        acc[dy][px + 4 * dx][0] = ASAC_MF(a0[r], u[px][r], acc[dy][px + 4 * dx][0]);
+                        acc[dy][px + 4 * dx][1] = ASAC_MF(a1[r], u[px][r], acc[dy][px + 4 * dx][1]);
                     }
-                }
             }
         }
     }
@@ -843,8 +954,11 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd2dw(const Bwd2dwArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_dec_reduce(const float* __restrict__ partial, int G, int S, const Params dst,
                                                     int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kPartialFloats) return;
+    // 64 entries per workgroup, four threads (group slices g = slice mod 4) per entry: the loads of an entry's 256 partials
+    // in flight four ways, the four slice sums added in slice order
+    __shared__ float s_sum[4][64];
+    const int slice = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     float* out = nullptr;
     int64_t nat = 0;
     int terms = 1, term_stride = 0;     // bias sections hold one partial per wave
@@ -864,19 +978,19 @@ __global__ void __launch_bounds__(256) k_dec_reduce(const float* __restrict__ pa
             out = dst.wd2;
             nat = ((16 * t + c) * 4 + p) * 64 + 16 * nt + x;
         } else if (sec == POFF_WD1) {
-            if (x >= S) return;
+            if (x >= S) out = nullptr; else {
             out = dst.wd1;
-            nat = (16 * tile + c) * S + x;
+            nat = (16 * tile + c) * S + x; }
         } else {
             const int m = 16 * tile + x;
-            if (m >= 27) return;
-            out = dst.w3;
-            nat = c * 27 + m;
+            if (m < 27) {
+                out = dst.w3;
+                nat = c * 27 + m;
+            }
         }
     } else if (i < POFF_B1) {
         const int j = i - POFF_B2;
-        if (j >= 16) return;
-        out = dst.b2, nat = j, terms = 4, term_stride = 16;
+        if (j < 16) out = dst.b2, nat = j, terms = 4, term_stride = 16;
     } else if (i < POFF_BD2) {
         out = dst.b1, nat = i - POFF_B1;
     } else if (i < POFF_BD1) {
@@ -885,26 +999,32 @@ __global__ void __launch_bounds__(256) k_dec_reduce(const float* __restrict__ pa
         out = dst.bd1, nat = i - POFF_BD1;
     } else {
         const int j = i - POFF_B3;
-        if (j >= 3) return;
-        out = dst.b3, nat = j, terms = 4, term_stride = 4;
+        if (j < 3) out = dst.b3, nat = j, terms = 4, term_stride = 4;
     }
-    if (out == nullptr) return;
-    const float* __restrict__ src = partial + i;
     float s = 0.f;
-    for (int g0 = 0; g0 < G; g0 += 8) {
-        float v[8][4];
+    if (out != nullptr) {
+        const float* __restrict__ src = partial + i;
+        for (int g0 = slice; g0 < G; g0 += 32) {
+            float v[8][4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                v[k][t] = (g0 + k < G && t < terms) ? src[(int64_t)(g0 + k) * kPartialFloats + t * term_stride] : 0.f;
+                for (int t = 0; t < 4; ++t)
+                    v[k][t] = (g0 + 4 * k < G && t < terms) ? src[(int64_t)(g0 + 4 * k) * kPartialFloats + t * term_stride] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < 8; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t < terms) s += v[k][t];
+                for (int t = 0; t < 4; ++t)
+                    if (t < terms) s += v[k][t];
+        }
     }
-    out[nat] = accumulate ? out[nat] + s : s;
+    s_sum[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && out != nullptr) {
+        const int e = threadIdx.x & 63;
+        const float total = ((s_sum[0][e] + s_sum[1][e]) + s_sum[2][e]) + s_sum[3][e];
+        out[nat] = accumulate ? out[nat] + total : total;
+    }
 }
 
 static int set_lds(const void* fn, int bytes, bool& done, const char* where) {
@@ -1008,7 +1128,7 @@ int asac_obs_decoder_backward(const float* state, int64_t state_stride, int64_t 
     c.act1 = sv.act1, c.dz2 = dz2, c.partial = partial;
     ASAC_LAUNCH(k_dec_bwd2dw, dim3((unsigned)G), dim3(kThreads), kDwLds, st, c);
     const Params D = as_params(grad_params_host);
-    ASAC_LAUNCH(k_dec_reduce, dim3((kPartialFloats + 255) / 256), dim3(256), 0, st, partial, (int)G, state_size, D,
+    ASAC_LAUNCH(k_dec_reduce, dim3((kPartialFloats + 63) / 64), dim3(256), 0, st, partial, (int)G, state_size, D,
                 accumulate);
     return finish_launch("asac_obs_decoder_backward");
 }
