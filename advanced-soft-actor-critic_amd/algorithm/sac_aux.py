@@ -103,6 +103,14 @@ class AuxHeadsMixin:
             self.model_reward = nn_mod.ModelReward(self.state_size).to(dev)
             self.model_observation = nn_mod.ModelObservation(self.state_size, self.obs_shapes,
                                                              self.use_extra_data).to(dev)
+            # dense stacks inside the (user) prediction models run as fused launches when they fit (fused_mlp.fused_dense
+            # falls back to the module path otherwise)
+            from .nn_models.layers.linear_layers import LinearLayers
+            if self._fuse_prediction_dense:
+                for mod in (self.model_transition, self.model_reward, self.model_observation):
+                    for sub in mod.modules():
+                        if isinstance(sub, LinearLayers):
+                            sub.fuse = True
             named.append(('prediction', list(chain(self.model_transition.parameters(), self.model_reward.parameters(),
                                                    self.model_observation.parameters()))))
         if self.use_rnd:
@@ -174,6 +182,12 @@ class AuxHeadsMixin:
         if all(p.grad is not None for p in params) and params[0].is_cuda:
             from .fused_mlp import _flat_alias
             flat_grad = _flat_alias([p.grad for p in params])
+        if (flat_grad is not None and self._fused_gating and flat_main.numel() == flat_grad.numel()
+                and len(aux) <= 4 and flat_grad.numel() <= (1 << 20)):
+            # the K cosines' signs and the gated additions, loss by loss, as ONE launch (csrc/optim.hip k_cosine_gate_add)
+            from asac_amd import native
+            native.cosine_gate_add(flat_main.view(-1), [torch.cat([g.reshape(-1) for g in gs]) for gs in aux], flat_grad)
+            return
         for gs in aux:
             flat_aux = torch.cat([g.reshape(1, -1) for g in gs], dim=1)
             cos = functional.cosine_similarity(flat_main, flat_aux)

@@ -248,6 +248,8 @@ class SAC_Base(AuxHeadsMixin):
         self._fused_rpm_loss = bool(hip_config.get('fused_rpm_loss', True))
         # one backward walk per prediction model (gates and model gradients from it): sac_aux._train_rpm
         self._rpm_single_backward = bool(hip_config.get('rpm_single_backward', True))
+        self._fused_gating = bool(hip_config.get('fused_gating', True))          # asac_cosine_gate_add
+        self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
         self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
         self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)

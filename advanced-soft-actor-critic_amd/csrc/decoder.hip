@@ -80,8 +80,6 @@ constexpr int POFF_BD1 = 59104;       // [64]
 constexpr int POFF_B3 = 59168;        // [w 4][4]
 constexpr int kPartialFloats = 59184;
 
-// natural parameter sizes
-constexpr int N_W2 = 32 * 16 * 64, N_W1 = 32 * 32 * 16, N_WD2 = 128 * 64, N_W3 = 16 * 3 * 9;
 
 struct Params {            // the ten parameter tensors (or their gradients), natural PyTorch layouts
     float* wd1;   // [64, S]

@@ -283,6 +283,57 @@ inline int stream_grid(int64_t n_vec) {
     return (int)b;
 }
 
+
+// Cosine-sign gating of auxiliary gradients (reference sac_base.py:1619-1631, after the autograd calls):
+//   gate_k = clamp(sign(cos(main, aux_k)), min = 0);  grad += gate_k * aux_k, loss by loss.
+// The cosine's sign is the sign of the dot product (the norms' product is positive, cosine_similarity clamps it at
+// eps from below); a NaN anywhere makes the gate NaN as torch.sign does.  ONE workgroup: the K dots in fixed order
+// (lane-strided partial sums, wave shuffles, waves in order), then the gated additions in the reference's order.
+constexpr int kGateThreads = 1024;
+struct GateArgs {
+    const float* main;
+    const float* aux[ASAC_GATE_MAX_LOSSES];
+    float* grad;
+    float* gates_out;
+    int n, K;
+};
+
+__global__ void __launch_bounds__(kGateThreads) k_cosine_gate_add(const GateArgs a) {
+    __shared__ float s_part[ASAC_GATE_MAX_LOSSES][kGateThreads / 64];
+    __shared__ float s_gate[ASAC_GATE_MAX_LOSSES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float dot[ASAC_GATE_MAX_LOSSES];
+#pragma unroll
+    for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) dot[k] = 0.f;
+    for (int i = tid; i < a.n; i += kGateThreads) {
+        const float m = a.main[i];
+#pragma unroll
+        for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
+            if (k < a.K) dot[k] += m * a.aux[k][i];
+    }
+#pragma unroll
+    for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) {
+        const float t = wave_sum(dot[k]);
+        if (lane == 0) s_part[k][wave] = t;
+    }
+    __syncthreads();
+    if (tid < a.K) {
+        float t = 0.f;
+        for (int w = 0; w < kGateThreads / 64; ++w) t += s_part[tid][w];
+        const float gate = t > 0.f ? 1.f : (t <= 0.f ? 0.f : t);     // (NaN stays NaN)
+        s_gate[tid] = gate;
+        if (a.gates_out) a.gates_out[tid] = gate;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.n; i += kGateThreads) {
+        float g = a.grad[i];
+#pragma unroll
+        for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
+            if (k < a.K) g += s_gate[k] * a.aux[k][i];
+        a.grad[i] = g;
+    }
+}
+
 }  // namespace asac
 
 using namespace asac;
@@ -347,6 +398,20 @@ int asac_normal_nll_kl(const float* loc, int64_t loc_stride_b, int64_t loc_strid
                 reinterpret_cast<unsigned int*>(workspace + 3 * blocks));
     return finish_launch("asac_normal_nll_kl");
 }
+
+int asac_cosine_gate_add(const float* main, const float* const* aux_host, int K, int64_t n, float* grad, float* gates_out,
+                         void* stream) {
+    if (!main || !aux_host || !grad || K <= 0 || K > ASAC_GATE_MAX_LOSSES || n <= 0 || n > ASAC_GATE_MAX_N)
+        return bad_arg("asac_cosine_gate_add");
+    GateArgs a;
+    a.main = main, a.grad = grad, a.gates_out = gates_out, a.n = (int)n, a.K = K;
+    for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) a.aux[k] = k < K ? aux_host[k] : nullptr;
+    for (int k = 0; k < K; ++k)
+        if (!a.aux[k]) return bad_arg("asac_cosine_gate_add");
+    ASAC_LAUNCH(k_cosine_gate_add, dim3(1), dim3(kGateThreads), 0, as_stream(stream), a);
+    return finish_launch("asac_cosine_gate_add");
+}
+
 
 int asac_gelu_eval(const float* z, float* value, float* deriv, int64_t n, void* stream) {
     if (n <= 0 || !z || !value || !deriv) return bad_arg("asac_gelu_eval");

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 56
+ABI_VERSION = 57
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -344,6 +344,8 @@ _SIGNATURES = {
     'asac_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     'asac_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'asac_cosine_gate_add': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     'asac_obs_decoder_packed_floats': (C.c_int64, []),
     'asac_obs_decoder_saved_floats': (C.c_int64, [C.c_int64]),
     'asac_obs_decoder_workspace_floats': (C.c_int64, [C.c_int64]),
@@ -1637,3 +1639,18 @@ def obs_decoder_backward(state, packed, saved, frames, grad_frames, grad_state, 
     _check(load().asac_obs_decoder_backward(_p(state), state.stride(0), N, S, _p(packed), _p(saved), _p(frames),
                                             _p(grad_frames), _p(grad_state), C.byref(gs), int(bool(accumulate)),
                                             _p(workspace), _stream()), 'asac_obs_decoder_backward')
+
+
+GATE_MAX_LOSSES, GATE_MAX_N = 4, 1 << 20
+
+
+@_profiled
+def cosine_gate_add(main, aux_list, grad, gates_out=None):
+    """grad += sum_k clamp(sign(cos(main, aux_k)), min=0) * aux_k, k in order (flat f32 tensors of one length)"""
+    n = main.numel()
+    assert 0 < len(aux_list) <= GATE_MAX_LOSSES and 0 < n <= GATE_MAX_N
+    _dense_f32(main, grad, gates_out, *aux_list)
+    assert grad.numel() == n and all(t.numel() == n for t in aux_list)
+    ptrs = (C.c_void_p * len(aux_list))(*[t.data_ptr() for t in aux_list])
+    _check(load().asac_cosine_gate_add(_p(main), ptrs, len(aux_list), n, _p(grad), _p(gates_out), _stream()),
+           'asac_cosine_gate_add')

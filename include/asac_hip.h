@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 56
+#define ASAC_ABI_VERSION 57
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -787,6 +787,16 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc_host, const float*
 int asac_conv2_backward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w2,
                         const float* z1, const float* z2, const float* grad_y, float* grad_params, int accumulate,
                         float* workspace, void* stream);
+
+/* Cosine-sign gating of auxiliary gradients: `calculate_adaptive_weights` (sac_base.py:1607-1631) after its autograd
+ * calls.  main / aux_k / grad: flat f32[n] (the representation's gradient segment and K <= 4 auxiliary gradients of the
+ * same layout; aux_host = host array of K device pointers):  gate_k = clamp(sign(cos(main, aux_k)), min = 0)  — the sign
+ * of the dot product —, then grad += gate_k * aux_k for k = 0 .. K-1 in that order.  gates_out (f32[K], or NULL) receives
+ * the gates.  One workgroup, fixed summation order (deterministic); n <= ASAC_GATE_MAX_N. */
+#define ASAC_GATE_MAX_LOSSES 4
+#define ASAC_GATE_MAX_N (1 << 20)
+int asac_cosine_gate_add(const float* main, const float* const* aux_host, int K, int64_t n, float* grad, float* gates_out,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Observation decoder of the recurrent prediction models (`use_prediction`): `ConvTransposeLayers`
