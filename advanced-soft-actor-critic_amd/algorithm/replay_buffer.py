@@ -115,6 +115,7 @@ class PrioritizedReplayBuffer:
         self.uniform_source = _DeviceUniform()
         self.min_ratio_reducer = None  # callable(f32[1] tensor) -> in-place MIN over ranks (parallel.py)
         self.sharded = None            # parallel.ShardedParityReplay: sampling / write-backs over all ranks' shards
+        self.lookahead, self.next_valid, self.parity, self._alt = False, False, 0, None
         self._closed = False
 
     # ------------------------------------------------------------------------------------------
@@ -285,6 +286,58 @@ class PrioritizedReplayBuffer:
         self._batch, specs = self._window_specs(self.batch_size, joined=True)
         self._gather_keys = native.make_gather_keys(specs)
         self._gather_refs = specs   # keep tensors alive
+        if self.lookahead:
+            self._build_second_set()
+
+    # ------------------------------------------------------------------------------------------
+    # one batch in flight (the reference's schedule, replay_buffer.py:275, 339-396)
+    # ------------------------------------------------------------------------------------------
+    # The reference's prefetch thread keeps ONE sampled batch queued (`Queue(maxsize=1)`) while the learner trains on the
+    # one before it: batch k + 1 is drawn and gathered before step k's priorities and row write-backs land.  `lookahead`
+    # offers that schedule deterministically: two static batch sets; `sample_next_into_static` draws into the one the
+    # learner is not training on, `swap_sets` exchanges their roles between two steps.
+    _SET_ATTRS = ('_u', '_leaf', '_p', '_ids', '_w', '_min_p', '_batch', '_gather_keys', '_gather_refs',
+                  'joint_pre_action', 'derived')
+
+    def enable_lookahead(self) -> None:
+        assert self.sharded is None and self.min_ratio_reducer is None, 'one batch in flight: single-shard replay only'
+        self.lookahead, self.next_valid, self.parity = True, False, 0
+        self._alt = None
+        if self._gather_keys is not None:
+            self._build_second_set()
+
+    def _build_second_set(self) -> None:
+        first = {a: getattr(self, a) for a in self._SET_ATTRS}
+        with torch.cuda.device(self.device):
+            for a in ('_u', '_leaf', '_p', '_ids', '_w', '_min_p'):
+                setattr(self, a, first[a].clone())
+            self._batch, specs = self._window_specs(self.batch_size, joined=True)   # (sets joint_pre_action / derived)
+            self._gather_keys = native.make_gather_keys(specs)
+            self._gather_refs = specs
+        self._alt = {a: getattr(self, a) for a in self._SET_ATTRS}
+        for a, v in first.items():
+            setattr(self, a, v)
+        self.next_valid = False
+
+    def swap_sets(self) -> None:
+        """the batch drawn last becomes the one `_ids` / `_batch` / ... name (host bookkeeping only)"""
+        for a in self._SET_ATTRS:
+            mine = getattr(self, a)
+            setattr(self, a, self._alt[a])
+            self._alt[a] = mine
+        self.parity ^= 1
+
+    def next_uniforms(self) -> torch.Tensor:
+        return self._alt['_u']
+
+    def sample_next_into_static(self) -> None:
+        """`sample_into_static` into the set the learner is NOT training on (device work only: capturable)"""
+        self.swap_sets()
+        try:
+            self.sample_into_static()
+        finally:
+            self.swap_sets()
+        self.next_valid = True
 
     def _index_ring(self):
         index_ring = self._columns.get('index') if self._pad_action is not None else None

@@ -249,6 +249,10 @@ class SAC_Base(AuxHeadsMixin):
         # one backward walk per prediction model (gates and model gradients from it): sac_aux._train_rpm
         self._rpm_single_backward = bool(hip_config.get('rpm_single_backward', True))
         self._fused_gating = bool(hip_config.get('fused_gating', True))          # asac_cosine_gate_add
+        # one sampled batch in flight, the reference's schedule (replay_buffer.py:275, 339-396): see `_step_sample`
+        self._lookahead = int(hip_config.get('lookahead', 0))
+        assert self._lookahead in (0, 1), 'hip_config lookahead: 0 (synchronous sampling) or 1 (one batch in flight)'
+        self._la_branch = bool(hip_config.get('lookahead_branch', False))   # a graph branch for the draw: measured slower
         self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
         self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
@@ -298,6 +302,7 @@ class SAC_Base(AuxHeadsMixin):
         self.noise = DeviceNoise()
         self._graph = None
         self._graph_runs = {}           # run length -> (the step graph it was captured beside, graph, exec handle)
+        self._la_graphs, self._la_stream, self._la_pending = {}, None, False      # hip_config['lookahead']
         self._graph_failed = False
         self._eager_steps = 0
         # called (eager steps only, never captured) right after the representation / critic update of a step: the
@@ -1694,6 +1699,7 @@ class SAC_Base(AuxHeadsMixin):
         self._step_policy(w)
         post = _AfterPolicy()
         self._vtrace_sidecars = self._pending_alpha = None
+        self._join_lookahead()       # (everything below may write priorities / replay rows)
         if w.stock and self.use_n_step_is:
             with torch.no_grad():
                 if not self._step_after_policy_one_launch(w, post):
@@ -1702,6 +1708,11 @@ class SAC_Base(AuxHeadsMixin):
         self._step_write_backs(w, post)
         if not self._counter_advanced:
             self._opt_steps.add_(1)
+
+    def _join_lookahead(self) -> None:
+        if self._la_pending:
+            torch.cuda.current_stream().wait_stream(self._la_stream)
+            self._la_pending = False
 
     def _step_sample(self):
         """-> the step's window views (`_Window`): [B, L] tensors are `bnx_*`, their first L - 1 rows `bn_*`"""
@@ -1712,12 +1723,28 @@ class SAC_Base(AuxHeadsMixin):
         if self.update_target_per_step == 1 and self._polyak_len > 0:
             polyak = (self._target_params.flat[:self._polyak_len], self._params.flat[:self._polyak_len], self.tau)
         zero = None if self._grads_overwrite else self._params.grad
-        sampled = self._use_sidecars and self.noise.begin_step_with_sample(
-            self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
-        if not sampled:
-            self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
-                                  self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
-        rb.sample_into_static(sampled=sampled)
+        if self._lookahead:
+            # the batch this step trains on was drawn during the previous step (`train` swapped the sets); the NEXT one
+            # is drawn now, from the tree and the rows as the previous step left them, beside this step's launches: a
+            # second stream (a branch of the captured graph) that joins before this step's first write to the replay
+            self.noise.begin_step(self._opt_steps, rb.next_uniforms() if rb.uniform_source is self.noise else None,
+                                  self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+            if self._la_branch:
+                if self._la_stream is None:
+                    self._la_stream = torch.cuda.Stream(device=self.device)
+                self._la_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._la_stream):
+                    rb.sample_next_into_static()
+                self._la_pending = True
+            else:
+                rb.sample_next_into_static()      # same launches, in line (no graph branch)
+        else:
+            sampled = self._use_sidecars and self.noise.begin_step_with_sample(
+                self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+            if not sampled:
+                self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
+                                      self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+            rb.sample_into_static(sampled=sampled)
         batch = rb._batch
         w = _Window()
         w.ids = rb._ids
@@ -2070,6 +2097,20 @@ class SAC_Base(AuxHeadsMixin):
         if rb._gather_keys is None:
             rb._build_batch()
             self._graph = None
+            self._la_graphs = {}
+
+        if self._lookahead:
+            if not rb.lookahead:
+                rb.enable_lookahead()
+            if not rb.next_valid:
+                # the very first batch (the reference's thread has drawn two before the first `sample()` returns)
+                with torch.cuda.device(self.device):
+                    rb.sample_next_into_static()
+            rb.swap_sets()
+            # the captured step holds the sets' addresses: one graph per arrangement, taken in turn
+            self._graph, self._graph_exec, self._graph_exec_checked, self._graph_stats_src = \
+                self._la_graphs.get(rb.parity, (None, None, False, None))
+            rb.next_valid = False
 
         with self._profiler('train', repeat=10):
             if self.update_target_per_step != 1 and step % self.update_target_per_step == 0:
@@ -2083,6 +2124,9 @@ class SAC_Base(AuxHeadsMixin):
             else:
                 self._device_step()
                 self._eager_steps += 1
+        if self._lookahead:
+            self._la_graphs[rb.parity] = (self._graph, self._graph_exec, self._graph_exec_checked, self._graph_stats_src)
+            rb.next_valid = True
 
         # host synchronisation points the reference has too: here the NaN flag of the priority update kernels is
         # read back, so a diverged run raises the reference's 'td_error has nan' (replay_buffer.py:418-420) within
@@ -2107,7 +2151,7 @@ class SAC_Base(AuxHeadsMixin):
         rb = self.replay_buffer
         due = any((step + i) % self.write_summary_per_step == 0 or (step + i) % self.save_model_per_step == 0
                   for i in range(k))
-        if (k <= 1 or due or self._graph is None or self._graph_exec is None or self.update_target_per_step != 1
+        if (k <= 1 or due or self._lookahead or self._graph is None or self._graph_exec is None or self.update_target_per_step != 1
                 or not rb.is_lg_batch_size or rb._gather_keys is None):
             for _ in range(k):
                 step = self.train()

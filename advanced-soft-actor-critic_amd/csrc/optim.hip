@@ -305,11 +305,22 @@ __global__ void __launch_bounds__(kGateThreads) k_cosine_gate_add(const GateArgs
     float dot[ASAC_GATE_MAX_LOSSES];
 #pragma unroll
     for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) dot[k] = 0.f;
-    for (int i = tid; i < a.n; i += kGateThreads) {
-        const float m = a.main[i];
+    // eight elements per lane in flight (the loop is one dependent round trip per iteration otherwise); the partial sums
+    // stay lane-strided in index order
+    for (int i0 = tid; i0 < a.n; i0 += 8 * kGateThreads) {
+        float m[8], v[ASAC_GATE_MAX_LOSSES][8];
 #pragma unroll
-        for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
-            if (k < a.K) dot[k] += m * a.aux[k][i];
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kGateThreads;
+            m[u] = i < a.n ? a.main[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) v[k][u] = (k < a.K && i < a.n) ? a.aux[k][i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
+                if (k < a.K) dot[k] += m[u] * v[k][u];
     }
 #pragma unroll
     for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) {
@@ -325,12 +336,26 @@ __global__ void __launch_bounds__(kGateThreads) k_cosine_gate_add(const GateArgs
         if (a.gates_out) a.gates_out[tid] = gate;
     }
     __syncthreads();
-    for (int i = tid; i < a.n; i += kGateThreads) {
-        float g = a.grad[i];
+    float gate[ASAC_GATE_MAX_LOSSES];
 #pragma unroll
-        for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
-            if (k < a.K) g += s_gate[k] * a.aux[k][i];
-        a.grad[i] = g;
+    for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) gate[k] = k < a.K ? s_gate[k] : 0.f;
+    for (int i0 = tid; i0 < a.n; i0 += 8 * kGateThreads) {
+        float g[8], v[ASAC_GATE_MAX_LOSSES][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kGateThreads;
+            g[u] = i < a.n ? a.grad[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k) v[k][u] = (k < a.K && i < a.n) ? a.aux[k][i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kGateThreads;
+#pragma unroll
+            for (int k = 0; k < ASAC_GATE_MAX_LOSSES; ++k)
+                if (k < a.K) g[u] += gate[k] * v[k][u];
+            if (i < a.n) a.grad[i] = g[u];
+        }
     }
 }
 

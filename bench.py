@@ -116,10 +116,13 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_adam_step_partials': 'asac::k_adam_partials', 'asac_adam_step': 'asac::k_adam',
               'asac_step_prologue': 'asac::k_noise_fill', 'asac_policy_sample_q_forward': 'asac::k_pi_sample_q',
               'asac_policy_step_fused': 'asac::k_policy_step', 'asac_rows_move': 'asac::k_rows_move',
-              'asac_td_update': 'asac::k_td_update'}
+              'asac_td_update': 'asac::k_td_update',
+              'asac_obs_decoder_forward': 'asac::dec::k_dec_fwd12+asac::dec::k_dec_fwd3',
+              'asac_obs_decoder_backward': 'asac::dec::k_dec_bwd3+asac::dec::k_dec_bwd2dx+asac::dec::k_dec_bwd2dw+asac::dec::k_dec_reduce',
+              'asac_cosine_gate_add': 'asac::k_cosine_gate_add'}
 SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
-ROUND = 'r03'
+ROUND = 'r04'
 
 
 def pmc_traffic(config: str, kernel: str):
@@ -139,6 +142,23 @@ def pmc_traffic(config: str, kernel: str):
         tot = sum((r['fetch_bytes_corrected'] + (r.get('write_bytes_raw') or 0.0)) * r.get('launches', 1) for r in recs)
         return round(tot / calls), f'profiles/{path.name}'
     return None, None
+
+
+def in_situ(config: str, kernel: str):
+    """(mean launch duration in us, launches per step, source) of a kernel INSIDE the replayed hipGraph step, from the
+    committed rocprofv3 --kernel-trace --stats summary of `bench.py --config <config>` (profiles/<round>_<config>_
+    kernel_stats.json, tools/summarize_rocprof.py); `a+b`: a launch group, durations added.  (None, None, None) without it."""
+    path = Path(__file__).resolve().parent / 'profiles' / f'{ROUND}_{config}_kernel_stats.json'
+    if not path.exists():
+        return None, None, None
+    d = json.loads(path.read_text())
+    us, per_step = 0.0, None
+    for k in kernel.split('+'):
+        if k not in d:
+            return None, None, None
+        us += d[k]['avg_us']
+        per_step = d[k]['launches_per_step'] if per_step is None else per_step
+    return us, per_step, f'profiles/{path.name}'
 
 
 def _gru_bytes(B, L):
@@ -227,7 +247,7 @@ def fill_buffer(agent, rng, n_transitions):
     torch.cuda.synchronize()
 
 
-def cpu_baseline(budget_s=24.0):
+def cpu_baseline(budget_s=24.0, fill=None):
     """The oracle port on this host: same workload, bounded sample.  The step is ~40 tiny eager ops
     on [256, <=64] tensors, so more intra-op threads only add synchronisation cost: a short sweep
     picks the best thread count and that one is reported (`cores` = threads actually used)."""
@@ -244,11 +264,11 @@ def cpu_baseline(budget_s=24.0):
                            seq_encoder=CFG['seq_encoder'], curiosity=CFG.get('curiosity'),
                            use_priority=CFG.get('use_priority', True), use_prediction=CFG.get('use_prediction', False),
                            replay_config={'capacity': CFG['capacity']})
-    fill = 2 ** 15   # bounded: the tree depth (19 levels) is what the sampler pays for, not the fill
+    fill = CFG['fill'] if fill is None else fill      # the rows the GPU run holds resident
     for _ in range(fill // CFG['episode_len']):
         agent.put_episode(**synthetic_episode(rng, CFG['episode_len']))
     default_threads = torch.get_num_threads()
-    candidates = sorted({1, 4, 8, 16, min(32, default_threads)})
+    candidates = sorted({1, 4, 8, 16, min(32, default_threads)}) if budget_s >= 20 else [1, 8]
     best, sweep = None, {}
     for th in candidates:
         torch.set_num_threads(th)
@@ -281,20 +301,28 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg3', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess
     out = {}
     for name in names:
-        cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name, '--steps', str(steps), '--warmup',
-               str(warmup), '--no-cpu-baseline', '--profile-steps', '0', '--no-extras']
+        env = dict(os.environ)
+        if name.endswith('_lookahead'):       # the headline workload with one sampled batch in flight (hip_config['lookahead'])
+            cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name[:-len('_lookahead')], '--steps', '2000',
+                   '--warmup', '100', '--no-cpu-baseline', '--profile-steps', '0', '--no-extras', '--run-length', '0']
+            env['ASAC_BENCH_HIP_CONFIG'] = json.dumps({**json.loads(env.get('ASAC_BENCH_HIP_CONFIG', '{}')), 'lookahead': 1})
+        else:
+            cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name, '--steps', str(steps), '--warmup',
+                   str(warmup), '--cpu-budget', '8', '--profile-steps', '12', '--no-extras', '--run-length', '0']
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
             d = json.loads(line)
             out[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
-                         'warmup': d['warmup'], 'workload': d['config']['workload'], 'hipgraph': d['config']['hipgraph']}
+                         'warmup': d['warmup'], 'workload': d['config']['workload'], 'hipgraph': d['config']['hipgraph'],
+                         'roofline': d.get('roofline'), 'roofline_hbm': d.get('roofline_hbm'),
+                         'cpu_baseline': d.get('cpu_baseline')}
         except Exception as e:   # a failed side run must not lose the main line
             out[name] = {'error': repr(e)[:200]}
     return out
@@ -309,6 +337,7 @@ def main():
                     help='strong (default): global batch 256, 256/N rows per GPU (SURVEY 8d, the BASELINE metric); '
                          'weak: batch 256 per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=24.0, help='seconds of host time for the CPU port leg')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--run-length', type=int, default=4,
                     help='the secondary figure `value_runs_of_<k>`: the same steps issued as SAC_Base.train_steps(k) '
@@ -475,6 +504,15 @@ def main():
                         'alg_bytes_per_launch': round(d['bytes_per_step'] / d['launches_per_step']), **common}
         if roofline is not None:
             roofline['traffic'], roofline['traffic_source'] = pmc_traffic(args.config, dom)
+            # the same kernel's duration INSIDE the replayed step (committed rocprofv3 summary of this command): what the
+            # profile readers recompute `frac` from
+            us_situ, per_step, src = in_situ(args.config, dom)
+            if us_situ is not None:
+                work = roofline.get('alg_flops_per_launch') or roofline.get('alg_bytes_per_launch')
+                scale = 1e12 if roofline['bound'] == 'mfma' else 1e9
+                ach_situ = work / (us_situ * 1e-6) / scale
+                roofline.update({'avg_launch_us_in_situ': round(us_situ, 3), 'achieved_in_situ': round(ach_situ, 4),
+                                 'frac_in_situ': round(ach_situ / roofline['peak'], 6), 'in_situ_source': src})
 
         # the north-star's "sample + return kernels" (K1-K4) as ONE group at this batch size
         members = [n_ for n_ in SAMPLE_RETURN if n_ in kernels]
@@ -490,12 +528,18 @@ def main():
                 traffic += tr * kernels[m]['launches_per_step']
                 srcs.add(src)
             ach = by_step / (us_step * 1e-6) / 1e9
+            situ = [in_situ(args.config, _KERNEL_OF[m]) for m in members]
+            us_situ = None if any(x[0] is None for x in situ) else sum(x[0] * kernels[m]['launches_per_step'] for x, m in zip(situ, members))
             roofline_hbm = {'kernels': [_KERNEL_OF[m] for m in members], 'bound': 'hbm', 'achieved': round(ach, 3),
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 6),
                             'alg_bytes_per_step': int(by_step), 'us_per_step': round(us_step, 2),
                             'traffic': None if traffic is None else int(traffic),
                             'traffic_over_algorithmic': None if traffic is None else round(traffic / by_step, 2),
                             'traffic_source': sorted(srcs) if traffic is not None else None,
+                            'us_per_step_in_situ': None if us_situ is None else round(us_situ, 2),
+                            'achieved_in_situ': None if us_situ is None else round(by_step / (us_situ * 1e-6) / 1e9, 3),
+                            'frac_in_situ': None if us_situ is None else round(by_step / (us_situ * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
+                            'in_situ_source': None if us_situ is None else situ[0][2],
                             'note': 'K1+K2 sample / IS weights (with the step prologue fused into the same launch: Polyak '
                                     'and the draws are counted in its bytes), K3 window gather, K4 return + ensemble min '
                                     '(the launches that exist as such: where the return target is formed inside the Q-loss '
@@ -513,7 +557,7 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(args.cpu_budget, args.fill)
 
     if rank == 0:
         value = (world if args.scaling == 'weak' else 1) * args.steps / dt
@@ -522,6 +566,7 @@ def main():
             'value': round(value, 2), 'unit': 'train_steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 4),
             f'value_runs_of_{spl}': None if dt_runs is None else round((world if args.scaling == 'weak' else 1) * args.steps / dt_runs, 2),
+            'value_lookahead': (configs or {}).get('cfg2_lookahead', {}).get('value') if args.config == 'cfg2' else None,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': f'{CFG["desc"]}, batch {CFG["batch_size"]} per GPU, {args.fill} transitions resident',

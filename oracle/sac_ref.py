@@ -150,7 +150,8 @@ class SacRef:
                  d_policy_entropy_penalty=0.5, learning_rate=3e-4, gamma=0.99, v_lambda=1.,
                  v_rho=1., v_c=1., clip_epsilon=0.2, use_n_step_is=True, use_priority=True,
                  curiosity=None, curiosity_strength=1., use_prediction=False, transition_kl=0.8, use_extra_data=True,
-                 replay_config=None, noise=None):
+                 replay_config=None, noise=None, lookahead=False):
+        self.lookahead, self._queued = bool(lookahead), None
         self.obs_names, self.obs_shapes = list(obs_names), list(obs_shapes)
         self.d_action_sizes, self.c_action_size = list(d_action_sizes), c_action_size
         self.d_sum, self.d_branches = sum(d_action_sizes), len(d_action_sizes)
@@ -556,7 +557,16 @@ class SacRef:
         rb, b, n = self.replay_buffer, self.b, self.n
         if not rb.is_lg_batch_size:
             return None
-        ids, windows, is_w = rb.sample(self.noise.uniforms(self.batch_size))
+        if self.lookahead:
+            # one batch in flight: the reference's `Queue(maxsize=1)` + prefetch thread (replay_buffer.py:275, 339-396)
+            # hold batch k + 1 — drawn and gathered BEFORE step k's priority update and row write-backs — while the
+            # learner trains on batch k; before the first step two batches are drawn from the initial tree
+            if self._queued is None:
+                self._queued = rb.sample(self.noise.uniforms(self.batch_size))
+            drawn = rb.sample(self.noise.uniforms(self.batch_size))
+            (ids, windows, is_w), self._queued = self._queued, drawn
+        else:
+            ids, windows, is_w = rb.sample(self.noise.uniforms(self.batch_size))
         batch = {k: torch.as_tensor(v) for k, v in windows.items()}
         priority_is = torch.as_tensor(is_w)
         pad_window(batch, b, self.padding_action)

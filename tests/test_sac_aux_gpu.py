@@ -209,3 +209,31 @@ def test_adaptive_gating_with_fused_layers():
     seen = prof.summary()
     assert seen['asac_conv2_backward']['calls'] == 3 and seen['asac_linear_tanh_backward2']['calls'] == 3
     agent.close()
+
+
+@pytest.mark.parametrize('n,K', [(25_000, 3), (1000, 1), (70_001, 4)])
+def test_cosine_gate_add_matches_torch(n, K):
+    """`asac_cosine_gate_add` against the reference's arithmetic (sac_base.py:1619-1631): cosine similarity of the flat
+    main gradient with each auxiliary one, sign().clamp(min=0) gates, `grad += gate * aux` loss by loss."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    gen = torch.Generator().manual_seed(n)
+    main = torch.randn(n, generator=gen)
+    aux = [torch.randn(n, generator=gen) for _ in range(K)]
+    aux[0] = 0.3 * main + 0.1 * aux[0]          # clearly aligned: gate 1
+    if K > 1:
+        aux[1] = -0.5 * main + 0.1 * aux[1]     # clearly opposed: gate 0
+    if K > 3:
+        aux[3] = torch.zeros(n)                 # zero gradient: cos 0, gate 0
+    grad = torch.randn(n, generator=gen)
+    want = grad.clone()
+    gates = []
+    for a in aux:
+        cos = torch.nn.functional.cosine_similarity(main.reshape(1, -1), a.reshape(1, -1))
+        gate = torch.sign(cos).clamp(min=0)
+        gates.append(float(gate))
+        want += gate * a
+    d_grad, d_gates = grad.cuda(), torch.empty(K, device='cuda')
+    native.cosine_gate_add(main.cuda(), [a.cuda() for a in aux], d_grad, d_gates)
+    assert d_gates.cpu().tolist() == gates
+    assert torch.equal(d_grad.cpu(), want)      # same products and additions, entry by entry

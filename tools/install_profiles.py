@@ -5,14 +5,15 @@ import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r03'
+R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r04'
 
 for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
     shutil.copy(R / f'{c}_bench.json', P / f'{TAG}_{c}_bench.json')
 for name in ('cfg2_kernel_stats.csv', 'cfg2_kernel_stats_summary.txt', 'kernel_sweep.txt', 'cfg2_step_sequence.txt',
              'cfg3_step_sequence.txt', 'cfg4_step_sequence.txt', 'cfg5_step_sequence.txt', 'cfg3_kernel_stats_summary.txt',
              'cfg4_kernel_stats_summary.txt', 'cfg5_kernel_stats_summary.txt', 'cfg5_without_prediction_step_sequence.txt',
-             'cfg5_without_prediction_kernel_stats_summary.txt'):
+             'cfg5_without_prediction_kernel_stats_summary.txt', 'cfg2_kernel_stats.json', 'cfg3_kernel_stats.json',
+             'cfg4_kernel_stats.json', 'cfg5_kernel_stats.json', 'cfg5_without_prediction_kernel_stats.json'):
     if (R / name).exists():
         shutil.copy(R / name, P / f'{TAG}_{name}')
 for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',

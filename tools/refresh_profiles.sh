@@ -8,17 +8,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
 mkdir -p $O
 cd $R
-timeout 900 python bench.py > $O/cfg2_bench.json 2> $O/cfg2_bench.err
-timeout 900 python bench.py --no-extras --config cfg3 > $O/cfg3_bench.json 2> $O/cfg3_bench.err
-timeout 900 python bench.py --no-extras --config cfg4 > $O/cfg4_bench.json 2> $O/cfg4_bench.err
-timeout 900 python bench.py --no-extras --config cfg5 --steps 500 > $O/cfg5_bench.json 2> $O/cfg5_bench.err
 timeout 600 python tools/kernel_sweep.py > $O/kernel_sweep.txt 2> $O/kernel_sweep.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmc_r /tmp/pmc_w /tmp/spmc_r /tmp/spmc_w
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-extras --no-cpu-baseline --profile-steps 0 --run-length 0 > /tmp/prof.log 2>&1
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 cp $f $O/cfg2_kernel_stats.csv
-python $R/tools/summarize_rocprof.py $f 2100 45 > $O/cfg2_kernel_stats_summary.txt
+python $R/tools/summarize_rocprof.py $f 2100 45 $O/cfg2_kernel_stats.json > $O/cfg2_kernel_stats_summary.txt
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/r.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -- python $R/bench.py --no-extras --no-cpu-baseline --steps 100 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/w.log 2>&1
 python $R/tools/summarize_pmc.py $(find /tmp/pmc_r -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w -name "*counter_collection.csv" | head -1) $O/cfg2_pmc_traffic.json > $O/cfg2_pmc_traffic_all.txt
@@ -29,9 +25,9 @@ f=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python $R/tools/step_sequence.py $f > $O/cfg2_step_sequence.txt
 for c in cfg3 cfg4 cfg5 cfg5_without_prediction; do
   rm -rf /tmp/prof_$c
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --profile-steps 0 --steps 200 --warmup 20 --fill 20000 --run-length 0 > /tmp/prof_$c.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --profile-steps 0 --steps 200 --warmup 20 --run-length 0 > /tmp/prof_$c.log 2>&1
   python $R/tools/step_sequence.py $(find /tmp/prof_$c -name "*kernel_trace.csv" | head -1) > $O/${c}_step_sequence.txt
-  python $R/tools/summarize_rocprof.py $(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1) 220 30 > $O/${c}_kernel_stats_summary.txt
+  python $R/tools/summarize_rocprof.py $(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1) 220 40 $O/${c}_kernel_stats.json > $O/${c}_kernel_stats_summary.txt
 done
 # HBM traffic of the representation kernels (cfg3 GRU, cfg4 / cfg5 convolution stack and attention): two PMC passes each
 for c in cfg3 cfg4 cfg5; do
@@ -40,5 +36,12 @@ for c in cfg3 cfg4 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline --steps 60 --warmup 10 --fill 20000 --profile-steps 0 --run-length 0 > /tmp/w_$c.log 2>&1
   python $R/tools/summarize_pmc.py $(find /tmp/pmc_r_$c -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w_$c -name "*counter_collection.csv" | head -1) $O/${c}_pmc_traffic.json > $O/${c}_pmc_traffic_all.txt
 done
+# the bench lines last: their `*_in_situ` fields read the kernel-trace summaries just made (profiles/r04_*_kernel_stats.json)
+for c in cfg2 cfg3 cfg4 cfg5 cfg5_without_prediction; do cp $O/${c}_kernel_stats.json $R/profiles/r04_${c}_kernel_stats.json; done
+cd $R
+timeout 1200 python bench.py > $O/cfg2_bench.json 2> $O/cfg2_bench.err
+timeout 900 python bench.py --no-extras --config cfg3 --cpu-budget 10 > $O/cfg3_bench.json 2> $O/cfg3_bench.err
+timeout 900 python bench.py --no-extras --config cfg4 --cpu-budget 10 > $O/cfg4_bench.json 2> $O/cfg4_bench.err
+timeout 900 python bench.py --no-extras --config cfg5 --steps 500 --cpu-budget 10 > $O/cfg5_bench.json 2> $O/cfg5_bench.err
 ls -la $O
 tail -c 300 $O/cfg2_bench.json

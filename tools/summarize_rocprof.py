@@ -1,6 +1,9 @@
 """Compact a rocprofv3 `*_kernel_stats.csv` into a short table (kernel names are truncated and
-torch's template noise is stripped).  usage: summarize_rocprof.py stats.csv [steps] [top]"""
+torch's template noise is stripped).  usage: summarize_rocprof.py stats.csv [steps] [top] [out.json]
+The optional JSON holds, per library kernel (template arguments dropped, instances merged), the launch-weighted mean
+duration and the launches per step: what bench.py's `*_in_situ` roofline fields are computed from."""
 import csv
+import json
 import re
 import sys
 
@@ -31,6 +34,17 @@ def main():
         print(f'{short(r["Name"]):72s} {int(r["Calls"]):7d} {int(r["Calls"]) / steps:6.2f} '
               f'{float(r["AverageNs"]) / 1e3:8.2f} {float(r["MinNs"]) / 1e3:7.2f} {float(r["Percentage"]):6.2f}')
     asac = [r for r in rows if 'asac::' in r['Name']]
+    if len(sys.argv) > 4:
+        merged = {}
+        for r in asac:
+            k = re.match(r'(void )?(asac::[A-Za-z_0-9:]+)', r['Name']).group(2)
+            m = merged.setdefault(k, [0, 0.0])
+            m[0] += int(r['Calls'])
+            m[1] += float(r['TotalDurationNs'])
+        out = {k: {'avg_us': round(t / c / 1e3, 3), 'launches_per_step': round(c / steps, 3)} for k, (c, t) in merged.items()}
+        out['_all'] = {'us_per_step': round(tot / 1e3 / steps, 1), 'launches_per_step': round(calls / steps, 1),
+                       'asac_share': round(sum(float(r['TotalDurationNs']) for r in asac) / tot, 4), 'steps': steps}
+        json.dump(out, open(sys.argv[4], 'w'), indent=1, sort_keys=True)
     print(f'# asac kernels: {sum(float(r["TotalDurationNs"]) for r in asac) / tot * 100:.1f}% of device time, '
           f'{sum(int(r["Calls"]) for r in asac) / steps:.1f} launches/step')
 
