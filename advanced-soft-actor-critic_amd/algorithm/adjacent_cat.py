@@ -99,9 +99,9 @@ for _name in ('__add__', '__radd__', '__sub__', '__rsub__', '__mul__', '__rmul__
 DeferredCat.__hash__ = object.__hash__
 
 
-def deferrable(tensors, dim, max_width) -> bool:
+def deferrable(tensors, dim, max_width, require_cuda=True) -> bool:
     """two float32 device tensors with the same leading shape, concatenated along the last dim, narrow enough for the
-    fused head"""
+    fused head (`require_cuda=False`: the transparency tests run the same logic on host tensors)"""
     if not isinstance(tensors, (list, tuple)) or len(tensors) != 2:
         return False
     a, b = tensors
@@ -109,7 +109,8 @@ def deferrable(tensors, dim, max_width) -> bool:
         return False
     if dim < 0:
         dim += a.dim()
-    return (dim == a.dim() - 1 and a.shape[:-1] == b.shape[:-1] and a.is_cuda and b.is_cuda and a.device == b.device
+    return (dim == a.dim() - 1 and a.shape[:-1] == b.shape[:-1] and (a.is_cuda and b.is_cuda or not require_cuda)
+            and a.device == b.device
             and a.dtype == torch.float32 and b.dtype == torch.float32 and 0 < a.shape[-1] and 0 < b.shape[-1]
             and a.shape[-1] + b.shape[-1] <= max_width)
 
@@ -119,9 +120,9 @@ class AdjacentCat(TorchFunctionMode):
     `DeferredCat`; `widths` (a set) restricts that to the total widths some consumer is known to take in two blocks
     (the input widths of the representation's fused Linear + Tanh heads)"""
 
-    def __init__(self, defer_width: int = 0, widths=None):
+    def __init__(self, defer_width: int = 0, widths=None, require_cuda: bool = True):
         super().__init__()
-        self.defer_width, self.widths = defer_width, widths
+        self.defer_width, self.widths, self.require_cuda = defer_width, widths, require_cuda
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -131,7 +132,7 @@ class AdjacentCat(TorchFunctionMode):
                 view = joined_view(args[0], dim)
                 if view is not None:
                     return view
-                if (self.defer_width and deferrable(args[0], dim, self.defer_width)
+                if (self.defer_width and deferrable(args[0], dim, self.defer_width, self.require_cuda)
                         and (self.widths is None or args[0][0].shape[-1] + args[0][1].shape[-1] in self.widths)):
                     return DeferredCat(args[0])
         return func(*args, **kwargs)

@@ -72,6 +72,13 @@ def _masked_mse_backward(pred, target, padding_mask, loss_out, fused=True):
         pred.backward(d)
 
 
+def _real(x):
+    """a concatenation that left the representation un-consumed (a plugin whose returned state IS a `torch.cat`) is
+    formed here: nothing outside the representation ever sees an `adjacent_cat.DeferredCat`"""
+    from .adjacent_cat import DeferredCat
+    return x.materialize() if isinstance(x, DeferredCat) else x
+
+
 class _Window:
     """views of the step's static batch tensors and what the phases of `_device_step_body` hand to each other"""
 
@@ -305,10 +312,6 @@ class SAC_Base(AuxHeadsMixin):
         self._la_graphs, self._la_stream, self._la_pending = {}, None, False      # hip_config['lookahead']
         self._graph_failed = False
         self._eager_steps = 0
-        # called (eager steps only, never captured) right after the representation / critic update of a step: the
-        # parity tests read the freshly updated weights there, or align them with the reference's so that what
-        # the step computes afterwards is compared from identical weights
-        self.after_rep_q_update = None
 
         self._build_model(nn, nn_config, init_log_alpha, learning_rate)
         self._build_ckpt()
@@ -861,8 +864,9 @@ class SAC_Base(AuxHeadsMixin):
             st, attn, _ = rep(l_indexes.shape[1], l_indexes, l_obses_list, l_pre_actions,
                               l_pre_seq_hidden_states[:, :1], is_prev_hidden_state=True,
                               padding_mask=l_padding_masks)
-            return st, attn
-        return rep(l_obses_list, l_pre_actions, l_pre_seq_hidden_states, padding_mask=l_padding_masks)
+            return _real(st), _real(attn)
+        out = rep(l_obses_list, l_pre_actions, l_pre_seq_hidden_states, padding_mask=l_padding_masks)
+        return tuple(_real(o) for o in out) if isinstance(out, tuple) else _real(out)
 
     # ------------------------------------------------------------------------------------------
     # network evaluation: fused stock path or the user modules
@@ -1823,8 +1827,6 @@ class SAC_Base(AuxHeadsMixin):
                           w.bn_rewards[:, b:], w.bn_dones[:, b:], w.bn_mu_probs[:, b:], w.priority_is, aux,
                           policy_sample=w.stock and not w.rep_trainable,
                           state_base=state_base)
-        if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
-            self.after_rep_q_update()
         if w.rep_trainable:   # states under the updated representation (reference 2097-2103)
             with torch.no_grad(), cat_mode():
                 w.bnx_states, w.next_hidden = self.get_l_states(*w.rep_in, is_target=False)

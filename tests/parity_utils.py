@@ -329,3 +329,23 @@ def _dump_parity_log():
 import atexit  # noqa: E402
 
 atexit.register(_dump_parity_log)
+
+
+def hooked_learner():
+    """-> a TEST-SIDE subclass of the product's `SAC_Base` with an `after_rep_q_update` hook: called (eager steps only)
+    right after the representation / critic update of a step returns — the step-parity tests read the freshly updated
+    weights there, or align them with the reference's so that what the step computes afterwards is compared from identical
+    weights.  The product class carries no such hook."""
+    import torch
+    from algorithm.sac_base import SAC_Base
+
+    class HookedSAC(SAC_Base):
+        after_rep_q_update = None
+
+        def _train_rep_q(self, *args, **kwargs):
+            out = super()._train_rep_q(*args, **kwargs)
+            if self.after_rep_q_update is not None and not torch.cuda.is_current_stream_capturing():
+                self.after_rep_q_update()
+            return out
+
+    return HookedSAC

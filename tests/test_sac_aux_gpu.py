@@ -34,7 +34,7 @@ NO_ALIGN = ()
 def test_optional_heads_vs_reference_golden(golden_dir, case):
     import asac_amd  # noqa: F401
     from algorithm.fused import RecordedNoise
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     from algorithm.utils.enums import convert_config_to_enum
     g = np.load(golden_dir / f'f6_step_{case}.npz')
     kw, d_sizes, c_size = CASES[case]
@@ -101,7 +101,7 @@ def test_rpm_vs_reference_golden(golden_dir, tag, fused_loss):
     differentiates again), so the function is pinned in isolation, the way f4 pins `_get_y`.  Variants: main gradient g
     (gates 1, 0, 1), -g (gates 0, 1, 0), other transition_kl without extra data (gates 0, 0, 1)."""
     import asac_amd  # noqa: F401
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     g = np.load(golden_dir / 'f11_rpm.npz')
     B, n, kl, extra = g[f'{tag}/cfg']
     torch.manual_seed(0)
@@ -161,7 +161,7 @@ def test_prediction_heads_inside_the_captured_step():
     prediction models train, nothing diverges.  Step-level parity with `use_prediction` is against the oracle, which
     restates the product's graph-retaining order: tests/test_full_size_gpu.py (cfg5)."""
     import asac_amd  # noqa: F401
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
     agent = SAC_Base(['vector'], [(6,)], [], 2, None, nn_vec_full, device='cuda:0', batch_size=16, n_step=3,
@@ -185,7 +185,7 @@ def test_adaptive_gating_with_fused_layers():
     import asac_amd  # noqa: F401
     from asac_amd import native
     from algorithm.fused_mlp import direct_param_grads
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     from tests.plugins import nn_conv
     torch.manual_seed(0)
     agent = SAC_Base(['vector', 'image'], [(10,), (3, 30, 30)], [], 4, None, nn_conv, device='cuda:0', batch_size=16,

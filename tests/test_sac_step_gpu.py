@@ -16,7 +16,7 @@ LR = 3e-4
 
 def make_agent(case, use_graph=False, hip=None):
     import asac_amd  # noqa: F401
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     from algorithm.utils.enums import convert_config_to_enum
     plugin_name, kw, d_sizes, io = pu.STEP_CASES[case]
     kw = dict(kw)
@@ -345,7 +345,7 @@ def test_data_parallel_path_single_rank_nccl():
     import torch.distributed as dist
     import asac_amd  # noqa: F401
     from algorithm.parallel import DataParallelContext
-    from algorithm.sac_base import SAC_Base
+    SAC_Base = pu.hooked_learner()
     with socket.socket() as s_:
         s_.bind(('127.0.0.1', 0))
         port = s_.getsockname()[1]

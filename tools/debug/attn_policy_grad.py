@@ -8,7 +8,8 @@ sys.path.insert(0, str(ROOT))
 import asac_amd  # noqa
 from tests import parity_utils as pu
 from algorithm.fused import RecordedNoise
-from algorithm.sac_base import SAC_Base
+from tests import parity_utils as _pu_h
+SAC_Base = _pu_h.hooked_learner()
 from algorithm.utils.enums import convert_config_to_enum
 
 case = sys.argv[1] if len(sys.argv) > 1 else 'attn'
