@@ -1,0 +1,115 @@
+"""GRU stacks of hidden size 32 / 64 / 128 with the time loops on MFMA (`asac_gru_wide_forward / _backward`).
+
+The plugin layer `nn_models.layers.GRU` (reference `seq_layers.py:14-114`) routes here on the device for the hidden sizes the
+reference's environments use (`m.GRU(…, 64, 1)` envs/square/memory_corridor/nn.py:19, `m.GRU(…, 128, 1)`
+envs/uav/uav_hole/nn.py:22) — `csrc/gru.hip` stops at 16.  Per layer and pass: ONE library GEMM for the input projections of
+all steps, ONE launch for the recurrence (MIOpen: one launch per step); backward: one launch for the recurrence through time,
+three library GEMMs (dW_ih, dW_hh, dx) and two column sums.  Same values as the cell loop of the module path (the padding rule
+of the layer included: steps before a row's first unpadded one are skipped, padded outputs are zero).
+"""
+import torch
+
+from asac_amd import native
+
+__all__ = ['fused_gru_wide', 'fused_gru_wide_supported']
+
+
+def fused_gru_wide_supported(x: torch.Tensor, cells) -> bool:
+    H = cells[0].hidden_size
+    return (x.is_cuda and x.dtype == torch.float32 and native.gru_wide_supported(H)
+            and all(c.hidden_size == H and c.bias and c.num_layers == 1 and not c.bidirectional for c in cells))
+
+
+class _GruWideFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, padding_mask, grad_mode, *weights):
+        B, L, _ = x.shape
+        layers = len(weights) // 4
+        H = weights[1].shape[1]
+        ctx.set_materialize_grads(False)
+        mask = None
+        if padding_mask is not None:
+            mask = padding_mask if padding_mask.dtype in (torch.bool, torch.uint8) else padding_mask != 0
+            mask = mask.contiguous()
+        if h0 is not None and h0.stride(2) != 1:
+            h0 = h0.contiguous()
+        need_grad = grad_mode and (any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[4:]))
+        hn = torch.empty(B, L, layers, H, dtype=x.dtype, device=x.device)
+        saved, inp = [], x
+        for l in range(layers):
+            w_ih, w_hh, b_ih, b_hh = (t.detach() for t in weights[4 * l:4 * l + 4])
+            gi = torch.addmm(b_ih, inp.reshape(B * L, -1), w_ih.t()).view(B, L, 3 * H)       # library GEMM
+            h_raw = torch.empty(B, L, H, dtype=x.dtype, device=x.device) if need_grad else None
+            gates = torch.empty(B, L, 4 * H, dtype=x.dtype, device=x.device) if need_grad else None
+            native.gru_wide_forward(gi, w_hh.contiguous(), b_hh.contiguous(), None if h0 is None else h0[:, l], mask,
+                                    hn[:, :, l], h_raw, gates)
+            if need_grad:
+                saved += [inp, h_raw, gates]
+            inp = hn[:, :, l]
+        if need_grad:
+            ctx.layers, ctx.H = layers, H
+            ctx.has_h0, ctx.has_mask = h0 is not None, mask is not None
+            ctx.save_for_backward(*saved, *([h0] if h0 is not None else []), *([mask] if mask is not None else []), *weights)
+        return hn[:, :, layers - 1], hn
+
+    @staticmethod
+    def backward(ctx, grad_out, grad_hn):
+        layers, H = ctx.layers, ctx.H
+        if grad_out is None and grad_hn is None:
+            return (None,) * (4 + 4 * layers)
+        saved = list(ctx.saved_tensors)
+        per_layer = [saved[3 * l:3 * l + 3] for l in range(layers)]
+        rest = saved[3 * layers:]
+        h0 = rest.pop(0) if ctx.has_h0 else None
+        mask = rest.pop(0) if ctx.has_mask else None
+        weights = rest
+        x = per_layer[0][0]
+        B, L = x.shape[:2]
+        dev, dt = x.device, x.dtype
+        g_w = [None] * (4 * layers)
+        g_h0 = torch.zeros(B, layers, H, dtype=dt, device=dev) if (h0 is not None and ctx.needs_input_grad[1]) else None
+        from_above = None        # d loss / d (this layer's masked output) coming from the layer above's input gradient
+        for l in reversed(range(layers)):
+            inp, h_raw, gates = per_layer[l]
+            w_ih, w_hh = weights[4 * l].detach(), weights[4 * l + 1].detach()
+            g = from_above
+            if grad_hn is not None:
+                g = grad_hn[:, :, l] if g is None else g + grad_hn[:, :, l]
+            if l == layers - 1 and grad_out is not None:
+                g = grad_out if g is None else g + grad_out
+            if g is None:
+                g = torch.zeros(B, L, H, dtype=dt, device=dev)
+            if g.stride(2) != 1 or g.stride(0) % 4 or g.stride(1) % 4 or g.data_ptr() % 16:
+                g = g.contiguous()
+            dgi = torch.empty(B, L, 3 * H, dtype=dt, device=dev)
+            dgh = torch.empty(B, L, 3 * H, dtype=dt, device=dev)
+            dh0 = torch.empty(B, H, dtype=dt, device=dev) if g_h0 is not None else None
+            native.gru_wide_backward(g, w_hh.t().contiguous(), gates, h_raw, None if h0 is None else h0[:, l], mask,
+                                     dgi, dgh, dh0)
+            if dh0 is not None:
+                g_h0[:, l] = dh0
+            dgi2, dgh2 = dgi.view(B * L, 3 * H), dgh.view(B * L, 3 * H)
+            # h_{t-1} of every step: the state one step earlier (held at the initial state before a row's first step)
+            h_first = (h0[:, l] if h0 is not None else torch.zeros(B, H, dtype=dt, device=dev)).unsqueeze(1)
+            h_prev = torch.cat([h_first, h_raw[:, :-1]], dim=1).reshape(B * L, H)
+            if ctx.needs_input_grad[4 + 4 * l]:
+                g_w[4 * l] = dgi2.t() @ inp.reshape(B * L, -1)
+                g_w[4 * l + 2] = dgi2.sum(0)
+            if ctx.needs_input_grad[4 + 4 * l + 1]:
+                g_w[4 * l + 1] = dgh2.t() @ h_prev
+                g_w[4 * l + 3] = dgh2.sum(0)
+            from_above = None
+            if l > 0 or ctx.needs_input_grad[0]:
+                from_above = (dgi2 @ w_ih).view(B, L, -1)
+        g_x = from_above if ctx.needs_input_grad[0] else None
+        return (g_x, g_h0, None, None, *g_w)
+
+
+def fused_gru_wide(x, h0, padding_mask, cells):
+    """x [B, L, I]; h0 [B, layers, H] | None; padding_mask bool [B, L] | None -> (output [B, L, H], hn [B, L, layers, H])"""
+    weights = []
+    for c in cells:
+        weights += [c.weight_ih_l0, c.weight_hh_l0, c.bias_ih_l0, c.bias_hh_l0]
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    return _GruWideFn.apply(x, h0, padding_mask, torch.is_grad_enabled(), *weights)

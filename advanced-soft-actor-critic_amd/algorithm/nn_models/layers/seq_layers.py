@@ -71,6 +71,11 @@ class GRU(nn.Module):
         if self._fusable and fused_gru_supported(x, cell.input_size, cell.hidden_size, self.num_layers):
             # one launch for the whole window (csrc/gru.hip); same values as the cell loop below
             return fused_gru(x, h0, padding_mask, list(self._grus), layer=self)     # (top layer [B, L, H], hn)
+        if self._fusable and x.is_cuda:
+            from algorithm.fused_gru_wide import fused_gru_wide, fused_gru_wide_supported
+            if fused_gru_wide_supported(x, list(self._grus)):
+                # hidden 32 / 64 / 128: the recurrence of each layer as one MFMA launch (csrc/gru_wide.hip)
+                return fused_gru_wide(x, h0, padding_mask, list(self._grus))
 
         if h0 is not None:
             h0 = h0.transpose(0, 1).contiguous()  # [layers, batch, hidden]

@@ -1,0 +1,308 @@
+// GRU recurrence for the hidden sizes the reference's environments use (32 / 64 / 128: `m.GRU(…, 64, 1)`
+// envs/square/memory_corridor/nn.py:19, `m.GRU(…, 128, 1)` envs/uav/uav_hole/nn.py:22; layer: reference
+// algorithm/nn_models/layers/seq_layers.py:14-114) on f32 MFMA.  csrc/gru.hip (one lane per hidden unit) stops at 16.
+//
+// What is a plain GEMM stays a library GEMM (the host side, algorithm/fused_gru_wide.py): the input projections of ALL steps
+// gi = x W_ih^T + b_ih before the recurrence, and after the backward recurrence dW_ih = dgi^T x, dW_hh = dgh^T h_prev,
+// dx = dgi W_ih and the bias sums.  Hand-written here: the two time loops — L dependent steps that MIOpen runs as one launch
+// per step and layer.
+//
+// A workgroup owns 16 rows of the batch for the whole window; rows are the N dimension of v_mfma_f32_16x16x4_f32 (the tile
+// scheme of csrc/decoder.hip: lane (q, x) of an accumulator holds units 4 q + r of a 16-unit block for row x, and that float4
+// IS the B operand of the next product's four k-steps).  The recurrent weights live in REGISTERS for the whole loop, read where
+// they lie (a lane's four k are 16 contiguous bytes of a W_hh row; the backward takes W_hh^T): wave w owns the unit blocks
+// w, w + 4, … with their r / z / n rows, so the gate arithmetic of a unit happens in one lane.  Per step: state tiles from LDS
+// (double-buffered, one barrier), 3 H / 16 x H / 4 MFMAs over the workgroup, the gates, stores nobody waits on.
+// Padding as csrc/gru.hip: steps before a row's first unpadded one are skipped (state held), the output of a padded step is 0.
+#include "asac_common.h"
+
+#include <cmath>
+
+namespace asac {
+namespace gruw {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kThreads = 256;
+
+#define GW_MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
+    c = GW_MF(a[0], b[0], c);
+    c = GW_MF(a[1], b[1], c);
+    c = GW_MF(a[2], b[2], c);
+    c = GW_MF(a[3], b[3], c);
+    return c;
+}
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+struct FwdArgs {
+    const float* gi; int64_t gi_sb, gi_st;      // [B][L][3H]: x W_ih^T + b_ih
+    const float* w_hh;                          // [3H][H]
+    const float* b_hh;                          // [3H]
+    const float* h0; int64_t h0_sb;             // [B][H] (row stride h0_sb) or NULL
+    const uint8_t* pad; int64_t pad_sb;         // [B][L] or NULL
+    float* out; int64_t out_sb, out_st;         // the layer's masked output (may be a slice of hn [B][L][layers][H])
+    float* hraw;                                // [B][L][H] the unmasked state after every step, or NULL
+    float* gates;                               // [B][L][4H]: r | z | n | W_hn h + b_hn, or NULL
+    int32_t B, L;
+};
+
+// first unpadded step of a row (0 without a mask or when the whole row is padded)
+__device__ __forceinline__ int lead_of(const uint8_t* pad, int64_t pad_sb, int64_t row, int L) {
+    if (!pad) return 0;
+    const uint8_t* p = pad + row * pad_sb;
+    for (int t = 0; t < L; ++t)
+        if (!p[t]) return t;
+    return 0;
+}
+
+template <int HB>
+__global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
+    constexpr int H = 16 * HB, NBW = (HB + 3) / 4;
+    __shared__ f32x4 s_h[2][HB][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
+    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
+    const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
+    f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int ub = w + 4 * i;
+        if (ub >= HB) continue;
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) {
+#pragma unroll
+            for (int kt = 0; kt < HB; ++kt)
+                wr[i][gate][kt] = *reinterpret_cast<const f32x4*>(a.w_hh + (int64_t)(gate * H + 16 * ub + x) * H + 16 * kt + 4 * q);
+            bh[i][gate] = *reinterpret_cast<const f32x4*>(a.b_hh + gate * H + 16 * ub + 4 * q);
+        }
+        h[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + 16 * ub + 4 * q) : zero4();
+        s_h[0][ub][l] = h[i];
+    }
+    const int lead = lead_of(a.pad, a.pad_sb, row, a.L);
+    // the step's inputs are requested one step ahead
+    f32x4 gi_n[NBW][3];
+    uint8_t pad_n = 0;
+    auto request = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                gi_n[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
+        }
+        pad_n = a.pad ? a.pad[row * a.pad_sb + t] : 0;
+    };
+    request(0);
+    __syncthreads();
+    for (int t = 0; t < a.L; ++t) {
+        const int cur = t & 1;
+        f32x4 gi[NBW][3];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) gi[i][gate] = gi_n[i][gate];
+        const bool padded = pad_n != 0, active = t >= lead;
+        if (t + 1 < a.L) request(t + 1);
+        f32x4 hb[HB];
+#pragma unroll
+        for (int kt = 0; kt < HB; ++kt) hb[kt] = s_h[cur][kt][l];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            f32x4 ar = zero4(), az = zero4(), an = zero4();
+#pragma unroll
+            for (int kt = 0; kt < HB; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ar = GW_MF(wr[i][0][kt][r], hb[kt][r], ar);
+                    az = GW_MF(wr[i][1][kt][r], hb[kt][r], az);
+                    an = GW_MF(wr[i][2][kt][r], hb[kt][r], an);
+                }
+            f32x4 rg, zg, ng, hn, hv, ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rg[r] = sigmoidf_(gi[i][0][r] + (ar[r] + bh[i][0][r]));
+                zg[r] = sigmoidf_(gi[i][1][r] + (az[r] + bh[i][1][r]));
+                hn[r] = an[r] + bh[i][2][r];
+                ng[r] = tanhf(gi[i][2][r] + rg[r] * hn[r]);
+                const float hnew = (1.f - zg[r]) * ng[r] + zg[r] * h[i][r];
+                hv[r] = active ? hnew : h[i][r];
+                ov[r] = padded ? 0.f : hv[r];
+            }
+            h[i] = hv;
+            s_h[cur ^ 1][ub][l] = hv;
+            if (live) {
+                const int col = 16 * ub + 4 * q;
+                *reinterpret_cast<f32x4*>(a.out + row * a.out_sb + t * a.out_st + col) = ov;
+                if (a.hraw) *reinterpret_cast<f32x4*>(a.hraw + (row * a.L + t) * H + col) = hv;
+                if (a.gates) {
+                    float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
+                    *reinterpret_cast<f32x4*>(gp) = rg;
+                    *reinterpret_cast<f32x4*>(gp + H) = zg;
+                    *reinterpret_cast<f32x4*>(gp + 2 * H) = ng;
+                    *reinterpret_cast<f32x4*>(gp + 3 * H) = hn;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct BwdArgs {
+    const float* gout; int64_t go_sb, go_st;    // [B][L][H] gradient of the layer's masked output
+    const float* w_hh_t;                        // [H][3H] = W_hh^T
+    const float* gates;                         // [B][L][4H]
+    const float* hraw;                          // [B][L][H]
+    const float* h0; int64_t h0_sb;
+    const uint8_t* pad; int64_t pad_sb;
+    float* dgi;                                 // [B][L][3H] gradient of gi (zero where a step did not run)
+    float* dgh;                                 // [B][L][3H] gradient of W_hh h + b_hh
+    float* dh0;                                 // [B][H] or NULL
+    int32_t B, L;
+};
+
+template <int HB>
+__global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
+    constexpr int H = 16 * HB, NBW = (HB + 3) / 4, KT = 3 * HB;
+    __shared__ f32x4 s_g[2][KT][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
+    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
+    const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
+    f32x4 wt[NBW][KT], dh[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int ub = w + 4 * i;
+        dh[i] = zero4();
+        if (ub >= HB) continue;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            wt[i][kt] = *reinterpret_cast<const f32x4*>(a.w_hh_t + (int64_t)(16 * ub + x) * (3 * H) + 16 * kt + 4 * q);
+    }
+    const int lead = lead_of(a.pad, a.pad_sb, row, a.L);
+    for (int t = a.L - 1; t >= 0; --t) {
+        const int cur = t & 1;
+        const bool padded = a.pad ? a.pad[row * a.pad_sb + t] != 0 : false;
+        const bool active = t >= lead;
+        f32x4 direct[NBW];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            const int col = 16 * ub + 4 * q;
+            f32x4 g = zero4();
+            if (!padded && live) g = *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col);
+            const float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
+            const f32x4 rg = *reinterpret_cast<const f32x4*>(gp), zg = *reinterpret_cast<const f32x4*>(gp + H),
+                        ng = *reinterpret_cast<const f32x4*>(gp + 2 * H), hn = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+            f32x4 hp;
+            if (t > 0) hp = *reinterpret_cast<const f32x4*>(a.hraw + (row * a.L + t - 1) * H + col);
+            else hp = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + col) : zero4();
+            f32x4 d_r, d_z, d_n, d_nh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dht = dh[i][r] + g[r];
+                const float dn = dht * (1.f - zg[r]), dz = dht * (hp[r] - ng[r]);
+                const float dn_pre = dn * (1.f - ng[r] * ng[r]);
+                const float dz_pre = dz * zg[r] * (1.f - zg[r]);
+                const float dr_pre = dn_pre * hn[r] * rg[r] * (1.f - rg[r]);
+                d_r[r] = active ? dr_pre : 0.f;
+                d_z[r] = active ? dz_pre : 0.f;
+                d_n[r] = active ? dn_pre : 0.f;
+                d_nh[r] = active ? dn_pre * rg[r] : 0.f;
+                direct[i][r] = active ? dht * zg[r] : dht;
+            }
+            if (live) {
+                float* o = a.dgi + (row * a.L + t) * (3 * H) + col;
+                *reinterpret_cast<f32x4*>(o) = d_r;
+                *reinterpret_cast<f32x4*>(o + H) = d_z;
+                *reinterpret_cast<f32x4*>(o + 2 * H) = d_n;
+                float* o2 = a.dgh + (row * a.L + t) * (3 * H) + col;
+                *reinterpret_cast<f32x4*>(o2) = d_r;
+                *reinterpret_cast<f32x4*>(o2 + H) = d_z;
+                *reinterpret_cast<f32x4*>(o2 + 2 * H) = d_nh;
+            }
+            s_g[cur][0 * HB + ub][l] = d_r;
+            s_g[cur][1 * HB + ub][l] = d_z;
+            s_g[cur][2 * HB + ub][l] = d_nh;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            f32x4 acc0 = zero4(), acc1 = zero4();      // two chains: the products are the whole step
+#pragma unroll
+            for (int kt = 0; kt < KT; kt += 2) {
+                acc0 = mfma4(wt[i][kt], s_g[cur][kt][l], acc0);
+                if (kt + 1 < KT) acc1 = mfma4(wt[i][kt + 1], s_g[cur][kt + 1][l], acc1);
+            }
+            dh[i] = direct[i] + (acc0 + acc1);
+        }
+    }
+    if (a.dh0 && live) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            *reinterpret_cast<f32x4*>(a.dh0 + row * H + 16 * ub + 4 * q) = dh[i];
+        }
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace gruw
+}  // namespace asac
+
+using namespace asac;
+using namespace asac::gruw;
+
+extern "C" {
+
+int asac_gru_wide_supported(int hidden) { return hidden == 32 || hidden == 64 || hidden == 128; }
+
+int asac_gru_wide_forward(const float* gi, int64_t gi_stride_b, int64_t gi_stride_t, const float* w_hh, const float* b_hh,
+                          const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask, int64_t mask_stride_b, int B,
+                          int L, int hidden, float* out, int64_t out_stride_b, int64_t out_stride_t, float* h_raw,
+                          float* gates, void* stream) {
+    if (!gi || !w_hh || !b_hh || !out || B <= 0 || L <= 0 || !asac_gru_wide_supported(hidden) || !aligned16(gi) ||
+        !aligned16(w_hh) || !aligned16(b_hh) || !aligned16(out) || (h0 && !aligned16(h0)) || (gi_stride_b & 3) ||
+        (gi_stride_t & 3) || (out_stride_b & 3) || (out_stride_t & 3) || (h0_stride_b & 3) || (h_raw && !aligned16(h_raw)) ||
+        (gates && !aligned16(gates)))
+        return bad_arg("asac_gru_wide_forward");
+    FwdArgs a;
+    a.gi = gi, a.gi_sb = gi_stride_b, a.gi_st = gi_stride_t, a.w_hh = w_hh, a.b_hh = b_hh, a.h0 = h0, a.h0_sb = h0_stride_b;
+    a.pad = padding_mask, a.pad_sb = mask_stride_b, a.out = out, a.out_sb = out_stride_b, a.out_st = out_stride_t;
+    a.hraw = h_raw, a.gates = gates, a.B = B, a.L = L;
+    const dim3 grid((unsigned)((B + 15) / 16)), block(kThreads);
+    hipStream_t s = as_stream(stream);
+    if (hidden == 32) ASAC_LAUNCH(k_gruw_fwd<2>, grid, block, 0, s, a);
+    else if (hidden == 64) ASAC_LAUNCH(k_gruw_fwd<4>, grid, block, 0, s, a);
+    else ASAC_LAUNCH(k_gruw_fwd<8>, grid, block, 0, s, a);
+    return finish_launch("asac_gru_wide_forward");
+}
+
+int asac_gru_wide_backward(const float* grad_out, int64_t go_stride_b, int64_t go_stride_t, const float* w_hh_t,
+                           const float* gates, const float* h_raw, const float* h0, int64_t h0_stride_b,
+                           const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, int hidden, float* grad_gi,
+                           float* grad_gh, float* grad_h0, void* stream) {
+    if (!grad_out || !w_hh_t || !gates || !h_raw || !grad_gi || !grad_gh || B <= 0 || L <= 0 ||
+        !asac_gru_wide_supported(hidden) || !aligned16(grad_out) || !aligned16(w_hh_t) || !aligned16(gates) ||
+        !aligned16(h_raw) || !aligned16(grad_gi) || !aligned16(grad_gh) || (h0 && !aligned16(h0)) ||
+        (grad_h0 && !aligned16(grad_h0)) || (go_stride_b & 3) || (go_stride_t & 3) || (h0_stride_b & 3))
+        return bad_arg("asac_gru_wide_backward");
+    BwdArgs a;
+    a.gout = grad_out, a.go_sb = go_stride_b, a.go_st = go_stride_t, a.w_hh_t = w_hh_t, a.gates = gates, a.hraw = h_raw;
+    a.h0 = h0, a.h0_sb = h0_stride_b, a.pad = padding_mask, a.pad_sb = mask_stride_b;
+    a.dgi = grad_gi, a.dgh = grad_gh, a.dh0 = grad_h0, a.B = B, a.L = L;
+    const dim3 grid((unsigned)((B + 15) / 16)), block(kThreads);
+    hipStream_t s = as_stream(stream);
+    if (hidden == 32) ASAC_LAUNCH(k_gruw_bwd<2>, grid, block, 0, s, a);
+    else if (hidden == 64) ASAC_LAUNCH(k_gruw_bwd<4>, grid, block, 0, s, a);
+    else ASAC_LAUNCH(k_gruw_bwd<8>, grid, block, 0, s, a);
+    return finish_launch("asac_gru_wide_backward");
+}
+
+}  // extern "C"

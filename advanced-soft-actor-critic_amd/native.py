@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 57
+ABI_VERSION = 58
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -344,6 +344,13 @@ _SIGNATURES = {
     'asac_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     'asac_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'asac_gru_wide_supported': (C.c_int, [C.c_int]),
+    'asac_gru_wide_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_gru_wide_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     'asac_cosine_gate_add': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     'asac_obs_decoder_packed_floats': (C.c_int64, []),
@@ -1654,3 +1661,45 @@ def cosine_gate_add(main, aux_list, grad, gates_out=None):
     ptrs = (C.c_void_p * len(aux_list))(*[t.data_ptr() for t in aux_list])
     _check(load().asac_cosine_gate_add(_p(main), ptrs, len(aux_list), n, _p(grad), _p(gates_out), _stream()),
            'asac_cosine_gate_add')
+
+
+# ------------------------------------------------------------------------------------------------
+# GRU recurrence for hidden 32 / 64 / 128 (csrc/gru_wide.hip)
+# ------------------------------------------------------------------------------------------------
+def gru_wide_supported(hidden: int) -> bool:
+    return bool(load().asac_gru_wide_supported(int(hidden)))
+
+
+def _mask_ptr(mask):
+    if mask is None:
+        return None, 0
+    assert mask.is_cuda and mask.element_size() == 1 and mask.dim() == 2 and mask.stride(1) == 1
+    return _p(mask), mask.stride(0)
+
+
+@_profiled
+def gru_wide_forward(gi, w_hh, b_hh, h0, mask, out, h_raw, gates):
+    """one layer's recurrence: gi [B, L, 3H] -> out [B, L, H] (a strided view is fine); see include/asac_hip.h"""
+    global _last_work
+    B, L, H3 = gi.shape
+    H = H3 // 3
+    _last_work = 2.0 * B * L * 3 * H * H
+    assert gi.stride(2) == 1 and out.stride(2) == 1 and out.shape == (B, L, H)
+    _dense_f32(w_hh, b_hh, h_raw, gates)
+    pm, ms = _mask_ptr(mask)
+    _check(load().asac_gru_wide_forward(_p(gi), gi.stride(0), gi.stride(1), _p(w_hh), _p(b_hh), _p(h0),
+                                        0 if h0 is None else h0.stride(0), pm, ms, B, L, H, _p(out), out.stride(0),
+                                        out.stride(1), _p(h_raw), _p(gates), _stream()), 'asac_gru_wide_forward')
+
+
+@_profiled
+def gru_wide_backward(grad_out, w_hh_t, gates, h_raw, h0, mask, grad_gi, grad_gh, grad_h0):
+    global _last_work
+    B, L, H = grad_out.shape
+    _last_work = 2.0 * B * L * 3 * H * H
+    assert grad_out.stride(2) == 1
+    _dense_f32(w_hh_t, gates, h_raw, grad_gi, grad_gh, grad_h0)
+    pm, ms = _mask_ptr(mask)
+    _check(load().asac_gru_wide_backward(_p(grad_out), grad_out.stride(0), grad_out.stride(1), _p(w_hh_t), _p(gates),
+                                         _p(h_raw), _p(h0), 0 if h0 is None else h0.stride(0), pm, ms, B, L, H,
+                                         _p(grad_gi), _p(grad_gh), _p(grad_h0), _stream()), 'asac_gru_wide_backward')

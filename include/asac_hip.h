@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 57
+#define ASAC_ABI_VERSION 58
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -739,6 +739,31 @@ int asac_gru_backward_at(const asac_gru_desc_t* desc_host, const float* const* w
                          const float* gates, const float* grad_top_members, int members, int position,
                          float* grad_x, float* grad_h0, float* grad_params, float* const* grad_param_tensors,
                          int accumulate, const asac_adam_epilogue_t* adam, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GRU recurrence for hidden sizes 32 / 64 / 128 on f32 MFMA (csrc/gru_wide.hip): the time loops of ONE layer of the
+ * plugin layer `GRU` (nn_models/layers/seq_layers.py:14-114; `m.GRU(…, 64, 1)` envs/square/memory_corridor/nn.py:19,
+ * `m.GRU(…, 128, 1)` envs/uav/uav_hole/nn.py:22) under `get_l_states` (sac_base.py:1117-1146).  The batched products
+ * around them are library GEMMs on the host side (algorithm/fused_gru_wide.py): gi = x W_ih^T + b_ih before, dW_ih =
+ * dgi^T x, dW_hh = dgh^T h_prev, dx = dgi W_ih and the bias sums after.
+ *   forward : gi [B][L][3H] (strides in floats), w_hh [3H][H], b_hh [3H], h0 [B][H] (row stride) or NULL, padding_mask
+ *             [B][L] bytes or NULL -> out (the masked output, strided: may be a layer's slice of hn [B][L][layers][H]),
+ *             h_raw [B][L][H] (the unmasked state after every step) and gates [B][L][4H] (r | z | n | W_hn h + b_hn): both
+ *             saved for the backward, both or neither NULL.  Padding as asac_gru_forward: steps before a row's first
+ *             unpadded one are skipped (state held), the output of a padded step is 0.
+ *   backward: grad_out [B][L][H] (gradient of the masked output, strided), w_hh_t [H][3H] = W_hh^T -> grad_gi, grad_gh
+ *             [B][L][3H] (gradients of gi and of W_hh h + b_hh; zero where a step did not run), grad_h0 [B][H] or NULL.
+ * Every pointer 16-byte aligned, every stride a multiple of 4 floats.  Deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------- */
+int asac_gru_wide_supported(int hidden);
+int asac_gru_wide_forward(const float* gi, int64_t gi_stride_b, int64_t gi_stride_t, const float* w_hh, const float* b_hh,
+                          const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask, int64_t mask_stride_b, int B,
+                          int L, int hidden, float* out, int64_t out_stride_b, int64_t out_stride_t, float* h_raw,
+                          float* gates, void* stream);
+int asac_gru_wide_backward(const float* grad_out, int64_t go_stride_b, int64_t go_stride_t, const float* w_hh_t,
+                           const float* gates, const float* h_raw, const float* h0, int64_t h0_stride_b,
+                           const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, int hidden, float* grad_gi,
+                           float* grad_gh, float* grad_h0, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused two-layer convolution stack: Conv2d(C->out1, kernel1, stride1) GELU Conv2d(out1->out2, kernel2,
