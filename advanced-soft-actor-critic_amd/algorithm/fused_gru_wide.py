@@ -7,16 +7,20 @@ all steps, ONE launch for the recurrence (MIOpen: one launch per step); backward
 three library GEMMs (dW_ih, dW_hh, dx) and two column sums.  Same values as the cell loop of the module path (the padding rule
 of the layer included: steps before a row's first unpadded one are skipped, padded outputs are zero).
 """
+import os
+
 import torch
 
 from asac_amd import native
 
 __all__ = ['fused_gru_wide', 'fused_gru_wide_supported']
 
+ENABLED = os.environ.get('ASAC_GRU_WIDE', '1') != '0'      # (0: keep the module path — A/B runs)
+
 
 def fused_gru_wide_supported(x: torch.Tensor, cells) -> bool:
     H = cells[0].hidden_size
-    return (x.is_cuda and x.dtype == torch.float32 and native.gru_wide_supported(H)
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and native.gru_wide_supported(H)
             and all(c.hidden_size == H and c.bias and c.num_layers == 1 and not c.bidirectional for c in cells))
 
 

@@ -33,7 +33,13 @@ __device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
     c = GW_MF(a[3], b[3], c);
     return c;
 }
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+// sigmoid / tanh on the hardware exp2 and reciprocal, as csrc/gru.hip (absolute error ~1e-7; on the serial chain of a step)
+__device__ __forceinline__ float sigmoidf_(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896f * v));
+}
+__device__ __forceinline__ float tanhf_(float v) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177793f * v));
+}
 
 struct FwdArgs {
     const float* gi; int64_t gi_sb, gi_st;      // [B][L][3H]: x W_ih^T + b_ih
@@ -126,7 +132,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
                 rg[r] = sigmoidf_(gi[i][0][r] + (ar[r] + bh[i][0][r]));
                 zg[r] = sigmoidf_(gi[i][1][r] + (az[r] + bh[i][1][r]));
                 hn[r] = an[r] + bh[i][2][r];
-                ng[r] = tanhf(gi[i][2][r] + rg[r] * hn[r]);
+                ng[r] = tanhf_(gi[i][2][r] + rg[r] * hn[r]);
                 const float hnew = (1.f - zg[r]) * ng[r] + zg[r] * h[i][r];
                 hv[r] = active ? hnew : h[i][r];
                 ov[r] = padded ? 0.f : hv[r];

@@ -83,6 +83,10 @@ CONFIGS['cfg5_without_prediction'] = dict(
     CONFIGS['cfg5'], use_prediction=False,
     desc='cfg5 without use_prediction: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, '
          'PER capacity 65536')
+# cfg3 with the recurrent core of the reference's environments (one GRU layer of 64 units: envs/square/memory_corridor/nn.py:19)
+CONFIGS['cfg3_h64'] = dict(
+    CONFIGS['cfg3'], plugin='nn_rnn_h64', hidden=(1, 64),
+    desc='cfg3_h64: GRU(64)x1 rep (the reference environments\' width), burn_in_step=40 n_step=40 (window 81), PER capacity 524288')
 CFG = dict(CONFIGS['cfg2'])
 
 
@@ -301,7 +305,7 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess
