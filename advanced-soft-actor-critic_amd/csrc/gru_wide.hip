@@ -41,6 +41,10 @@ __device__ __forceinline__ float tanhf_(float v) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008177793f * v));
 }
 
+// workgroup barrier that orders LDS traffic only: `__syncthreads()` is a full fence and would wait, every step, for the
+// step's stores and the next step's prefetched loads
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct FwdArgs {
     const float* gi; int64_t gi_sb, gi_st;      // [B][L][3H]: x W_ih^T + b_ih
     const float* w_hh;                          // [3H][H]
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
             s_g[cur][1 * HB + ub][l] = d_z;
             s_g[cur][2 * HB + ub][l] = d_nh;
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
