@@ -4,7 +4,7 @@ The plugin layer `nn_models.layers.GRU` (reference `seq_layers.py:14-114`) route
 reference's environments use (`m.GRU(…, 64, 1)` envs/square/memory_corridor/nn.py:19, `m.GRU(…, 128, 1)`
 envs/uav/uav_hole/nn.py:22) — `csrc/gru.hip` stops at 16.  Per layer and pass: ONE library GEMM for the input projections of
 all steps, ONE launch for the recurrence (MIOpen: one launch per step); backward: one launch for the recurrence through time,
-three library GEMMs (dW_ih, dW_hh, dx) and two column sums.  Same values as the cell loop of the module path (the padding rule
+three library GEMMs (dW_ih, dW_hh, dx) and two column sums (as products with a row of ones).  Same values as the cell loop of the module path (the padding rule
 of the layer included: steps before a row's first unpadded one are skipped, padded outputs are zero).
 """
 import os
@@ -93,15 +93,16 @@ class _GruWideFn(torch.autograd.Function):
             if dh0 is not None:
                 g_h0[:, l] = dh0
             dgi2, dgh2 = dgi.view(B * L, 3 * H), dgh.view(B * L, 3 * H)
+            ones = torch.ones(1, B * L, dtype=dt, device=dev)      # column sums as library products (fixed order)
             # h_{t-1} of every step: the state one step earlier (held at the initial state before a row's first step)
             h_first = (h0[:, l] if h0 is not None else torch.zeros(B, H, dtype=dt, device=dev)).unsqueeze(1)
             h_prev = torch.cat([h_first, h_raw[:, :-1]], dim=1).reshape(B * L, H)
             if ctx.needs_input_grad[4 + 4 * l]:
                 g_w[4 * l] = dgi2.t() @ inp.reshape(B * L, -1)
-                g_w[4 * l + 2] = dgi2.sum(0)
+                g_w[4 * l + 2] = (ones @ dgi2).view(-1)
             if ctx.needs_input_grad[4 + 4 * l + 1]:
                 g_w[4 * l + 1] = dgh2.t() @ h_prev
-                g_w[4 * l + 3] = dgh2.sum(0)
+                g_w[4 * l + 3] = (ones @ dgh2).view(-1)
             from_above = None
             if l > 0 or ctx.needs_input_grad[0]:
                 from_above = (dgi2 @ w_ih).view(B, L, -1)

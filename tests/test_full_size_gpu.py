@@ -23,7 +23,7 @@ import bench  # noqa: E402
 from oracle import sac_ref  # noqa: E402
 from tests import parity_utils as pu  # noqa: E402
 
-FILL = {'cfg1': 2 ** 15, 'cfg2': 2 ** 15, 'cfg3': 2 ** 14, 'cfg4': 4096, 'cfg5': 4096}
+FILL = {'cfg1': 2 ** 15, 'cfg2': 2 ** 15, 'cfg3': 2 ** 14, 'cfg3_h64': 2 ** 13, 'cfg4': 4096, 'cfg5': 4096}
 # observable -> (rtol, atol), set from the observed errors (profiles/r03_parity_errors.json; <= 4x the worst seen)
 TOL = {'is_weights': (2e-6, 0.), 'loss_q': (2e-4, 0.), 'loss_curiosity': (2e-4, 0.), 'td_error': (2e-4, 5e-5),
        'tree': (2e-4, 1e-5), 'mu_prob': (5e-3, 1e-6), 'hidden': (2e-4, 5e-5), 'log_c_alpha': (2e-4, 0.)}
@@ -49,7 +49,7 @@ def _episode(rng, cfg, T):
                 ep_pre_seq_hidden_states=rng.standard_normal((1, T, *cfg['hidden'])).astype(np.float32))
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg4', 'cfg5'])
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5'])
 def test_baseline_config_full_size_vs_oracle(name):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
@@ -114,6 +114,7 @@ def test_baseline_config_full_size_vs_oracle(name):
         assert np.array_equal(rb._ids.cpu().numpy(), out['ids']), f'{name} step {step}: PER index selection differs in {int((rb._ids.cpu().numpy() != out["ids"]).sum())} of {B} rows'
         if cfg.get('use_priority', True):
             chk('is_weights', rb._w.cpu().numpy()[:, None], out['is_weights'])
+        print(f'{name} step {step}: loss_q {agent._stats["loss_q"].item():.6f} / {float(out["loss_q"]):.6f}')
         chk('loss_q', agent._stats['loss_q'].item(), float(out['loss_q']))
         if cfg.get('curiosity'):
             chk('loss_curiosity', agent._stats['loss_curiosity'].item(), float(out['loss_curiosity']))
@@ -125,6 +126,8 @@ def test_baseline_config_full_size_vs_oracle(name):
                     pu.check(f'full_size/{name}/prediction_weights', v, vo, rtol=0., atol=2.2 * 3e-4 * (step + 1))
             assert out['rpm'] is not None and np.isfinite(out['rpm']['losses'].numpy()).all()
         if cfg.get('use_priority', True):
+            _t, _o = agent._td_error.cpu().numpy(), out['td_error'].reshape(-1)
+            print(f'{name} step {step}: td max|diff| {np.abs(_t - _o).max():.3e} of {np.abs(_o).max():.3f}; log_alpha {agent.log_c_alpha.item():.6f} / {oracle.log_c_alpha.item():.6f}')
             chk('td_error', agent._td_error.cpu().numpy(), out['td_error'].reshape(-1))
         else:       # the tree is frozen: sampled, never updated (reference sac_base.py:2571-2584)
             assert torch.equal(rb._tree, tree_before)

@@ -20,9 +20,9 @@ from collections import defaultdict
 
 def short(name: str) -> str:
     name = re.sub(r'\[clone.*', '', name).strip()
-    m = re.match(r'(void )?(asac::)?([A-Za-z_0-9]+)', name)
-    if name.startswith('asac::') or 'asac::' in name[:12]:
-        return 'asac::' + m.group(3)
+    m = re.match(r'(void )?(asac::[A-Za-z_0-9:]+)', name)
+    if m:       # (nested namespaces kept: asac::dec::k_dec_fwd12)
+        return m.group(2)
     name = re.sub(r'at::native::(\(anonymous namespace\)::)?', '', name)
     m = re.match(r'(void )?([A-Za-z_0-9:]+)', name)
     return (m.group(2) if m else name)[:60]
