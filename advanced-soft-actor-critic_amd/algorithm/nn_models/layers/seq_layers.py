@@ -36,6 +36,7 @@ positions, which lets a window be continued from where the last one stopped:
                                    element (training: one stored state per sampled window)
 """
 import math
+import os
 from enum import Enum
 
 import torch
@@ -179,6 +180,8 @@ class RotaryPositionalEncoding2(nn.Module):
 
 # ------------------------------------------------------------------------------------------------
 FUSED_PROJECTIONS = True      # q / k / v Linear projections inside the attention launch when they are plain Linears
+# several heads: the core of all heads as one MFMA launch (csrc/attn_mh.hip); ASAC_ATTN_MH=0 keeps the module path (A/B runs)
+FUSED_MULTIHEAD = os.environ.get('ASAC_ATTN_MH', '1') != '0'
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -211,6 +214,43 @@ class _AttnCoreFn(torch.autograd.Function):
         native.attention_backward(q, k, v, weights, g_out.contiguous(), None if g_w is None else g_w.contiguous(),
                                   g_q, g_k, g_v)
         return g_q, g_k, g_v, None
+
+
+class _AttnMhFn(torch.autograd.Function):
+    """scores / mask / softmax / weighted sum of ALL heads and the head-averaged weights as one MFMA launch per pass
+    (`asac_attention_mh_forward/backward`, csrc/attn_mh.hip): q, k, v [B, L, heads * d] -> (out [B, Lq, heads * d] with the
+    heads concatenated, mean-over-heads weights * keep, keep)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads):
+        from asac_amd import native
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        out = torch.empty(B, Lq, E, dtype=q.dtype, device=q.device)
+        weights = torch.empty(B, Lq, Lk, dtype=q.dtype, device=q.device)
+        keep = torch.empty(B, Lq, dtype=q.dtype, device=q.device)
+        p_heads = torch.empty(B, heads, Lq, Lk, dtype=q.dtype, device=q.device) if any(ctx.needs_input_grad[:3]) else None
+        native.attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads)
+        if p_heads is not None:
+            ctx.save_for_backward(q, k, v, p_heads, *([mask] if mask is not None else []))
+        ctx.heads, ctx.has_mask = heads, mask is not None
+        ctx.mark_non_differentiable(keep)
+        ctx.set_materialize_grads(False)
+        return out, weights, keep
+
+    @staticmethod
+    def backward(ctx, g_out, g_w, _g_keep):
+        from asac_amd import native
+        q, k, v, p_heads, *rest = ctx.saved_tensors
+        if g_out is None and g_w is None:
+            return None, None, None, None, None
+        if g_out is None:
+            g_out = torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+        g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        native.attention_mh_backward(q, k, v, rest[0] if ctx.has_mask else None, ctx.heads, p_heads, g_out.contiguous(),
+                                     None if g_w is None else g_w.contiguous(), g_q, g_k, g_v)
+        return g_q, g_k, g_v, None, None
 
 
 class _AttnProjFn(torch.autograd.Function):
@@ -418,6 +458,25 @@ class MultiheadAttention(nn.Module):
         q, k, v = self.q_proj(query), self.k_proj(key), self.v_proj(value)
         if self.pe in (POSITIONAL_ENCODING.ROPE, POSITIONAL_ENCODING.ROPE2):
             q, k = self.rope(query_index, key_index, q, k)
+        if (FUSED_MULTIHEAD and (self.num_heads > 1 or self.head_dim > 16) and q.is_cuda and q.dtype == torch.float32
+                and not (self.training and self.dropout > 0.)):
+            from asac_amd import native
+            if native.attention_mh_supported(q_len, k_len, self.num_heads, self.head_dim):
+                # several heads (or one wide head): scores, mask, softmax, weighted sum and the head average as one MFMA launch (csrc/attn_mh.hip)
+                m = attn_mask
+                if key_padding_mask is not None:
+                    kpm = key_padding_mask.unsqueeze(1)
+                    m = kpm.expand(-1, q_len, -1) if m is None else torch.logical_or(m, kpm)
+                if m is not None:
+                    m = m.unsqueeze(0) if m.dim() == 2 else m
+                    m = m if m.dtype in (torch.bool, torch.uint8) else m != 0
+                out, weights, keep = _AttnMhFn.apply(q, k, v, m, self.num_heads)
+                out = self.out_proj(out)
+                if m is not None:
+                    out = out * keep.unsqueeze(-1)
+                if out_row_mask is not None:
+                    out = out * (~out_row_mask.reshape(-1, out_row_mask.shape[-1])).to(out.dtype).unsqueeze(-1)
+                return out.reshape(*lead, *out.shape[1:]), weights.reshape(*lead, *weights.shape[1:])
         q, k, v = self._split_heads(q), self._split_heads(k), self._split_heads(v)
 
         if key_padding_mask is not None:

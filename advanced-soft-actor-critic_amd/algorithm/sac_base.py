@@ -230,6 +230,7 @@ class SAC_Base(AuxHeadsMixin):
         hip_config = dict(hip_config or {})
         self._use_graph = bool(hip_config.get('use_graph', True))
         self._graph_warmup = int(hip_config.get('graph_warmup', 3))
+        self._direct_graph_launch = bool(hip_config.get('direct_graph_launch', True))   # (False: every replay through torch)
         self._dist = hip_config.get('dist')     # parallel.DataParallelContext or None
         self._use_fused_mlp = bool(hip_config.get('fused_mlp', True))
         self._graph_collectives = bool(hip_config.get('graph_collectives', True))
@@ -2027,15 +2028,27 @@ class SAC_Base(AuxHeadsMixin):
         if self.use_n_step_is and not post.mu_written:
             rb.update_window_transitions(ids, -b, b + n, w.bnx_pad, 'mu_prob', pi_probs)
 
+    def _finish_graph(self, graph) -> None:
+        """A captured (kept, not yet instantiated) graph -> executable: its memset nodes become kernel nodes first — on this
+        ROCm a captured hipMemsetAsync takes effect on the first launch only, and ATen's split reductions (every
+        nn.Linear's bias gradient) zero their semaphores with one (csrc/graph_fix.hip)."""
+        replaced, kept = native.graph_replace_memset_nodes(int(graph.raw_cuda_graph()))
+        graph.instantiate()
+        if replaced or kept:
+            self._logger.info(f'captured graph: {replaced} memset node(s) replaced by fill kernels' +
+                              (f', {kept} 2-D memset node(s) left as captured' if kept else ''))
+        self._graph_memsets = (replaced, kept)
+
     def _try_capture(self) -> None:
         """Warm up on a side stream, then capture `_device_step` into one hipGraph."""
         try:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True)
             # thread_local: the RCCL watchdog thread may query events while this thread captures
             with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                 self._device_step()
+            self._finish_graph(graph)
             self._graph = graph
             self._graph_exec, self._graph_exec_checked = None, False
             # (logp, scale) of the policy step live in THIS graph's private pool: whichever graph ran last is the one
@@ -2057,7 +2070,7 @@ class SAC_Base(AuxHeadsMixin):
         if self._graph_exec is not None:
             native.graph_launch(self._graph_exec)
             return
-        if self._graph_exec_checked:
+        if self._graph_exec_checked or not self._direct_graph_launch:
             self._graph.replay()
             return
         gen = torch.cuda.default_generators[self.device.index or 0]
@@ -2163,10 +2176,11 @@ class SAC_Base(AuxHeadsMixin):
             try:
                 side = torch.cuda.Stream(device=self.device)
                 side.wait_stream(torch.cuda.current_stream())
-                graph = torch.cuda.CUDAGraph()
+                graph = torch.cuda.CUDAGraph(keep_graph=True)
                 with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
                     for _ in range(k):
                         self._device_step()
+                self._finish_graph(graph)
                 torch.cuda.current_stream().wait_stream(side)
                 cached = self._graph_runs[k] = (self._graph, graph, int(graph.raw_cuda_graph_exec()), self._pi_stats_src)
             except Exception as e:

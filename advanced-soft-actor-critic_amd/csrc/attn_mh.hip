@@ -1,0 +1,398 @@
+// Multi-head attention core for short windows on f32 MFMA: scores, mask, softmax, weighted sum of values and the head-averaged
+// weights of `MultiheadAttention.forward` (reference algorithm/nn_models/layers/seq_layers.py:239-333) for the widths the
+// reference's environments use (`EpisodeMultiheadAttention(64, …, num_heads 2 … 8)`: envs/square/obstacle/nn_attn.py:16,
+// envs/gym/toy_queue/nn_attn.py:28-45) — csrc/attn.hip (one lane per (batch, query) row) covers one head of <= 16 channels.
+// The q / k / v / output projections around it are plain Linears: library GEMMs on the host side (seq_layers.py here).
+//
+// One wave owns a batch entry and walks its heads (so the head average of the weights is a register sum, in head order).
+// Per head, with windows of <= 32 positions as <= 2 x 2 tiles of 16 and the QUERIES as the N dimension:
+//   S[key][query]  = K Q^T       A = a key row's 16 bytes of channels, B = a query row's (x 1/sqrt(d))
+//   P = softmax over the keys: the keys of a query live in 4 registers x 4 lanes x <= 2 tiles -> two shuffles
+//   O[c][query]    = V^T P       B = the P tile as it stands (keys are its k-slots), A = 4 strided words of V
+// Backward: dP = V dO^T (same shape as S), dS = P (dP - sum_keys P dP), dQ = K^T dS, and the two products over the QUERIES
+// (dV = P dO, dK = dS Q) with P / dS turned through LDS.  "Dead" rows (every key blocked) attend unmasked and report
+// keep = 0, as csrc/attn.hip and the reference do.
+#include "asac_common.h"
+
+#include <cmath>
+
+namespace asac {
+namespace amh {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kThreads = 256;      // 4 waves = 4 batch entries
+constexpr int kMaxL = 32;
+
+#define AM_MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 mfma4(const f32x4 a, const f32x4 b, f32x4 c) {
+    c = AM_MF(a[0], b[0], c);
+    c = AM_MF(a[1], b[1], c);
+    c = AM_MF(a[2], b[2], c);
+    c = AM_MF(a[3], b[3], c);
+    return c;
+}
+// reductions over the lanes that share x (a query's keys are spread over the four lane quarters)
+__device__ __forceinline__ float max_over_q(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float sum_over_q(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ int tpos(int f) { return ((f & 3) << 2) | (f >> 2); }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct Args {
+    const float* q; const float* k; const float* v;      // [B][Lq][E], [B][Lk][E], [B][Lk][E]  (E = heads * d)
+    const uint8_t* mask; int64_t m_sb, m_si, m_sj;       // blocked (b, query, key), shared by the heads; or NULL
+    int32_t B, Lq, Lk, H, d;
+    float* out;            // [B][Lq][E]
+    float* w_avg;          // [B][Lq][Lk]  mean over heads of softmax, * keep
+    float* keep;           // [B][Lq]
+    float* p_heads;        // [B][H][Lq][Lk] per-head softmax (saved for the backward) or NULL
+    // backward
+    const float* g_out;    // [B][Lq][E]
+    const float* g_w;      // [B][Lq][Lk] or NULL
+    float* g_q; float* g_k; float* g_v;
+};
+
+// 16 bytes of channels [c0, c0 + 4) of a row, zero beyond d (and for rows beyond the window)
+__device__ __forceinline__ f32x4 row4(const float* base, bool live, int c0, int d) {
+    f32x4 v = zero4();
+    if (live && c0 + 3 < d) return *reinterpret_cast<const f32x4*>(base + c0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (live && c0 + r < d) v[r] = base[c0 + r];
+    return v;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
+    __shared__ float s_t[4][8][256];       // per wave: P and dS tiles turned for the products over the queries
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, qq = l >> 4, x = l & 15;
+    const int b = blockIdx.x * 4 + wv;
+    if (b >= a.B) return;
+    const int Lq = a.Lq, Lk = a.Lk, H = a.H, d = a.d, E = H * d;
+    const int QT = (Lq + 15) >> 4, KT = (Lk + 15) >> 4, CT = (d + 15) >> 4;
+    const float scale = 1.f / sqrtf((float)d);
+    const float* qb = a.q + (int64_t)b * Lq * E;
+    const float* kb = a.k + (int64_t)b * Lk * E;
+    const float* vb = a.v + (int64_t)b * Lk * E;
+    // mask of this entry: lane (qq, x) of tile (km, qn) holds keys 16 km + 4 qq + r of query 16 qn + x
+    bool blocked[2][2][4];
+    bool dead[2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn) {
+        const int qi = 16 * qn + x;
+        bool all_blocked = true;
+#pragma unroll
+        for (int km = 0; km < 2; ++km)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kj = 16 * km + 4 * qq + r;
+                bool bl = false;
+                if (a.mask && qi < Lq && kj < Lk) bl = a.mask[(int64_t)b * a.m_sb + (int64_t)qi * a.m_si + (int64_t)kj * a.m_sj] != 0;
+                blocked[km][qn][r] = bl;
+                if (kj < Lk && !bl) all_blocked = false;
+            }
+        // every key of the row blocked <=> all four quarters say so
+        const int votes = (int)sum_over_q(all_blocked ? 1.f : 0.f);
+        dead[qn] = a.mask != nullptr && votes == 4;
+    }
+    f32x4 wsum[2][2];
+#pragma unroll
+    for (int km = 0; km < 2; ++km)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) wsum[km][qn] = zero4();
+    float* tbuf = &s_t[wv][0][0];
+
+    for (int h = 0; h < H; ++h) {
+        const int hc = h * d;
+        f32x4 P[2][2];
+        if (!BWD) {
+            // ---- scores ---------------------------------------------------------------------------------------------
+            f32x4 S[2][2];
+#pragma unroll
+            for (int km = 0; km < 2; ++km)
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn) S[km][qn] = zero4();
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 ka[2], qv[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int kj = 16 * t + x, qi = 16 * t + x;
+                    ka[t] = row4(kb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
+                    qv[t] = row4(qb + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d) * scale;
+                }
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn)
+                        if (km < KT && qn < QT) S[km][qn] = mfma4(ka[km], qv[qn], S[km][qn]);
+            }
+            // ---- mask + softmax over the keys of each query ---------------------------------------------------------
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = 16 * km + 4 * qq + r;
+                        const bool off = kj >= Lk || (blocked[km][qn][r] && !dead[qn]);
+                        S[km][qn][r] = off ? -INFINITY : S[km][qn][r];
+                        mx = fmaxf(mx, S[km][qn][r]);
+                    }
+                mx = max_over_q(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = S[km][qn][r] == -INFINITY ? 0.f : expf(S[km][qn][r] - mx);
+                        P[km][qn][r] = e;
+                        sum += e;
+                    }
+                sum = sum_over_q(sum);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int km = 0; km < 2; ++km) {
+                    P[km][qn] *= inv;
+                    wsum[km][qn] += P[km][qn];
+                }
+                if (a.p_heads) {
+                    const int qi = 16 * qn + x;
+#pragma unroll
+                    for (int km = 0; km < 2; ++km)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kj = 16 * km + 4 * qq + r;
+                            if (qi < Lq && kj < Lk) a.p_heads[(((int64_t)b * H + h) * Lq + qi) * Lk + kj] = P[km][qn][r];
+                        }
+                }
+            }
+            // ---- weighted sum of the values: O[c][query] = sum_keys V[key][c] P[key][query] ----------------------------
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = 16 * ct + x;
+                f32x4 va[2];
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = 16 * km + 4 * qq + r;
+                        va[km][r] = (c < d && kj < Lk) ? vb[(int64_t)kj * E + hc + c] : 0.f;
+                    }
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn) {
+                    if (qn >= QT) continue;
+                    f32x4 o = zero4();
+#pragma unroll
+                    for (int km = 0; km < 2; ++km)
+                        if (km < KT) o = mfma4(va[km], P[km][qn], o);
+                    const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
+                    if (qi < Lq) {
+                        float* dst = a.out + ((int64_t)b * Lq + qi) * E + hc + c0;
+                        if (c0 + 3 < d) *reinterpret_cast<f32x4*>(dst) = o;
+                        else
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (c0 + r < d) dst[r] = o[r];
+                    }
+                }
+            }
+        } else {
+            // ---- backward of head h ---------------------------------------------------------------------------------
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                const int qi = 16 * qn + x;
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = 16 * km + 4 * qq + r;
+                        P[km][qn][r] = (qi < Lq && kj < Lk) ? a.p_heads[(((int64_t)b * H + h) * Lq + qi) * Lk + kj] : 0.f;
+                    }
+            }
+            const float* gob = a.g_out + (int64_t)b * Lq * E;
+            // dP[key][query] = sum_c V[key][c] dO[query][c]  (+ the head's share of the averaged weights' gradient)
+            f32x4 dP[2][2];
+#pragma unroll
+            for (int km = 0; km < 2; ++km)
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn) dP[km][qn] = zero4();
+            for (int ct = 0; ct < CT; ++ct) {
+                f32x4 va[2], go[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int kj = 16 * t + x, qi = 16 * t + x;
+                    va[t] = row4(vb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
+                    go[t] = row4(gob + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d);
+                }
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn)
+                        if (km < KT && qn < QT) dP[km][qn] = mfma4(va[km], go[qn], dP[km][qn]);
+            }
+            f32x4 dS[2][2];
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+                const int qi = 16 * qn + x;
+                const float kp = dead[qn] ? 0.f : 1.f / (float)H;       // weights returned = mean_h(P) * keep
+                float dot = 0.f;
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = 16 * km + 4 * qq + r;
+                        if (a.g_w && qi < Lq && kj < Lk) dP[km][qn][r] += kp * a.g_w[((int64_t)b * Lq + qi) * Lk + kj];
+                        dot += P[km][qn][r] * dP[km][qn][r];
+                    }
+                dot = sum_over_q(dot);
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dS[km][qn][r] = P[km][qn][r] * (dP[km][qn][r] - dot);
+            }
+            // dQ[query][c] = scale * sum_keys K[key][c] dS[key][query]
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = 16 * ct + x;
+                f32x4 ka[2];
+#pragma unroll
+                for (int km = 0; km < 2; ++km)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kj = 16 * km + 4 * qq + r;
+                        ka[km][r] = (c < d && kj < Lk) ? kb[(int64_t)kj * E + hc + c] : 0.f;
+                    }
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn) {
+                    if (qn >= QT) continue;
+                    f32x4 o = zero4();
+#pragma unroll
+                    for (int km = 0; km < 2; ++km)
+                        if (km < KT) o = mfma4(ka[km], dS[km][qn], o);
+                    const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
+                    if (qi < Lq) {
+                        float* dst = a.g_q + ((int64_t)b * Lq + qi) * E + hc + c0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c0 + r < d) dst[r] = o[r] * scale;
+                    }
+                }
+            }
+            // the products over the QUERIES: P and dS tiles turned (lane (qq, x = key) then holds queries 4 s + qq)
+            wave_sync();
+#pragma unroll
+            for (int km = 0; km < 2; ++km)
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tbuf[((km * 2 + qn) * 256) + (4 * qq + r) * 16 + tpos(x)] = P[km][qn][r];
+                        tbuf[((4 + km * 2 + qn) * 256) + (4 * qq + r) * 16 + tpos(x)] = dS[km][qn][r];
+                    }
+            wave_sync();
+            // dV[key][c] = sum_queries P[key][query] dO[query][c];  dK[key][c] = scale * sum_queries dS[key][query] Q[query][c]
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = 16 * ct + x;
+                f32x4 ga[2], qa[2];       // A[i = c][k-slot (qq, s) <-> query 16 qn + 4 s + qq]
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int qi = 16 * qn + 4 * s + qq;
+                        const bool ok = c < d && qi < Lq;
+                        ga[qn][s] = ok ? gob[(int64_t)qi * E + hc + c] : 0.f;
+                        qa[qn][s] = ok ? qb[(int64_t)qi * E + hc + c] : 0.f;
+                    }
+#pragma unroll
+                for (int km = 0; km < 2; ++km) {
+                    if (km >= KT) continue;
+                    f32x4 dv = zero4(), dk = zero4();
+#pragma unroll
+                    for (int qn = 0; qn < 2; ++qn) {
+                        if (qn >= QT) continue;
+                        const f32x4 pt = *reinterpret_cast<const f32x4*>(tbuf + (km * 2 + qn) * 256 + x * 16 + 4 * qq);
+                        const f32x4 st = *reinterpret_cast<const f32x4*>(tbuf + (4 + km * 2 + qn) * 256 + x * 16 + 4 * qq);
+                        dv = mfma4(ga[qn], pt, dv);
+                        dk = mfma4(qa[qn], st, dk);
+                    }
+                    const int kj = 16 * km + x, c0 = 16 * ct + 4 * qq;
+                    if (kj < Lk) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c0 + r < d) {
+                                a.g_v[((int64_t)b * Lk + kj) * E + hc + c0 + r] = dv[r];
+                                a.g_k[((int64_t)b * Lk + kj) * E + hc + c0 + r] = dk[r] * scale;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (!BWD) {
+        const float invH = 1.f / (float)H;
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn) {
+            const int qi = 16 * qn + x;
+            if (qi >= Lq) continue;
+            const float kp = dead[qn] ? 0.f : 1.f;
+            if (qq == 0) a.keep[(int64_t)b * Lq + qi] = kp;
+#pragma unroll
+            for (int km = 0; km < 2; ++km)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = 16 * km + 4 * qq + r;
+                    if (kj < Lk) a.w_avg[((int64_t)b * Lq + qi) * Lk + kj] = wsum[km][qn][r] * invH * kp;
+                }
+        }
+    }
+}
+
+}  // namespace amh
+}  // namespace asac
+
+using namespace asac;
+using namespace asac::amh;
+
+extern "C" {
+
+int asac_attention_mh_supported(int Lq, int Lk, int heads, int head_dim) {
+    return Lq >= 1 && Lk >= 1 && Lq <= kMaxL && Lk <= kMaxL && heads >= 1 && heads <= 16 && head_dim >= 1 && head_dim <= 64;
+}
+
+int asac_attention_mh_forward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
+                              int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                              float* out, float* weights, float* keep, float* p_heads, void* stream) {
+    if (!q || !k || !v || !out || !weights || !keep || B <= 0 || !asac_attention_mh_supported(Lq, Lk, heads, head_dim))
+        return bad_arg("asac_attention_mh_forward");
+    Args a{};
+    a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
+    a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = weights, a.keep = keep, a.p_heads = p_heads;
+    ASAC_LAUNCH(k_attn_mh<false>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, as_stream(stream), a);
+    return finish_launch("asac_attention_mh_forward");
+}
+
+int asac_attention_mh_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
+                               int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                               const float* p_heads, const float* grad_out, const float* grad_weights, float* grad_q,
+                               float* grad_k, float* grad_v, void* stream) {
+    if (!q || !k || !v || !p_heads || !grad_out || !grad_q || !grad_k || !grad_v || B <= 0 ||
+        !asac_attention_mh_supported(Lq, Lk, heads, head_dim))
+        return bad_arg("asac_attention_mh_backward");
+    Args a{};
+    a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
+    a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim;
+    a.p_heads = const_cast<float*>(p_heads), a.g_out = grad_out, a.g_w = grad_weights, a.g_q = grad_q, a.g_k = grad_k, a.g_v = grad_v;
+    ASAC_LAUNCH(k_attn_mh<true>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, as_stream(stream), a);
+    return finish_launch("asac_attention_mh_backward");
+}
+
+}  // extern "C"

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 58
+ABI_VERSION = 60
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -344,6 +344,14 @@ _SIGNATURES = {
     'asac_polyak': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     'asac_adam_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    'asac_graph_replace_memset_nodes': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'asac_attention_mh_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'asac_attention_mh_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
+    'asac_attention_mh_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_gru_wide_supported': (C.c_int, [C.c_int]),
     'asac_gru_wide_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
@@ -1566,6 +1574,15 @@ def graph_launch(graph_exec: int):
     _check(load().asac_graph_launch(C.c_void_p(int(graph_exec)), _stream()), 'asac_graph_launch')
 
 
+def graph_replace_memset_nodes(graph: int):
+    """Fix-up pass over a captured hipGraph_t (raw pointer value, not yet instantiated): 1-D memset nodes -> kernel nodes
+    (csrc/graph_fix.hip: captured memsets take effect on the first launch only on this ROCm).  -> (replaced, kept)"""
+    rep, kept = C.c_int(0), C.c_int(0)
+    _check(load().asac_graph_replace_memset_nodes(C.c_void_p(int(graph)), C.byref(rep), C.byref(kept)),
+           'asac_graph_replace_memset_nodes')
+    return rep.value, kept.value
+
+
 @_profiled
 def alpha_adam_step(logp, target, slot, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, steps_done,
                     advance_counter=False):
@@ -1703,3 +1720,44 @@ def gru_wide_backward(grad_out, w_hh_t, gates, h_raw, h0, mask, grad_gi, grad_gh
     _check(load().asac_gru_wide_backward(_p(grad_out), grad_out.stride(0), grad_out.stride(1), _p(w_hh_t), _p(gates),
                                          _p(h_raw), _p(h0), 0 if h0 is None else h0.stride(0), pm, ms, B, L, H,
                                          _p(grad_gi), _p(grad_gh), _p(grad_h0), _stream()), 'asac_gru_wide_backward')
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-head attention core (csrc/attn_mh.hip)
+# ------------------------------------------------------------------------------------------------
+def attention_mh_supported(Lq, Lk, heads, head_dim) -> bool:
+    return bool(load().asac_attention_mh_supported(int(Lq), int(Lk), int(heads), int(head_dim)))
+
+
+def _mask3(mask, B):
+    """[1 | B, 1 | Lq, Lk] byte mask -> (pointer, stride_b, stride_q, stride_k) with broadcast strides of 0"""
+    if mask is None:
+        return None, 0, 0, 0
+    assert mask.is_cuda and mask.element_size() == 1 and mask.dim() == 3
+    return (_p(mask), 0 if mask.shape[0] == 1 and B > 1 else mask.stride(0), 0 if mask.shape[1] == 1 else mask.stride(1),
+            mask.stride(2))
+
+
+@_profiled
+def attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads):
+    global _last_work
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    _last_work = 4.0 * B * Lq * Lk * E
+    _dense_f32(q, k, v, out, weights, keep, p_heads)
+    pm, sb, si, sj = _mask3(mask, B)
+    _check(load().asac_attention_mh_forward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(out),
+                                            _p(weights), _p(keep), _p(p_heads), _stream()), 'asac_attention_mh_forward')
+
+
+@_profiled
+def attention_mh_backward(q, k, v, mask, heads, p_heads, grad_out, grad_weights, grad_q, grad_k, grad_v):
+    global _last_work
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    _last_work = 10.0 * B * Lq * Lk * E
+    _dense_f32(q, k, v, p_heads, grad_out, grad_weights, grad_q, grad_k, grad_v)
+    pm, sb, si, sj = _mask3(mask, B)
+    _check(load().asac_attention_mh_backward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(p_heads),
+                                             _p(grad_out), _p(grad_weights), _p(grad_q), _p(grad_k), _p(grad_v), _stream()),
+           'asac_attention_mh_backward')

@@ -87,6 +87,14 @@ CONFIGS['cfg5_without_prediction'] = dict(
 CONFIGS['cfg3_h64'] = dict(
     CONFIGS['cfg3'], plugin='nn_rnn_h64', hidden=(1, 64),
     desc='cfg3_h64: GRU(64)x1 rep (the reference environments\' width), burn_in_step=40 n_step=40 (window 81), PER capacity 524288')
+# the attention representation at the reference environments' width (64 channels, 8 heads, 2 layers:
+# envs/gym/toy_queue/nn_attn.py:28-45) on the TEST observations, windows of 9 as configs[4]
+CONFIGS['cfg_attn_h64'] = dict(
+    obs_names=['vector'], obs_shapes=[(6,)], d_action_sizes=[], c_action_size=2, plugin='nn_attn_h64', n_step=3,
+    burn_in_step=5, batch_size=1024, ensemble_q_num=2, ensemble_q_sample=2, capacity=65536, fill=2 ** 15, episode_len=100,
+    hidden=(64,), seq_encoder='ATTN',
+    desc='cfg_attn_h64: EpisodeMultiheadAttention(64, 2 layers, 8 heads) rep (the reference environments\' width), b=5 n=3, '
+         'batch 1024, PER capacity 65536')
 CFG = dict(CONFIGS['cfg2'])
 
 
@@ -305,7 +313,7 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', 'cfg5_without_prediction'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', 'cfg5_without_prediction', 'cfg_attn_h64'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess

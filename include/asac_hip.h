@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 58
+#define ASAC_ABI_VERSION 60
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -864,6 +864,28 @@ int asac_obs_decoder_backward(const float* state, int64_t state_stride, int64_t 
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-head attention core for short windows on f32 MFMA (csrc/attn_mh.hip): the scores / mask / softmax / weighted-sum
+ * part of `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333) for num_heads >= 1 heads of head_dim <= 64
+ * channels and windows of <= 32 positions — the widths of the reference's environments (`EpisodeMultiheadAttention(64, …)`
+ * with 2 - 8 heads: envs/square/obstacle/nn_attn.py:16, envs/gym/toy_queue/nn_attn.py:28-45).  The q / k / v / output
+ * projections around it stay Linears (library GEMMs) on the host side.
+ *   q [B][Lq][E], k / v [B][Lk][E], E = heads * head_dim, head h = channels [h * head_dim, (h + 1) * head_dim);
+ *   mask as asac_attention_forward (shared by the heads).  out [B][Lq][E] (heads concatenated);  weights [B][Lq][Lk] = the
+ *   mean over the heads of softmax(s) * keep;  keep [B][Lq] = 1 - dead;  p_heads [B][heads][Lq][Lk] (or NULL): every head's
+ *   softmax, saved for the backward.
+ * Backward: grad_out [B][Lq][E], grad_weights [B][Lq][Lk] (w.r.t. the returned weights) or NULL -> grad_q / grad_k / grad_v.
+ * One wave per batch entry, heads in order: deterministic.
+ * ------------------------------------------------------------------------------------------- */
+int asac_attention_mh_supported(int Lq, int Lk, int heads, int head_dim);
+int asac_attention_mh_forward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
+                              int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                              float* out, float* weights, float* keep, float* p_heads, void* stream);
+int asac_attention_mh_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
+                               int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                               const float* p_heads, const float* grad_out, const float* grad_weights, float* grad_q,
+                               float* grad_k, float* grad_v, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Attention core for short windows: the scores / mask / softmax / weighted-sum part of
  * `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333) under the episode attention of
  * `get_l_states` (sac_base.py:1117-1146).  One head per batch entry (callers fold heads into the batch).
@@ -974,6 +996,13 @@ int asac_step_prologue_sample(float* target, const float* source, int64_t n_poly
 
 /* hipGraphLaunch of an instantiated graph (the captured train step) on `stream`. */
 int asac_graph_launch(void* graph_exec, void* stream);
+
+/* Fix-up pass over the captured train step (a hipGraph_t, before it is instantiated): every 1-D memset node is replaced by a
+ * kernel node with the same edges (csrc/graph_fix.hip).  On ROCm 7.2 / gfx950 a captured hipMemsetAsync of >= 16 bytes takes
+ * effect on the first launch of the instantiated graph only; ATen's split reductions zero their semaphores with one, so a
+ * captured bias gradient (`x.sum(0)` of an nn.Linear backward inside `SAC_Base._train_rep_q`, sac_base.py:1916-2010) is wrong
+ * from the second replay on.  n_replaced / n_kept (2-D memsets, left alone) may be NULL. */
+int asac_graph_replace_memset_nodes(void* graph, int* n_replaced, int* n_kept);
 
 /* Temperature step in one launch: dL/dlog_alpha = mean_b(-logp_b) - target into grad[slot], then the
  * same Adam update as asac_adam_step over the n temperature parameters (param / grad / moments point

@@ -13,6 +13,9 @@ step's sampling is compared from identical replay contents, its results within t
 tolerances of tests/test_sac_step_gpu.py.  This covers what the small goldens cannot: the multi-workgroup return
 kernel, the fused sampler at 256..1024 strata over 19 tree levels, convolution group tails at 4 608 and 9 216
 frames, the GRU at 256 x 81."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -23,7 +26,7 @@ import bench  # noqa: E402
 from oracle import sac_ref  # noqa: E402
 from tests import parity_utils as pu  # noqa: E402
 
-FILL = {'cfg1': 2 ** 15, 'cfg2': 2 ** 15, 'cfg3': 2 ** 14, 'cfg3_h64': 2 ** 13, 'cfg4': 4096, 'cfg5': 4096}
+FILL = {'cfg1': 2 ** 15, 'cfg2': 2 ** 15, 'cfg3': 2 ** 14, 'cfg3_h64': 2 ** 13, 'cfg4': 4096, 'cfg5': 4096, 'cfg_attn_h64': 4096}
 # observable -> (rtol, atol), set from the observed errors (profiles/r03_parity_errors.json; <= 4x the worst seen)
 TOL = {'is_weights': (2e-6, 0.), 'loss_q': (2e-4, 0.), 'loss_curiosity': (2e-4, 0.), 'td_error': (2e-4, 5e-5),
        'tree': (2e-4, 1e-5), 'mu_prob': (5e-3, 1e-6), 'hidden': (2e-4, 5e-5), 'log_c_alpha': (2e-4, 0.)}
@@ -49,7 +52,7 @@ def _episode(rng, cfg, T):
                 ep_pre_seq_hidden_states=rng.standard_normal((1, T, *cfg['hidden'])).astype(np.float32))
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5'])
+@pytest.mark.parametrize('name', ['cfg1', 'cfg2', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', 'cfg_attn_h64'])
 def test_baseline_config_full_size_vs_oracle(name):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
@@ -64,7 +67,8 @@ def test_baseline_config_full_size_vs_oracle(name):
     agent = SAC_Base(cfg['obs_names'], cfg['obs_shapes'], [], A, None, plugin, device='cuda:0',
                      seq_encoder=SEQ_ENCODER[cfg['seq_encoder']] if cfg['seq_encoder'] else None,
                      curiosity=CURIOSITY[cfg['curiosity']] if cfg.get('curiosity') else None,
-                     hip_config={'use_graph': True, 'graph_warmup': 1}, **common)
+                     hip_config={'use_graph': not os.environ.get('ASAC_TEST_EAGER'), 'graph_warmup': 1,
+                                 **json.loads(os.environ.get('ASAC_TEST_HIP_CONFIG', '{}'))}, **common)
     oracle = sac_ref.SacRef(cfg['obs_names'], cfg['obs_shapes'], [], A, plugin, seq_encoder=cfg['seq_encoder'],
                             curiosity=cfg.get('curiosity'), **common)
     pu.copy_weights_to_oracle(agent, oracle)
@@ -100,7 +104,7 @@ def test_baseline_config_full_size_vs_oracle(name):
     for step in range(3):
         agent.train()
         torch.cuda.synchronize()
-        assert (agent._graph is not None) == (step >= 1), 'step 0 eager, step 1 captures and replays'
+        assert os.environ.get('ASAC_TEST_EAGER') or (agent._graph is not None) == (step >= 1), 'step 0 eager, step 1 captures and replays'
         # the step's draws, read back from its static buffers
         u = [rb._u.cpu().numpy()]
         eps = [b.cpu().numpy().copy() for b in (agent._eps_y, agent._eps_pi, agent._eps_alpha, agent._eps_td)]
@@ -125,9 +129,32 @@ def test_baseline_config_full_size_vs_oracle(name):
                 for (k, v), vo in zip(getattr(agent, mname).state_dict().items(), getattr(oracle, mname).state_dict().values()):
                     pu.check(f'full_size/{name}/prediction_weights', v, vo, rtol=0., atol=2.2 * 3e-4 * (step + 1))
             assert out['rpm'] is not None and np.isfinite(out['rpm']['losses'].numpy()).all()
+        if trained_rep:     # diagnostics: where the two learners' weights stand after this step's Adam updates (units of lr)
+            mods = {'model_rep': agent.model_rep, 'model_policy': agent.model_policy, 'model_target_rep': agent.model_target_rep,
+                    **{f'model_q_{i}': q for i, q in enumerate(agent.model_q_list)},
+                    **{f'model_target_q_{i}': q for i, q in enumerate(agent.model_target_q_list)}}
+            omods = oracle.named_modules()
+            worst = []
+            for mn, mod in mods.items():
+                for (k, v), vo in zip(mod.state_dict().items(), omods[mn].state_dict().values()):
+                    dv = (v.detach().cpu() - vo).abs()
+                    worst.append((float(dv.max()) / 3e-4, int((dv > 1.5e-4).sum()), dv.numel(), f'{mn}.{k}'))
+            worst.sort(reverse=True)
+            print(f'{name} step {step}: weights vs oracle, max|diff|/lr (entries off by > lr/2 of n): ' +
+                  '; '.join(f'{w[3]} {w[0]:.2f} ({w[1]}/{w[2]})' for w in worst[:40] if w[0] > 0.02))
         if cfg.get('use_priority', True):
             _t, _o = agent._td_error.cpu().numpy(), out['td_error'].reshape(-1)
             print(f'{name} step {step}: td max|diff| {np.abs(_t - _o).max():.3e} of {np.abs(_o).max():.3f}; log_alpha {agent.log_c_alpha.item():.6f} / {oracle.log_c_alpha.item():.6f}')
+            if os.environ.get('ASAC_TEST_DUMP'):
+                os.makedirs('gpurun_out', exist_ok=True)
+                np.savez(f'gpurun_out/td_{name}_{step}_{os.environ["ASAC_TEST_DUMP"]}.npz', t=_t, o=_o, ids=out['ids'],
+                         **{f'w_{mn}.{k}': v.detach().cpu().numpy() for mn, mod in mods.items() for k, v in mod.state_dict().items()},
+                         hid=rb._columns['pre_seq_hidden_state'].cpu().numpy(), mu=rb._columns['mu_prob'].cpu().numpy(),
+                         u=u[0], **{f'eps{i}': e for i, e in enumerate(eps)}, **{f'perm{i}': e for i, e in enumerate(perm)})
+            if trained_rep:
+                _bad = np.argsort(-np.abs(_t - _o))[:8]
+                print(f'{name} step {step}: worst td rows: ' + ', '.join(
+                    f'id%T {int(out["ids"][i]) % T} {_t[i]:.4f}/{_o[i]:.4f}' for i in _bad))
             chk('td_error', agent._td_error.cpu().numpy(), out['td_error'].reshape(-1))
         else:       # the tree is frozen: sampled, never updated (reference sac_base.py:2571-2584)
             assert torch.equal(rb._tree, tree_before)

@@ -1,0 +1,154 @@
+"""GPU: the multi-head attention core on MFMA (`asac_attention_mh_forward/backward`, csrc/attn_mh.hip) inside
+`MultiheadAttention` / `EpisodeMultiheadAttention` against the same modules' PyTorch path on the CPU (reference
+nn_models/layers/seq_layers.py:239-333): outputs, head-averaged weights and the gradients of inputs and parameters, at the
+widths of the reference's environments (embed 64 with 2 - 8 heads) and at ragged ones, with causal / per-batch / padding masks,
+fully masked ("dead") rows and rotary position encoding in front of the core."""
+import copy
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask(kind, B, Lq, Lk, gen):
+    if kind == 'none':
+        return None, None
+    if kind == 'causal2d':
+        return torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), diagonal=1 + Lk - Lq), None
+    m = torch.rand(B, Lq, Lk, generator=gen) < 0.4
+    m[0, 0] = True                       # a dead row
+    m[1] = True                          # a dead batch entry
+    kpm = torch.rand(B, Lk, generator=gen) < 0.3
+    if kind == 'padding':
+        return None, kpm
+    return m, kpm
+
+
+@pytest.mark.parametrize('B,Lq,Lk,E,H,kind,pe', [
+    (256, 9, 9, 64, 8, 'batch', None),         # EpisodeMultiheadAttention(64, num_heads 8) over a window of 9
+    (64, 9, 18, 64, 2, 'batch', None),         # second block: keys = previous states ++ outputs
+    (33, 16, 16, 64, 4, 'causal2d', 'rope'),
+    (5, 1, 32, 64, 1, 'padding', None),        # one head of 64 channels (too wide for csrc/attn.hip)
+    (7, 32, 32, 128, 2, 'none', None),         # head_dim 64, both tile pairs
+    (3, 7, 5, 24, 2, 'batch', None),           # ragged: head_dim 12
+    (4, 20, 27, 40, 8, 'batch', 'rope2'),      # ragged tiles, head_dim 5
+])
+def test_multihead_core_matches_module_path(B, Lq, Lk, E, H, kind, pe):
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    import algorithm.nn_models as m
+    from algorithm.nn_models.layers.seq_layers import POSITIONAL_ENCODING
+    pe = {None: None, 'rope': POSITIONAL_ENCODING.ROPE, 'rope2': POSITIONAL_ENCODING.ROPE2}[pe]
+    torch.manual_seed(0)
+    ref = m.MultiheadAttention(E, H, pe=pe, out_dense_depth=1)
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(1)
+    q, k, v = (torch.randn(B, L, E, generator=gen) for L in (Lq, Lk, Lk))
+    mask, kpm = _mask(kind, B, Lq, Lk, gen)
+    g_out, g_w = torch.randn(B, Lq, E, generator=gen), torch.randn(B, Lq, Lk, generator=gen) * 0.2
+
+    def run(layer, device):
+        qd, kd, vd = (t.clone().to(device).requires_grad_(True) for t in (q, k, v))
+        out, w = layer(qd, kd, vd, key_padding_mask=None if kpm is None else kpm.to(device),
+                       attn_mask=None if mask is None else mask.to(device))
+        ((out * g_out.to(device)).sum() + (w * g_w.to(device)).sum()).backward()
+        return [t.detach().cpu().numpy() for t in (out, w, qd.grad, kd.grad, vd.grad, *(p.grad for p in layer.parameters()))]
+
+    want = run(ref, 'cpu')
+    with native.LaunchProfiler() as prof:
+        got = run(dev, 'cuda')
+    seen = prof.summary()
+    assert seen['asac_attention_mh_forward']['calls'] == 1 and seen['asac_attention_mh_backward']['calls'] == 1
+    for n_, (a, b) in enumerate(zip(got, want)):
+        assert np.isfinite(a).all()
+        atol = 3e-5 if n_ < 5 else 2e-7 * B * Lq * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
+        np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')
+
+
+def test_only_the_weights_or_only_the_output_are_used():
+    """either result of the module may stay unused (its gradient is then None): no NaN, same gradients as the module path"""
+    import asac_amd  # noqa: F401
+    import algorithm.nn_models as m
+    torch.manual_seed(0)
+    ref = m.MultiheadAttention(64, 8)
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(10, 9, 64, generator=gen)
+    mask, kpm = _mask('batch', 10, 9, 9, gen)
+    for use in (0, 1):
+        xc, xg = x.clone().requires_grad_(True), x.clone().cuda().requires_grad_(True)
+        ref(xc, xc, xc, attn_mask=mask, key_padding_mask=kpm)[use].square().sum().backward()
+        dev(xg, xg, xg, attn_mask=mask.cuda(), key_padding_mask=kpm.cuda())[use].square().sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=3e-4, atol=3e-5)
+    with torch.no_grad():
+        o_c, w_c = ref(x, x, x, attn_mask=mask)
+        o_g, w_g = dev(x.cuda(), x.cuda(), x.cuda(), attn_mask=mask.cuda())
+    np.testing.assert_allclose(o_g.cpu().numpy(), o_c.numpy(), rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(w_g.cpu().numpy(), w_c.numpy(), rtol=3e-4, atol=3e-5)
+
+
+def test_episode_attention_of_the_reference_environments_and_its_speed():
+    """`EpisodeMultiheadAttention(64, num_layers 2, num_heads 8)` (envs/gym/toy_queue/nn_attn.py:28-45) over windows of 9:
+    GPU against CPU, then the device time of forward + backward with and without the MFMA core."""
+    import asac_amd  # noqa: F401
+    import algorithm.nn_models as m
+    from algorithm.nn_models.layers import seq_layers
+    torch.manual_seed(2)
+    ref = m.EpisodeMultiheadAttention(64, num_layers=2, num_heads=8)
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(3)
+    B, L = 48, 9
+    key = torch.randn(B, L, 64, generator=gen)
+    hidden = torch.randn(B, L, ref.output_hidden_state_dim, generator=gen)
+    index = torch.arange(L).repeat(B, 1) + torch.randint(0, 5, (B, 1), generator=gen)
+    pad = torch.arange(L).unsqueeze(0) < torch.randint(0, 4, (B, 1), generator=gen)
+    g_o = torch.randn(B, L, 64, generator=gen)
+    kc = key.clone().requires_grad_(True)
+    out_c, hn_c, w_c = ref(kc, seq_q_len=L, hidden_state=hidden[:, :1], is_prev_hidden_state=True, key_index=index,
+                           key_padding_mask=pad)
+    ((out_c * g_o).sum() + hn_c.sum()).backward()
+    kg = key.clone().cuda().requires_grad_(True)
+    out_g, hn_g, w_g = dev(kg, seq_q_len=L, hidden_state=hidden[:, :1].cuda(), is_prev_hidden_state=True,
+                           key_index=index.cuda(), key_padding_mask=pad.cuda())
+    ((out_g * g_o.cuda()).sum() + hn_g.sum()).backward()
+    np.testing.assert_allclose(kg.grad.cpu().numpy(), kc.grad.numpy(), rtol=5e-4, atol=5e-5)
+    for pr, pd in zip(ref.parameters(), dev.parameters()):
+        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(), rtol=5e-4, atol=2e-4)
+    np.testing.assert_allclose(out_g.detach().cpu().numpy(), out_c.detach().numpy(), rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(hn_g.detach().cpu().numpy(), hn_c.detach().numpy(), rtol=3e-4, atol=3e-5)
+    for a, b in zip(w_g, w_c):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=3e-4, atol=3e-5)
+
+    # speed at the learner's batch (1024 windows of 9)
+    B = 1024
+    key = torch.randn(B, L, 64, device='cuda')
+    index = torch.arange(L, device='cuda').repeat(B, 1)
+    pad = torch.zeros(B, L, dtype=torch.bool, device='cuda')
+    h0 = torch.zeros(B, 1, ref.output_hidden_state_dim, device='cuda')
+
+    def step():
+        kk = key.clone().requires_grad_(True)
+        o, hn, _ = dev(kk, seq_q_len=L, hidden_state=h0, is_prev_hidden_state=True, key_index=index, key_padding_mask=pad)
+        (o.sum() + hn.sum()).backward()
+
+    def timed():
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 30 * 1e3
+
+    fused = timed()
+    seq_layers.FUSED_MULTIHEAD = False
+    try:
+        generic = timed()
+    finally:
+        seq_layers.FUSED_MULTIHEAD = True
+    print(f'\nEpisodeMultiheadAttention(64, 2 layers, 8 heads), 1024 x 9, forward + backward (eager, wall): MFMA core '
+          f'{fused:.3f} ms, module path {generic:.3f} ms')
