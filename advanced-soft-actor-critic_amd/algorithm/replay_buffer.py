@@ -116,6 +116,7 @@ class PrioritizedReplayBuffer:
         self.min_ratio_reducer = None  # callable(f32[1] tensor) -> in-place MIN over ranks (parallel.py)
         self.sharded = None            # parallel.ShardedParityReplay: sampling / write-backs over all ranks' shards
         self.lookahead, self.next_valid, self.parity, self._alt = False, False, 0, None
+        self._gather_sidecar = None
         self._closed = False
 
     # ------------------------------------------------------------------------------------------
@@ -297,7 +298,7 @@ class PrioritizedReplayBuffer:
     # offers that schedule deterministically: two static batch sets; `sample_next_into_static` draws into the one the
     # learner is not training on, `swap_sets` exchanges their roles between two steps.
     _SET_ATTRS = ('_u', '_leaf', '_p', '_ids', '_w', '_min_p', '_batch', '_gather_keys', '_gather_refs',
-                  'joint_pre_action', 'derived')
+                  'joint_pre_action', 'derived', '_gather_sidecar')
 
     def enable_lookahead(self) -> None:
         assert self.sharded is None and self.min_ratio_reducer is None, 'one batch in flight: single-shard replay only'
@@ -314,10 +315,31 @@ class PrioritizedReplayBuffer:
             self._batch, specs = self._window_specs(self.batch_size, joined=True)   # (sets joint_pre_action / derived)
             self._gather_keys = native.make_gather_keys(specs)
             self._gather_refs = specs
+            # each set's window gather as a sidecar job (its launch description in device memory: a blocking copy, so here)
+            self._gather_sidecar = self._make_gather_sidecar()
         self._alt = {a: getattr(self, a) for a in self._SET_ATTRS}
         for a, v in first.items():
             setattr(self, a, v)
+        with torch.cuda.device(self.device):
+            self._gather_sidecar = self._make_gather_sidecar()
         self.next_valid = False
+
+    def _make_gather_sidecar(self):
+        return native.sidecar_window_gather(self._gather_keys, self._ids, self.batch_size, self.prev_n, self.post_n,
+                                            self.capacity, self._index_ring())
+
+    def next_gather_sidecar(self):
+        """the NEXT set's window gather (its ids already drawn by the step's prologue) as a sidecar job of a launch of
+        the current step; `gather_next_now` if no launch took it"""
+        self.next_valid = True
+        return self._alt['_gather_sidecar']
+
+    def gather_next_now(self) -> None:
+        self.swap_sets()
+        try:
+            self.sample_into_static(sampled=True)
+        finally:
+            self.swap_sets()
 
     def swap_sets(self) -> None:
         """the batch drawn last becomes the one `_ids` / `_batch` / ... name (host bookkeeping only)"""
@@ -330,11 +352,11 @@ class PrioritizedReplayBuffer:
     def next_uniforms(self) -> torch.Tensor:
         return self._alt['_u']
 
-    def sample_next_into_static(self) -> None:
+    def sample_next_into_static(self, sampled: bool = False) -> None:
         """`sample_into_static` into the set the learner is NOT training on (device work only: capturable)"""
         self.swap_sets()
         try:
-            self.sample_into_static()
+            self.sample_into_static(sampled=sampled)
         finally:
             self.swap_sets()
         self.next_valid = True

@@ -261,6 +261,8 @@ class SAC_Base(AuxHeadsMixin):
         self._lookahead = int(hip_config.get('lookahead', 0))
         assert self._lookahead in (0, 1), 'hip_config lookahead: 0 (synchronous sampling) or 1 (one batch in flight)'
         self._la_branch = bool(hip_config.get('lookahead_branch', False))   # a graph branch for the draw: measured slower
+        self._la_gather_sidecar = bool(hip_config.get('lookahead_gather_sidecar', True)) and self._use_sidecars
+        self._la_gather = None
         self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
         self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
@@ -1139,7 +1141,7 @@ class SAC_Base(AuxHeadsMixin):
             if policy_sample:
                 self.noise.normal_(self._eps_pi)
                 self._pi_sampled = True
-            native.policy_sample_q_forward(fused, [job_tq])
+            native.policy_sample_q_forward(fused, [job_tq], sidecars=self._take_la_gather())
             ls = ls[0].view(B, T, 2 * A)
             # the return target is formed by the Q-loss backward's own workgroups where that form applies: its
             # arguments are assembled as always, its launch is not issued
@@ -1718,6 +1720,14 @@ class SAC_Base(AuxHeadsMixin):
         if self._la_pending:
             torch.cuda.current_stream().wait_stream(self._la_stream)
             self._la_pending = False
+        if self._la_gather is not None:      # no launch hosted the next batch's gather: on its own, before any write-back
+            self._la_gather = None
+            self.replay_buffer.gather_next_now()
+
+    def _take_la_gather(self):
+        """-> the pending gather of the NEXT batch as a sidecar list for a launch that reads nothing of it, or None"""
+        sc, self._la_gather = self._la_gather, None
+        return None if sc is None else [sc]
 
     def _step_sample(self):
         """-> the step's window views (`_Window`): [B, L] tensors are `bnx_*`, their first L - 1 rows `bn_*`"""
@@ -1732,8 +1742,18 @@ class SAC_Base(AuxHeadsMixin):
             # the batch this step trains on was drawn during the previous step (`train` swapped the sets); the NEXT one
             # is drawn now, from the tree and the rows as the previous step left them, beside this step's launches: a
             # second stream (a branch of the captured graph) that joins before this step's first write to the replay
-            self.noise.begin_step(self._opt_steps, rb.next_uniforms() if rb.uniform_source is self.noise else None,
-                                  self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+            sampled = False
+            if self._use_sidecars and not self._la_branch:
+                # the prologue launch hosts the NEXT batch's tree walk (its sampler workgroup), as in the plain schedule
+                rb.swap_sets()
+                try:
+                    sampled = self.noise.begin_step_with_sample(self._opt_steps, rb, self._eps_all, self._subsets_all,
+                                                                self.ensemble_q_num, polyak=polyak, zero=zero)
+                finally:
+                    rb.swap_sets()
+            if not sampled:
+                self.noise.begin_step(self._opt_steps, rb.next_uniforms() if rb.uniform_source is self.noise else None,
+                                      self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
             if self._la_branch:
                 if self._la_stream is None:
                     self._la_stream = torch.cuda.Stream(device=self.device)
@@ -1742,7 +1762,12 @@ class SAC_Base(AuxHeadsMixin):
                     rb.sample_next_into_static()
                 self._la_pending = True
             else:
-                rb.sample_next_into_static()      # same launches, in line (no graph branch)
+                if sampled and self._la_gather_sidecar:
+                    # ... and its window gather rides as extra workgroups of the step's first policy / critic launch
+                    # (`_take_la_gather`; `_join_lookahead` runs it on its own if no launch took it)
+                    self._la_gather = rb.next_gather_sidecar()
+                else:
+                    rb.sample_next_into_static(sampled=sampled)      # same launches, in line (no graph branch)
         else:
             sampled = self._use_sidecars and self.noise.begin_step_with_sample(
                 self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)

@@ -9,6 +9,7 @@
 //                   of <= 32 bytes, one wave per row above
 #pragma once
 #include "asac_common.h"
+#include "asac_gather.h"
 
 #include <cmath>
 
@@ -218,6 +219,7 @@ struct SidecarDev {
     int32_t kind, first_block;        // first workgroup of this job among the launch's sidecar workgroups
     AlphaAdamArgs alpha;
     ScatterArgs scatter;
+    const void* gather;               // WINDOW_GATHER: a GatherLaunch<ASAC_MAX_GATHER_KEYS> in device memory
 };
 // (kernel arguments are copied per launch: hosts that usually carry no or one sidecar have variants taking a shorter
 // list — SidecarsT<1> is 250 bytes, the full list 1 KB)
@@ -264,6 +266,10 @@ inline int sidecars_prepare(const asac_sidecar_t* jobs, int n, SidecarsDev& out)
             const int total = h.batch * h.count;
             const int per = h.kind == ASAC_SIDECAR_SCATTER_ELECT ? kSidecarRowsPerWg : scatter_write_rows_per_wg(h.row_bytes);
             out.blocks += (total + per - 1) / per;
+        } else if (h.kind == ASAC_SIDECAR_WINDOW_GATHER) {
+            if (!h.gather_plan || h.gather_blocks <= 0) return 1;
+            d.gather = h.gather_plan;
+            out.blocks += h.gather_blocks;
         } else {
             return 1;
         }
@@ -273,7 +279,8 @@ inline int sidecars_prepare(const asac_sidecar_t* jobs, int n, SidecarsDev& out)
 }
 
 // device: workgroup `block` (0-based among the sidecar workgroups) of a host kernel with >= 256 threads
-template <int NSC>
+// (GATHER: hosts that accept ASAC_SIDECAR_WINDOW_GATHER jobs — the others do not carry the gather's code)
+template <int NSC, bool GATHER = false>
 __device__ __forceinline__ void sidecar_run(const SidecarsT<NSC>& sc, int block, float* lds256) {
     int k = 0;
 #pragma unroll
@@ -283,6 +290,10 @@ __device__ __forceinline__ void sidecar_run(const SidecarsT<NSC>& sc, int block,
     const int local = block - job.first_block;
     if (job.kind == ASAC_SIDECAR_ALPHA_ADAM) {
         alpha_adam_block(job.alpha, lds256);
+    } else if (GATHER && job.kind == ASAC_SIDECAR_WINDOW_GATHER) {
+        if (threadIdx.x < kGatherBlock)
+            gather_block<ASAC_MAX_GATHER_KEYS, 1>(*static_cast<const GatherLaunch<ASAC_MAX_GATHER_KEYS>*>(job.gather),
+                                                  (unsigned)local);
     } else if (threadIdx.x < 256) {
         if (job.kind == ASAC_SIDECAR_SCATTER_ELECT) {
             scatter_elect_row(job.scatter, local * kSidecarRowsPerWg + (int)threadIdx.x);

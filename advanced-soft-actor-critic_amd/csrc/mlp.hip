@@ -1940,7 +1940,7 @@ __global__ __launch_bounds__(kPiQThreads) void k_pi_sample_q(const PiQLaunch m_b
     }
     const int xb = blk - fused_blocks;
     if (xb >= m.x_blocks) {
-        sidecar_run(sc, xb - m.x_blocks, reinterpret_cast<float*>(smem_raw));
+        sidecar_run<NSC, true>(sc, xb - m.x_blocks, reinterpret_cast<float*>(smem_raw));
         return;
     }
     int k = 0;

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 60
+ABI_VERSION = 61
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -107,10 +107,11 @@ class Sidecar(C.Structure):
                 ('ring', C.c_void_p), ('row_bytes', C.c_int32), ('capacity', C.c_int32), ('ids', C.c_void_p),
                 ('batch', C.c_int32), ('first_off', C.c_int32), ('count', C.c_int32), ('slot_ids', C.c_void_p),
                 ('padding_mask', C.c_void_p), ('mask_sample_stride', C.c_int32), ('rows', C.c_void_p),
-                ('rows_sample_stride_bytes', C.c_int64), ('rows_row_stride_bytes', C.c_int64), ('winner', C.c_void_p)]
+                ('rows_sample_stride_bytes', C.c_int64), ('rows_row_stride_bytes', C.c_int64), ('winner', C.c_void_p),
+                ('gather_plan', C.c_void_p), ('gather_blocks', C.c_int32)]
 
 
-SIDECAR_ALPHA_ADAM, SIDECAR_SCATTER_ELECT, SIDECAR_SCATTER_WRITE, MAX_SIDECARS = 1, 2, 3, 4
+SIDECAR_ALPHA_ADAM, SIDECAR_SCATTER_ELECT, SIDECAR_SCATTER_WRITE, SIDECAR_WINDOW_GATHER, MAX_SIDECARS = 1, 2, 3, 4, 4
 
 
 class SquashJob(C.Structure):
@@ -173,6 +174,9 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_void_p]),
     'asac_window_gather_pad': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_window_gather_plan_bytes': (C.c_int64, []),
+    'asac_window_gather_plan': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     'asac_sumtree_descend': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'asac_gather_rows': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -568,6 +572,19 @@ def window_gather_pad(keys, ids, batch, prev_n, post_n, capacity, index_ring):
     """keys: ctypes array of GatherKey (build once with `make_gather_keys`)."""
     _check(load().asac_window_gather_pad(keys, len(keys), _p(ids), batch, prev_n, post_n, capacity,
                                          _p(index_ring), _stream()), 'asac_window_gather_pad')
+
+
+def sidecar_window_gather(keys, ids, batch, prev_n, post_n, capacity, index_ring) -> Sidecar:
+    """`window_gather_pad` as a sidecar job (hosted by `policy_sample_q_forward`): the launch description goes to device
+    memory once (a blocking copy: call at build time, not inside a capture); the job keeps it alive through `_keep`."""
+    import torch
+    plan = torch.empty(int(load().asac_window_gather_plan_bytes()), dtype=torch.uint8, device=ids.device)
+    blocks = C.c_int(0)
+    _check(load().asac_window_gather_plan(keys, len(keys), _p(ids), batch, prev_n, post_n, capacity, _p(index_ring), _p(plan),
+                                          C.byref(blocks)), 'asac_window_gather_plan')
+    sc = Sidecar(kind=SIDECAR_WINDOW_GATHER, gather_plan=_p(plan), gather_blocks=blocks.value)
+    sc._keep = (plan, keys, ids, index_ring)
+    return sc
 
 
 @_profiled

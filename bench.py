@@ -446,6 +446,7 @@ def main():
         sync_all()
         dt_runs = max_over_ranks(time.perf_counter() - t1)
     graph_used = agent._graph is not None
+    graph_memsets = getattr(agent, '_graph_memsets', None)
     agent.replay_buffer.check_health()
 
     # ---- per-kernel HIP-event timing of the same step, eager, on the launch stream -------------
@@ -588,6 +589,7 @@ def main():
                        'parallelism': f'dp{world}' if world > 1 else 'single',
                        'ranks': world, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
                        'hipgraph': bool(graph_used),
+                       'hipgraph_memset_nodes_replaced': None if graph_memsets is None else graph_memsets[0],
                        'steps_per_graph_launch': 1},
             'roofline': roofline, 'roofline_hbm': roofline_hbm, 'sweep': sweep, 'configs': configs,
             'kernels': kernels, 'cpu_baseline': cpu,

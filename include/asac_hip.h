@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 60
+#define ASAC_ABI_VERSION 61
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -195,6 +195,14 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
  * ASAC_CVT_NONE), any ids, no residency check, ONE launch for all keys — the reference's
  * `DataStorage.get(ids)` behind `PrioritizedReplayBuffer.get_storage_data` (replay_buffer.py:64-75, 401-406), which
  * the option-critic variant calls per key-transition hop (oc/option_selector_base.py:2205, 2223). */
+/* The same gather as a PLAN in device memory (asac_window_gather_plan_bytes() bytes at plan_dev, written with a blocking
+ * copy: build time, not step time) for an ASAC_SIDECAR_WINDOW_GATHER job: the windows of the batch the lookahead schedule
+ * (`hip_config['lookahead']`) draws one step ahead are gathered by extra workgroups of a launch of the current step
+ * (replay_buffer.py:377-396 `sample`'s `get_storage_data` part).  blocks_out: the workgroups the job needs. */
+int64_t asac_window_gather_plan_bytes(void);
+int asac_window_gather_plan(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int batch, int prev_n,
+                            int post_n, int capacity, const int32_t* index_ring, void* plan_dev, int* blocks_out);
+
 int asac_gather_rows(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int n_rows, int capacity,
                      void* stream);
 
@@ -292,10 +300,13 @@ int asac_squash_sample_bwd(const float* loc, const float* scale, int64_t ls_row_
  * not touch what the host launch itself reads or writes.  Fields as the arguments of the stand-alone entry points:
  *   ASAC_SIDECAR_ALPHA_ADAM      asac_alpha_adam_step (reference sac_base.py:1913-1949)
  *   ASAC_SIDECAR_SCATTER_ELECT   pass 1 of asac_scatter_rows_if_id_match (replay_buffer.py:429-434)
- *   ASAC_SIDECAR_SCATTER_WRITE   pass 2; needs a launch boundary after the ELECT job of the same scatter */
+ *   ASAC_SIDECAR_SCATTER_WRITE   pass 2; needs a launch boundary after the ELECT job of the same scatter
+ *   ASAC_SIDECAR_WINDOW_GATHER   asac_window_gather_pad of a plan made by asac_window_gather_plan (the NEXT batch's
+ *                                windows of the lookahead schedule); hosted by asac_policy_sample_q_forward only */
 #define ASAC_SIDECAR_ALPHA_ADAM 1
 #define ASAC_SIDECAR_SCATTER_ELECT 2
 #define ASAC_SIDECAR_SCATTER_WRITE 3
+#define ASAC_SIDECAR_WINDOW_GATHER 4
 #define ASAC_MAX_SIDECARS 4
 typedef struct {
     int32_t kind;
@@ -320,6 +331,9 @@ typedef struct {
     const void* rows;
     int64_t rows_sample_stride_bytes, rows_row_stride_bytes;
     int32_t* winner;
+    /* WINDOW_GATHER */
+    const void* gather_plan;
+    int32_t gather_blocks;
 } asac_sidecar_t;
 
 /* Up to ASAC_SQUASH_MAX_JOBS independent jobs of the two kinds above / below in ONE launch (a train

@@ -49,8 +49,14 @@ def test_one_batch_in_flight_matches_the_delayed_oracle(name, fill):
     orb.tree.tree[:] = rb._tree.cpu().numpy()
 
     trained = []
+    from asac_amd import native
     for step in range(7):
-        agent.train()
+        if step == 1:      # (eager) the next batch's gather: extra workgroups of the first policy / critic launch where the
+            with native.LaunchProfiler(repeat=1) as prof:      # stock chain runs, a launch of its own before the write-backs otherwise
+                agent.train()
+            assert ('asac_window_gather_pad' in prof.summary()) == (name != 'cfg2')
+        else:
+            agent.train()
         torch.cuda.synchronize()
         # steps 0, 1 eager; 2 and 3 capture one arrangement of the two batch sets each; 4 .. 6 replay them in turn
         assert (agent._graph is not None) == (step >= 2)
