@@ -825,6 +825,12 @@ def f11_rpm():
     np.savez_compressed(HERE / 'f11_rpm.npz', **out)
 
 
+def attn_tanh_case():
+    small = dict(batch_size=32, replay_config={'capacity': 512})
+    f6_step('attn_tanh', str(HERE.parent / 'plugins' / 'nn_attn_tanh.py'),
+            dict(n_step=3, burn_in_step=4, seq_encoder=SEQ_ENCODER.ATTN, **small), [60, 45, 70, 12], 3)
+
+
 def main():
     torch.set_num_threads(1)
     if len(sys.argv) > 1:
@@ -848,6 +854,10 @@ def main():
     # ATTN representation (configs[4]'s sequence encoder, scaled down)
     f6_step('attn', 'envs/test/nn_attn.py', dict(n_step=3, burn_in_step=4, seq_encoder=SEQ_ENCODER.ATTN, **small),
             [60, 45, 70, 12], 3)
+    # ... and with a bounded state (Linear + tanh head behind the attention, this repository's tests/plugins/nn_attn_tanh.py:
+    # plugin API only, so it loads under the reference): the well-conditioned ATTN case
+    f6_step('attn_tanh', str(HERE.parent / 'plugins' / 'nn_attn_tanh.py'),
+            dict(n_step=3, burn_in_step=4, seq_encoder=SEQ_ENCODER.ATTN, **small), [60, 45, 70, 12], 3)
     # discrete + continuous actions, ensemble 3 of 2 sampled
     f6_step('hybrid', 'envs/test/nn.py', dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2, **small),
             [60, 45, 70], 3, d_action_sizes=(3, 2), c_action_size=2)

@@ -96,6 +96,7 @@ STEP_CASES = {
     'cfg2': ('nn_vec', dict(n_step=4), (), VEC),
     'cfg3': ('nn_rnn', dict(n_step=3, burn_in_step=3, seq_encoder='RNN'), (), VEC),
     'attn': ('nn_attn', dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), VEC),
+    'attn_tanh': ('nn_attn_tanh', dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), VEC),
     'hybrid': ('nn_vec', dict(n_step=3, ensemble_q_num=3, ensemble_q_sample=2), (3, 2), VEC),
     # BASELINE configs[3] / configs[4] compositions (reference tests/nn_conv_vanilla.py, tests/nn_conv_attn.py)
     'conv': ('nn_conv', dict(n_step=3, burn_in_step=5, ensemble_q_num=4, ensemble_q_sample=2), (), IMG),

@@ -47,14 +47,20 @@ def main():
         where = own(ev.stack)
         if not where and ev.sequence_nr is not None and ev.sequence_nr in forward_of:
             where = '(backward of) ' + forward_of[ev.sequence_nr]
+        node, up = '', ev.cpu_parent
+        while up is not None:       # the autograd node (backward) or the module-level op this ATen call serves
+            if up.name.startswith('autograd::engine::evaluate_function: '):
+                node = up.name.split(': ', 1)[1]
+                break
+            up = up.cpu_parent
         for k in ev.kernels:
-            rows.append((ev.time_range.start, k.name[:60], k.duration, ev.name, where))
+            rows.append((ev.time_range.start, k.name[:60], k.duration, ev.name + (f'  [{node}]' if node else ''), where))
     rows.sort()
     Path(out_path).parent.mkdir(parents=True, exist_ok=True)
     with open(out_path, 'w') as f:
         f.write(f'# {name}: {len(rows)} ATen-issued kernels of one eager step (launch order)\n')
         for _, kname, dur, op, where in rows:
-            f.write(f'{dur:8.1f} us  {kname:60s}  {op:40s}  {where}\n')
+            f.write(f'{dur:8.1f} us  {kname:44.44s}  {op:70s}  {where}\n')
     print(f'wrote {out_path}: {len(rows)} kernels')
 
 
