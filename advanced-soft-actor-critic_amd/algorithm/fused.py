@@ -214,6 +214,81 @@ def clipped_q_loss(q, tq, y, w, clip_eps):
 
 
 # ------------------------------------------------------------------------------------------------
+_ZERO_BLOCKS = {}
+
+
+def _zero_block(shape, like):
+    """a cached all-zero tensor (never written): the padding of `time_slice`'s backward"""
+    key = (tuple(shape), like.dtype, like.device)
+    z = _ZERO_BLOCKS.get(key)
+    if z is None:
+        z = _ZERO_BLOCKS[key] = torch.zeros(shape, dtype=like.dtype, device=like.device)
+    return z
+
+
+class _TimeSliceFn(torch.autograd.Function):
+    """x[:, a:b] of a [B, L, ...] tensor.  The slice node's own backward is a fill and a copy (two launches of a few KB
+    each, several times per backward walk through the representation); this one is ONE concatenation with cached zeros."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.full, ctx.a, ctx.b = x.shape, a, b
+        return x[:, a:b]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, *rest = ctx.full
+        parts = []
+        if ctx.a > 0:
+            parts.append(_zero_block((B, ctx.a, *rest), g))
+        parts.append(g)
+        if ctx.b < L:
+            parts.append(_zero_block((B, L - ctx.b, *rest), g))
+        return torch.cat(parts, dim=1), None, None
+
+
+def time_slice(x: torch.Tensor, a: int = 0, b: int | None = None) -> torch.Tensor:
+    """x[:, a:b] (non-negative bounds) — x itself when that is all of it; differentiable inputs on the device get the
+    one-launch backward of `_TimeSliceFn`"""
+    L = x.shape[1]
+    b = L if b is None else (b + L if b < 0 else b)
+    a = a + L if a < 0 else a
+    if a == 0 and b == L:
+        return x
+    if x.is_cuda and x.requires_grad and torch.is_grad_enabled() and x.dim() >= 2:
+        return _TimeSliceFn.apply(x, a, b)
+    return x[:, a:b]
+
+
+class _ScaledMseFn(torch.autograd.Function):
+    """mse_loss(pred, target) / divisor with its gradient formed by the loss launch itself (`asac_masked_mse`: one launch
+    for ATen's subtract / square / mean, one for the division; the backward is one scaling) — reference sac_base.py:1817"""
+
+    @staticmethod
+    def forward(ctx, pred, target, divisor):
+        from asac_amd import native
+        grad = torch.empty_like(pred)
+        loss = torch.empty((), dtype=pred.dtype, device=pred.device)
+        native.masked_mse(pred.detach(), target, None, grad, loss)
+        ctx.save_for_backward(grad)
+        ctx.divisor = divisor
+        return loss / divisor
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad,) = ctx.saved_tensors
+        return grad * (g_loss / ctx.divisor), None, None
+
+
+def scaled_mse(pred: torch.Tensor, target: torch.Tensor, divisor: float) -> torch.Tensor:
+    from asac_amd import native
+    if (pred.is_cuda and pred.dim() == 3 and pred.dtype == torch.float32 and pred.is_contiguous() and target.shape == pred.shape
+            and target.dtype == torch.float32 and target.stride(-1) == 1 and not target.requires_grad
+            and 0 < pred.numel() <= native.MASKED_MSE_MAX):
+        return _ScaledMseFn.apply(pred, target, divisor)
+    return torch.nn.functional.mse_loss(pred, target) / divisor
+
+
 class DeviceNoise:
     """Draws on the device; every call is graph-capturable.  `begin_step` produces every uniform and
     Gaussian draw of a train step with ONE `asac_noise_fill` launch (Philox keyed by `seed`, counter =

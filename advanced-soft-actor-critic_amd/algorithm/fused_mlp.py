@@ -219,7 +219,7 @@ def _param_grad_target(mlp, param_grads, n_params):
     scratch buffer with the parameters' layout, returned as one view per parameter"""
     if not param_grads or direct_enabled() or n_params == 0:
         return None, [None] * n_params
-    scratch = torch.zeros_like(mlp.grad_params)
+    scratch = torch.empty_like(mlp.grad_params)      # (every parameter's span is overwritten: MLP_REDUCE_OVERWRITE)
     base = mlp.params.storage_offset()
     views = [scratch[p.data.storage_offset() - base:p.data.storage_offset() - base + p.numel()].view(p.shape)
              for p in mlp.param_tensors]

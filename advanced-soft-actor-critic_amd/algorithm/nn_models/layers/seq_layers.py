@@ -296,8 +296,11 @@ class _AttnProjFn(torch.autograd.Function):
             g_out = torch.zeros(xq.shape[0], xq.shape[1], xq.shape[2], dtype=xq.dtype, device=xq.device)
         B, Lq, E = xq.shape
         Lk = xk.shape[1]
-        g_xq = torch.empty(B, Lq, E, dtype=xq.dtype, device=xq.device)
+        # (tail: the queries are the last rows of the keys — the launch adds their gradient into those rows of g_xk)
+        g_xq = None if tail else torch.empty(B, Lq, E, dtype=xq.dtype, device=xq.device)
         g_xk = torch.empty(B, Lk, E, dtype=xq.dtype, device=xq.device)
+        if g_out.stride(2) != 1:
+            g_out = g_out.contiguous()
         ws = torch.empty(native.attention_proj_workspace(B, Lq, Lk, E), dtype=xq.dtype, device=xq.device)
         pd = [t.detach().contiguous() for t in params]
         gw = None if g_w is None else g_w.contiguous()
@@ -305,23 +308,17 @@ class _AttnProjFn(torch.autograd.Function):
         if direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
         if flat is not None:
-            native.attention_proj_backward(xq, xk, pd, weights, g_out.contiguous(), gw, g_xq, g_xk, flat, True, ws,
+            native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, flat, True, ws,
                                            keep, attn_out, ctx.row_zero)
-            if tail:
-                g_xk[:, -tail:].add_(g_xq)
-                g_xq = None
             return (g_xq, g_xk, None, None, *([None] * len(params)))
         g = torch.empty(sum(p.numel() for p in params), dtype=xq.dtype, device=xq.device)
-        native.attention_proj_backward(xq, xk, pd, weights, g_out.contiguous(), gw, g_xq, g_xk, g, False, ws, keep,
+        native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, g, False, ws, keep,
                                        attn_out, ctx.row_zero)
         grads, off = [], 0
         for p_ in params:
             k = p_.numel()
             grads.append(g[off:off + k].view(p_.shape) if p_.requires_grad else None)
             off += k
-        if tail:
-            g_xk[:, -tail:].add_(g_xq)
-            g_xq = None
         return (g_xq, g_xk, None, None, *grads)
 
 

@@ -38,11 +38,18 @@ class ModelTransition(ModelBaseTransition):
         self.dense = LinearLayers(n_in, dense_n, dense_depth, self.state_size * 2)
         self.dense.fuse = True     # one launch per pass when the stack fits (fused_mlp.describe_dense)
 
+    SCALE_MIN, SCALE_MAX = 0.1, 1.0
+
+    def mean_logstd(self, obs_list, state, action):
+        """the dense stack's raw output [..., 2 * state_size] = (mean | logstd); the learner's fused transition loss
+        (`asac_normal_nll_kl_logstd`) applies exp / clamp itself"""
+        parts = [state, self.extra_obs(obs_list), action] if self.use_extra_data else [state, action]
+        return self.dense(torch.cat(parts, dim=-1))       # (one concatenation: same columns as cat(cat(s, e), a))
+
     def forward(self, obs_list, state, action):
-        if self.use_extra_data:
-            state = torch.cat([state, self.extra_obs(obs_list)], dim=-1)
-        mean, logstd = torch.chunk(self.dense(torch.cat([state, action], dim=-1)), 2, dim=-1)
-        return torch.distributions.Normal(mean, torch.clamp(torch.exp(logstd), 0.1, 1.0), validate_args=False)
+        mean, logstd = torch.chunk(self.mean_logstd(obs_list, state, action), 2, dim=-1)
+        return torch.distributions.Normal(mean, torch.clamp(torch.exp(logstd), self.SCALE_MIN, self.SCALE_MAX),
+                                          validate_args=False)
 
 
 class ModelBaseReward(nn.Module):

@@ -40,6 +40,41 @@ class _NormalNllKlFn(autograd.Function):
         return g_loss * g_loc, g_loss * g_scale, None, None
 
 
+class _NormalNllKlLogstdFn(autograd.Function):
+    """`_NormalNllKlFn` on the transition model's raw output (mean | logstd) [B, T, 2K]: the head's
+    clamp(exp(logstd), lo, hi) and its backward run inside the launch (`asac_normal_nll_kl_logstd`)"""
+
+    @staticmethod
+    def forward(ctx, raw, target, w, lo, hi):
+        from asac_amd import native
+        g_raw = torch.empty(raw.shape, device=raw.device)
+        out = torch.empty(2, device=raw.device)
+        native.normal_nll_kl_logstd(raw.detach(), lo, hi, target.detach(), w, g_raw, out)
+        ctx.save_for_backward(g_raw)
+        entropy = out[1]
+        ctx.mark_non_differentiable(entropy)
+        return out[0], entropy
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_entropy):
+        (g_raw,) = ctx.saved_tensors
+        return g_loss * g_raw, None, None, None, None
+
+
+def _stock_transition(model) -> bool:
+    """the model's forward is the library's (plugins usually override `_build_model` only)"""
+    from .nn_models.predictions import ModelTransition
+    return isinstance(model, ModelTransition) and type(model).forward is ModelTransition.forward \
+        and type(model).mean_logstd is ModelTransition.mean_logstd
+
+
+def _normal_nll_kl_raw_ok(raw, target) -> bool:
+    from asac_amd import native
+    return (raw.is_cuda and raw.dim() == 3 and raw.dtype == torch.float32 and raw.stride(-1) == 1
+            and raw.shape[-1] == 2 * target.shape[-1] and raw.shape[:2] == target.shape[:2] and target.dtype == torch.float32
+            and target.stride(-1) == 1 and 0 < target.numel() <= native.MASKED_MSE_MAX and not target.requires_grad)
+
+
 def _normal_nll_kl_ok(dist, target) -> bool:
     from asac_amd import native
     loc, scale = dist.loc, dist.scale
@@ -288,9 +323,26 @@ class AuxHeadsMixin:
         PyTorch refuses once the Q loss has freed it; this build keeps that graph alive
         (`retain_graph` on the Q loss) so the head runs."""
         n_obs = [o[:, :-1] for o in nx_obses_list]
-        dist_next = self.model_transition(n_obs, nx_states[:, :-1], n_actions)
-        entropy_next = None
-        if self._fused_rpm_loss and _normal_nll_kl_ok(dist_next, nx_target_states[:, 1:]):
+        entropy_next = dist_next = None
+        target_next = nx_target_states[:, 1:]
+        if self._fused_rpm_loss and _stock_transition(self.model_transition):
+            # the library's own transition model: its raw (mean | logstd) output goes to the loss launch, which applies the
+            # head's exp / clamp and their backward itself
+            from .fused import time_slice
+            mt = self.model_transition
+            raw = mt.mean_logstd(n_obs, time_slice(nx_states, 0, -1), n_actions)
+            if _normal_nll_kl_raw_ok(raw, target_next):
+                loss_transition, entropy_next = _NormalNllKlLogstdFn.apply(raw, target_next, float(self.transition_kl),
+                                                                          float(mt.SCALE_MIN), float(mt.SCALE_MAX))
+            else:
+                mean, logstd = torch.chunk(raw, 2, dim=-1)
+                dist_next = distributions.Normal(mean, torch.clamp(torch.exp(logstd), mt.SCALE_MIN, mt.SCALE_MAX),
+                                                 validate_args=False)
+        else:
+            dist_next = self.model_transition(n_obs, nx_states[:, :-1], n_actions)
+        if entropy_next is not None:
+            pass
+        elif self._fused_rpm_loss and _normal_nll_kl_ok(dist_next, nx_target_states[:, 1:]):
             loss_transition, entropy_next = _NormalNllKlFn.apply(dist_next.loc, dist_next.scale, nx_target_states[:, 1:],
                                                                  float(self.transition_kl))
         else:
@@ -299,7 +351,11 @@ class AuxHeadsMixin:
                                               validate_args=False)
             loss_transition = loss_transition + self.transition_kl * torch.mean(
                 distributions.kl.kl_divergence(dist_next, std_normal))
-        loss_reward = functional.mse_loss(self.model_reward(nx_states[:, 1:]), n_rewards.unsqueeze(2)) / self.n_step
+        if self._fused_rpm_loss:
+            from .fused import scaled_mse, time_slice
+            loss_reward = scaled_mse(self.model_reward(time_slice(nx_states, 1)), n_rewards.unsqueeze(2), self.n_step)
+        else:
+            loss_reward = functional.mse_loss(self.model_reward(nx_states[:, 1:]), n_rewards.unsqueeze(2)) / self.n_step
         loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
         model_params = [list(mod.parameters()) for mod in (self.model_transition, self.model_reward, self.model_observation)]
         pred_params = list(chain(*model_params))

@@ -34,7 +34,7 @@ from torch.nn import functional
 from asac_amd import native
 
 from . import fused_gru, fused_linear
-from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls
+from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls, time_slice
 from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
 from .nn_models.layers.seq_layers import step_mask_cache
@@ -1849,7 +1849,7 @@ class SAC_Base(AuxHeadsMixin):
             aux = dict(n_indexes=w.bn_indexes[:, b:],
                        n_pre_actions=w.bn_actions[:, b - 1:-1] if b > 0 else w.bn_actions[:, 0:0],
                        n_pre_seq_hidden_states=w.bnx_hidden[:, b:-1], nx_target_states=w.nx_target_states)
-        self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, bnx_states[:, pb:], w.bnx_actions[:, b:],
+        self._train_rep_q(w.bn_last[:, b:], w.bn_pad[:, b:], w.nx_obs, time_slice(bnx_states, pb), w.bnx_actions[:, b:],
                           w.bn_rewards[:, b:], w.bn_dones[:, b:], w.bn_mu_probs[:, b:], w.priority_is, aux,
                           policy_sample=w.stock and not w.rep_trainable,
                           state_base=state_base)

@@ -213,6 +213,7 @@ struct AttnProjArgs {
     int32_t B, Lq, Lk, E;
     float* out; float* w; float* keep;
     const float* g_out; const float* g_w;
+    int64_t go_sb, go_sr;                                   // projection backward: strides of g_out (floats: entry, row)
     float* g_xq; float* g_xk;                               // dense [B][Lq][E], [B][Lk][E]
     float* partial;                                         // [blocks][(3 or 4) * (E*E + E)]
 };
@@ -381,8 +382,10 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
     __shared__ float kL[kProjStage], vL[kProjStage], qL[kProjStage], xqL[kProjStage], xkL[kProjStage];
     __shared__ float gqL[kProjStage], gkL[kProjStage], gvL[kProjStage], wL[4 * (EM * EM + EM)];
     __shared__ float goL[kProjStage], gzL[kProjStage], ovL[kProjStage];   // d/d attention output; output-block terms
+    __shared__ float gxqL[kProjStage];      // tail form: the query rows' input gradients on their way into the key rows'
     constexpr int blk = EM * EM + EM;
     const int E = a.E;
+    const bool tail = a.g_xq == nullptr;     // the queries ARE the last Lq key rows: one gradient serves both
     const int b0 = blockIdx.x * EPB, nb = min(EPB, a.B - b0);
     stage_weights<EM>(a, wL);
     for (int f = threadIdx.x; f < nb * a.Lq * a.Lk; f += kAttnThreads) {
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
     float xk[EM], xq[EM], go[EM], o[EM];
     load_row<EM>(a.xk + (int64_t)b * a.xk_sb + (int64_t)min(r, a.Lk - 1) * a.xk_sr, E, xk);
     load_row<EM>(a.xq + (int64_t)b * a.xq_sb + (int64_t)min(r, a.Lq - 1) * a.xq_sr, E, xq);
-    load_row<EM>(a.g_out + row * E, E, go);
+    load_row<EM>(a.g_out + (int64_t)b * a.go_sb + (int64_t)min(r, a.Lq - 1) * a.go_sr, E, go);
     float kp = 1.f;
     if (a.wo) {
         load_row<EM>(a.attn_out + row * E, E, o);
@@ -467,9 +470,13 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         for (int d = 0; d < EM; ++d) gq[d] = gq[d] / rsd;      // gradient of the unscaled projection output
         put_row<EM>(gqL + (bl * a.Lq + r) * EM, gq);
         project_t<EM>(wL, gq, gx);                                // gradient of x_q: Wq^T g_q
+        if (tail) {
+            put_row<EM>(gxqL + (bl * a.Lq + r) * EM, gx);
+        } else {
 #pragma unroll
-        for (int c = 0; c < EM; ++c)
-            if (c < E) a.g_xq[row * E + c] = gx[c];
+            for (int c = 0; c < EM; ++c)
+                if (c < E) a.g_xq[row * E + c] = gx[c];
+        }
     }
     __syncthreads();
     // phase 2: key row j = r -> g_k, g_v (sums over the entry's queries), gradient of x_k
@@ -491,9 +498,14 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         project_t<EM>(wL + blk, gk, gx);
         project_t<EM>(wL + 2 * blk, gv, gx2);
         const int64_t kr = ((int64_t)b * a.Lk + r) * E;
+        const int qi = r - (a.Lk - a.Lq);                         // tail form: this key row is query row qi
 #pragma unroll
         for (int c = 0; c < EM; ++c)
-            if (c < E) a.g_xk[kr + c] = gx[c] + gx2[c];
+            if (c < E) {
+                float v = gx[c] + gx2[c];
+                if (tail && qi >= 0) v += gxqL[(bl * a.Lq + qi) * EM + c];     // (as `g_xk[:, -Lq:] += g_xq`)
+                a.g_xk[kr + c] = v;
+            }
     }
     __syncthreads();
     // phase 3: this workgroup's partial parameter gradients (fixed order over its rows), packed for width E
@@ -637,11 +649,12 @@ int asac_attention_proj_forward(const float* xq, int64_t xq_stride_b, int64_t xq
 int asac_attention_proj_backward(const float* xq, int64_t xq_stride_b, int64_t xq_stride_r, const float* xk,
                                  int64_t xk_stride_b, int64_t xk_stride_r, const float* const* params,
                                  const float* weights, const float* keep, const float* attn_out, const float* grad_out,
+                                 int64_t grad_out_stride_b, int64_t grad_out_stride_r,
                                  const float* grad_weights, const uint8_t* row_zero, int64_t row_zero_stride_b,
                                  int64_t row_zero_stride_q, int B, int Lq, int Lk, int E, float* grad_xq, float* grad_xk,
                                  float* grad_params, int accumulate, float* workspace, void* stream) {
-    if (!attn_ok(B, Lq, Lk, E) || !xq || !xk || !params || !weights || !grad_out || !grad_xq || !grad_xk ||
-        !grad_params || !workspace)
+    if (!attn_ok(B, Lq, Lk, E) || !xq || !xk || !params || !weights || !grad_out || !grad_xk || !grad_params || !workspace ||
+        (!grad_xq && Lq > Lk))
         return bad_arg("asac_attention_proj_backward");
     for (int i = 0; i < 6; ++i)
         if (!params[i]) return bad_arg("asac_attention_proj_backward: params");
@@ -654,6 +667,7 @@ int asac_attention_proj_backward(const float* xq, int64_t xq_stride_b, int64_t x
     fill_proj(a, xq, xq_stride_b, xq_stride_r, xk, xk_stride_b, xk_stride_r, params, B, Lq, Lk, E);
     a.w = const_cast<float*>(weights);
     a.g_out = grad_out; a.g_w = grad_weights;
+    a.go_sb = grad_out_stride_b; a.go_sr = grad_out_stride_r;
     a.g_xq = grad_xq; a.g_xk = grad_xk;
     a.partial = workspace;
     const int P = Lq > Lk ? Lq : Lk, EPB = attn_proj_bwd_entries(Lq, Lk, E);

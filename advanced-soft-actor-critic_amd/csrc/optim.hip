@@ -214,7 +214,9 @@ __global__ __launch_bounds__(kMseThreads) void k_normal_nll_kl(const float* __re
                                                                int64_t target_sb, int64_t target_st, int B, int T, int K,
                                                                float w, float* __restrict__ grad_loc,
                                                                float* __restrict__ grad_scale, float* __restrict__ out,
-                                                               float* __restrict__ partial, unsigned int* __restrict__ counter) {
+                                                               float* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                               int log_scale, float scale_min, float scale_max,
+                                                               int64_t grad_pitch) {
     __shared__ float red[3][kMseThreads];
     __shared__ bool last;
     const int N = B * T * K;
@@ -231,6 +233,18 @@ __global__ __launch_bounds__(kMseThreads) void k_normal_nll_kl(const float* __re
         sg[u] = scale[b * scale_sb + t * scale_st + k];
         xv[u] = target[b * target_sb + t * target_st + k];
     }
+    // log_scale: `scale` holds log-std values; the distribution's scale is clamp(exp(.), scale_min, scale_max)
+    // (ModelTransition.forward, nn_models/predictions.py) and grad_scale becomes the gradient of the log-std: exp's
+    // backward times the clamp's pass-through test (min <= exp <= max, both inclusive as ATen's clamp_backward)
+    float e_raw[kMsePerLane];
+#pragma unroll
+    for (int u = 0; u < kMsePerLane; ++u) {
+        e_raw[u] = 1.f;
+        if (log_scale) {
+            e_raw[u] = expf(sg[u]);
+            sg[u] = fminf(fmaxf(e_raw[u], scale_min), scale_max);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < kMsePerLane; ++u) {
         const int i = base + u * kMseThreads + (int)threadIdx.x;
@@ -239,8 +253,11 @@ __global__ __launch_bounds__(kMseThreads) void k_normal_nll_kl(const float* __re
             s_lp += -(d * d) / (2.f * var) - ls - c_lp;
             s_kl += 0.5f * (var + mu[u] * mu[u] - 1.f - logf(var));
             s_ent += c_ent + ls;
-            grad_loc[i] = (-(d / var) + w * mu[u]) * inv_n;
-            grad_scale[i] = (-((d * d) / (var * sg[u])) + inv_s + w * (sg[u] - inv_s)) * inv_n;
+            const int64_t at = (int64_t)(i / K) * grad_pitch + (i % K);
+            grad_loc[at] = (-(d / var) + w * mu[u]) * inv_n;
+            float gs = (-((d * d) / (var * sg[u])) + inv_s + w * (sg[u] - inv_s)) * inv_n;
+            if (log_scale) gs = (e_raw[u] >= scale_min && e_raw[u] <= scale_max) ? gs * e_raw[u] : 0.f;
+            grad_scale[at] = gs;
         }
     }
     red[0][threadIdx.x] = s_lp, red[1][threadIdx.x] = s_kl, red[2][threadIdx.x] = s_ent;
@@ -420,8 +437,24 @@ int asac_normal_nll_kl(const float* loc, int64_t loc_stride_b, int64_t loc_strid
     ASAC_LAUNCH(k_normal_nll_kl, dim3((unsigned)blocks), dim3(kMseThreads), 0, as_stream(stream), loc, loc_stride_b,
                 loc_stride_t, scale, scale_stride_b, scale_stride_t, target, target_stride_b, target_stride_t, B, T, K,
                 kl_weight, grad_loc, grad_scale, loss_entropy_out, workspace,
-                reinterpret_cast<unsigned int*>(workspace + 3 * blocks));
+                reinterpret_cast<unsigned int*>(workspace + 3 * blocks), 0, 0.f, 0.f, (int64_t)K);
     return finish_launch("asac_normal_nll_kl");
+}
+
+int asac_normal_nll_kl_logstd(const float* mean_logstd, int64_t stride_b, int64_t stride_t, float scale_min, float scale_max,
+                              const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T, int K,
+                              float kl_weight, float* grad_mean_logstd, float* loss_entropy_out, float* workspace,
+                              void* stream) {
+    const int64_t n = (int64_t)B * T * K;
+    if (B <= 0 || T <= 0 || K <= 0 || !mean_logstd || !target || !grad_mean_logstd || !loss_entropy_out || !workspace ||
+        n > ASAC_MASKED_MSE_MAX || !(scale_min > 0.f) || !(scale_max >= scale_min))
+        return bad_arg("asac_normal_nll_kl_logstd");
+    const int64_t blocks = (asac_normal_nll_kl_workspace(n) - 1) / 3;
+    ASAC_LAUNCH(k_normal_nll_kl, dim3((unsigned)blocks), dim3(kMseThreads), 0, as_stream(stream), mean_logstd, stride_b,
+                stride_t, mean_logstd + K, stride_b, stride_t, target, target_stride_b, target_stride_t, B, T, K, kl_weight,
+                grad_mean_logstd, grad_mean_logstd + K, loss_entropy_out, workspace,
+                reinterpret_cast<unsigned int*>(workspace + 3 * blocks), 1, scale_min, scale_max, (int64_t)2 * K);
+    return finish_launch("asac_normal_nll_kl_logstd");
 }
 
 int asac_cosine_gate_add(const float* main, const float* const* aux_host, int K, int64_t n, float* grad, float* gates_out,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 61
+ABI_VERSION = 62
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -268,8 +268,8 @@ _SIGNATURES = {
                                               C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'asac_attention_proj_backward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
-                                               C.c_void_p * 8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_int64, C.c_int64,
+                                               C.c_void_p * 8, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p, C.c_void_p]),
     'asac_linear_tanh_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
@@ -297,6 +297,9 @@ _SIGNATURES = {
     'asac_normal_nll_kl': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                      C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_normal_nll_kl_logstd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int64,
+                                            C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -1138,11 +1141,14 @@ def attention_proj_forward(xq, xk, params, mask, out, weights, keep, attn_out=No
 @_profiled
 def attention_proj_backward(xq, xk, params, weights, grad_out, grad_weights, grad_xq, grad_xk, grad_params, accumulate,
                             workspace, keep=None, attn_out=None, row_zero=None):
-    _dense_f32(weights, grad_out, grad_weights, grad_xq, grad_xk, grad_params, workspace, keep, attn_out)
+    """grad_out: [B, Lq, E] view with a dense last dim (read in place); grad_xq None: the queries are the last Lq key
+    rows and their gradient is added into those rows of grad_xk by the launch"""
+    _dense_f32(weights, grad_weights, grad_xq, grad_xk, grad_params, workspace, keep, attn_out)
     pq, qsb, qsr = _rows3(xq)
     pk, ksb, ksr = _rows3(xk)
+    pg, gsb, gsr = _rows3(grad_out)
     _check(load().asac_attention_proj_backward(pq, qsb, qsr, pk, ksb, ksr, _proj_ptrs(params), _p(weights), _p(keep),
-                                               _p(attn_out), _p(grad_out), _p(grad_weights), *_row_mask(row_zero),
+                                               _p(attn_out), pg, gsb, gsr, _p(grad_weights), *_row_mask(row_zero),
                                                xq.shape[0], xq.shape[1], xk.shape[1], xq.shape[2],
                                                _p(grad_xq), _p(grad_xk), _p(grad_params), int(bool(accumulate)),
                                                _p(workspace), _stream()), 'asac_attention_proj_backward')
@@ -1237,6 +1243,23 @@ def normal_nll_kl(loc, scale, target, kl_weight, grad_loc, grad_scale, out):
         _NLL_WS[key] = torch.zeros(int(load().asac_normal_nll_kl_workspace(loc.numel())), dtype=torch.float32, device=loc.device)
     _check(load().asac_normal_nll_kl(pl, lb, lt, ps, sb, st, pt, tb, tt, B, T, K, float(kl_weight), _p(grad_loc),
                                      _p(grad_scale), _p(out), _p(_NLL_WS[key]), _stream()), 'asac_normal_nll_kl')
+
+
+@_profiled
+def normal_nll_kl_logstd(raw, scale_min, scale_max, target, kl_weight, grad_raw, out):
+    """`normal_nll_kl` of N(mean, clamp(exp(logstd), scale_min, scale_max)) with (mean | logstd) = the halves of raw
+    [B, T, 2K]; grad_raw [B, T, 2K] dense <- d out[0] / d raw"""
+    B, T, K2 = raw.shape
+    K = K2 // 2
+    assert K2 == 2 * K and raw.stride(2) == 1 and target.shape == (B, T, K) and target.stride(2) == 1
+    assert grad_raw.is_contiguous() and grad_raw.shape == raw.shape and out.numel() == 2 and out.is_contiguous()
+    _dense_f32(grad_raw, out)
+    key = (B * T * K, raw.device)
+    if key not in _NLL_WS:
+        _NLL_WS[key] = torch.zeros(int(load().asac_normal_nll_kl_workspace(B * T * K)), dtype=torch.float32, device=raw.device)
+    _check(load().asac_normal_nll_kl_logstd(_p(raw), raw.stride(0), raw.stride(1), float(scale_min), float(scale_max),
+                                            _p(target), target.stride(0), target.stride(1), B, T, K, float(kl_weight),
+                                            _p(grad_raw), _p(out), _p(_NLL_WS[key]), _stream()), 'asac_normal_nll_kl_logstd')
 
 
 @_profiled

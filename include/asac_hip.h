@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 61
+#define ASAC_ABI_VERSION 62
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -930,7 +930,10 @@ int asac_attention_backward(const float* q, const float* k, const float* v, cons
  *   receives o (the backward reads it back together with keep);  row_zero (optional, with the output block):
  *   bytes [B][Lq] with the given strides, nonzero = the row's output is zeroed as well (the episode block's
  *   padded positions, seq_layers.py:445-447)
- * Backward recomputes the projections; grad_xq [B][Lq][E] and grad_xk [B][Lk][E] are written dense; the parameter
+ * Backward recomputes the projections; grad_out element (b, i, c) at grad_out + b*stride_b + i*stride_r + c (a slice of a
+ * longer gradient needs no copy); grad_xq [B][Lq][E] and grad_xk [B][Lk][E] are written dense — grad_xq == NULL: the
+ * queries are the LAST Lq key rows (the episode blocks' cut query, seq_layers.py:600-610) and their input gradient is added
+ * to those rows of grad_xk inside the launch; the parameter
  * gradients, packed Wq | bq | Wk | bk | Wv | bv (| Wo | bo) (3 or 4 times E*E+E floats), are written or (accumulate != 0) added to
  * grad_params after a fixed-order reduction over workgroups; workspace of asac_attention_proj_workspace floats. */
 int64_t asac_attention_proj_workspace(int B, int Lq, int Lk, int E);
@@ -943,7 +946,8 @@ int asac_attention_proj_forward(const float* xq, int64_t xq_stride_b, int64_t xq
 int asac_attention_proj_backward(const float* xq, int64_t xq_stride_b, int64_t xq_stride_r, const float* xk,
                                  int64_t xk_stride_b, int64_t xk_stride_r, const float* const* params_host,
                                  const float* weights, const float* keep, const float* attn_out,
-                                 const float* grad_out, const float* grad_weights, const uint8_t* row_zero,
+                                 const float* grad_out, int64_t grad_out_stride_b, int64_t grad_out_stride_r,
+                                 const float* grad_weights, const uint8_t* row_zero,
                                  int64_t row_zero_stride_b, int64_t row_zero_stride_q, int B, int Lq, int Lk, int E,
                                  float* grad_xq, float* grad_xk, float* grad_params, int accumulate,
                                  float* workspace, void* stream);
@@ -1059,6 +1063,15 @@ int asac_normal_nll_kl(const float* loc, int64_t loc_stride_b, int64_t loc_strid
                        int64_t scale_stride_b, int64_t scale_stride_t, const float* target, int64_t target_stride_b,
                        int64_t target_stride_t, int B, int T, int K, float kl_weight, float* grad_loc, float* grad_scale,
                        float* loss_entropy_out, float* workspace, void* stream);
+
+/* The same with the head's activation inside: mean_logstd [B][T][2K] (strides in floats) is the transition model's raw
+ * output (mean | logstd, `torch.chunk` of nn_models/predictions.py:39-44), the distribution's scale is
+ * clamp(exp(logstd), scale_min, scale_max); grad_mean_logstd [B][T][2K] dense = d out[0] / d (mean | logstd) — exp's and
+ * clamp's backward (pass-through where scale_min <= exp <= scale_max) applied in the launch. */
+int asac_normal_nll_kl_logstd(const float* mean_logstd, int64_t stride_b, int64_t stride_t, float scale_min, float scale_max,
+                              const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T, int K,
+                              float kl_weight, float* grad_mean_logstd, float* loss_entropy_out, float* workspace,
+                              void* stream);
 
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with
