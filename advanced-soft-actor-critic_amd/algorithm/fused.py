@@ -277,6 +277,9 @@ class _ScaledMseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss):
         (grad,) = ctx.saved_tensors
+        from .sac_aux import _is_unit
+        if _is_unit(g_loss):      # the root gradient of `autograd.grad(loss, ...)`: 1 / divisor is a host constant
+            return grad / ctx.divisor, None, None
         return grad * (g_loss / ctx.divisor), None, None
 
 

@@ -53,12 +53,33 @@ class _NormalNllKlLogstdFn(autograd.Function):
         ctx.save_for_backward(g_raw)
         entropy = out[1]
         ctx.mark_non_differentiable(entropy)
+        ctx.set_materialize_grads(False)
         return out[0], entropy
 
     @staticmethod
     def backward(ctx, g_loss, _g_entropy):
         (g_raw,) = ctx.saved_tensors
-        return g_loss * g_raw, None, None, None, None
+        if g_loss is None:
+            return None, None, None, None, None
+        return (g_raw if _is_unit(g_loss) else g_loss * g_raw), None, None, None, None
+
+
+_UNIT = {}
+
+
+def unit_gradient(like: torch.Tensor) -> torch.Tensor:
+    """a cached scalar 1 on `like`'s device: the root gradient of `autograd.grad(loss, ...)` without the fill launch that
+    building `ones_like(loss)` costs on every call; the loss functions of this module recognise it and skip the scaling"""
+    key = (like.device, like.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        one = _UNIT[key] = torch.ones((), dtype=like.dtype, device=like.device)
+    return one
+
+
+def _is_unit(g: torch.Tensor) -> bool:
+    one = _UNIT.get((g.device, g.dtype))
+    return one is not None and g.data_ptr() == one.data_ptr() and g.dim() == 0
 
 
 def _stock_transition(model) -> bool:
@@ -368,7 +389,8 @@ class AuxHeadsMixin:
             rep_params = list(self.model_rep.parameters())
             aux, gs = [], []
             for loss_i, params_i in zip(losses, model_params):
-                got = autograd.grad(loss_i, [nx_states, *params_i], allow_unused=True, retain_graph=True)
+                got = autograd.grad(loss_i, [nx_states, *params_i], grad_outputs=unit_gradient(loss_i), allow_unused=True,
+                                    retain_graph=True)
                 gs += got[1:]
                 if got[0] is None:
                     aux.append([None] * len(rep_params))
