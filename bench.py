@@ -131,7 +131,11 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_td_update': 'asac::k_td_update',
               'asac_obs_decoder_forward': 'asac::dec::k_dec_fwd12+asac::dec::k_dec_fwd3',
               'asac_obs_decoder_backward': 'asac::dec::k_dec_bwd3+asac::dec::k_dec_bwd2dx+asac::dec::k_dec_bwd2dw+asac::dec::k_dec_reduce',
-              'asac_cosine_gate_add': 'asac::k_cosine_gate_add'}
+              'asac_cosine_gate_add': 'asac::k_cosine_gate_add',
+              'asac_attention_mh_forward': 'asac::amh::k_attn_mh', 'asac_attention_mh_backward': 'asac::amh::k_attn_mh',
+              'asac_gru_wide_forward': 'asac::gruw::k_gruw_fwd', 'asac_gru_wide_backward': 'asac::gruw::k_gruw_bwd',
+              'asac_normal_nll_kl': 'asac::k_normal_nll_kl', 'asac_normal_nll_kl_logstd': 'asac::k_normal_nll_kl',
+              'asac_masked_mse': 'asac::k_masked_mse'}
 SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
 ROUND = 'r04'

@@ -13,7 +13,10 @@ for name in ('cfg2_kernel_stats.csv', 'cfg2_kernel_stats_summary.txt', 'kernel_s
              'cfg3_step_sequence.txt', 'cfg4_step_sequence.txt', 'cfg5_step_sequence.txt', 'cfg3_kernel_stats_summary.txt',
              'cfg4_kernel_stats_summary.txt', 'cfg5_kernel_stats_summary.txt', 'cfg5_without_prediction_step_sequence.txt',
              'cfg5_without_prediction_kernel_stats_summary.txt', 'cfg2_kernel_stats.json', 'cfg3_kernel_stats.json',
-             'cfg4_kernel_stats.json', 'cfg5_kernel_stats.json', 'cfg5_without_prediction_kernel_stats.json'):
+             'cfg4_kernel_stats.json', 'cfg5_kernel_stats.json', 'cfg5_without_prediction_kernel_stats.json',
+             'cfg3_h64_kernel_stats.json', 'cfg3_h64_kernel_stats_summary.txt', 'cfg3_h64_step_sequence.txt',
+             'cfg_attn_h64_kernel_stats.json', 'cfg_attn_h64_kernel_stats_summary.txt', 'cfg_attn_h64_step_sequence.txt',
+             'cfg2_lookahead_step_sequence.txt', 'cfg2_lookahead_kernel_stats.json', 'cfg2_lookahead_kernel_stats_summary.txt'):
     if (R / name).exists():
         shutil.copy(R / name, P / f'{TAG}_{name}')
 for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',
