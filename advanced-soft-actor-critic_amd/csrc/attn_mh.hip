@@ -22,6 +22,7 @@ namespace amh {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kThreads = 256;      // 4 waves = 4 batch entries
 constexpr int kMaxL = 32;
+constexpr int kTP = 20;             // LDS pitch of a turned tile's rows
 
 #define AM_MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -74,7 +75,9 @@ __device__ __forceinline__ f32x4 row4(const float* base, bool live, int c0, int 
 
 template <bool BWD>
 __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
-    __shared__ float s_t[4][8][256];       // per wave: P and dS tiles turned for the products over the queries
+    // per wave: P and dS tiles turned for the products over the queries; rows of 16 at a pitch of kTP = 20 floats: the four
+    // lane quarters of a store then fall into four different 16-bank groups, rows stay 16-byte aligned for the b128 reads
+    __shared__ float s_t[4][8][16 * kTP];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, qq = l >> 4, x = l & 15;
     const int b = blockIdx.x * 4 + wv;
     if (b >= a.B) return;
@@ -295,8 +298,8 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                 for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        tbuf[((km * 2 + qn) * 256) + (4 * qq + r) * 16 + tpos(x)] = P[km][qn][r];
-                        tbuf[((4 + km * 2 + qn) * 256) + (4 * qq + r) * 16 + tpos(x)] = dS[km][qn][r];
+                        tbuf[((km * 2 + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = P[km][qn][r];
+                        tbuf[((4 + km * 2 + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = dS[km][qn][r];
                     }
             wave_sync();
             // dV[key][c] = sum_queries P[key][query] dO[query][c];  dK[key][c] = scale * sum_queries dS[key][query] Q[query][c]
@@ -319,8 +322,8 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
                     for (int qn = 0; qn < 2; ++qn) {
                         if (qn >= QT) continue;
-                        const f32x4 pt = *reinterpret_cast<const f32x4*>(tbuf + (km * 2 + qn) * 256 + x * 16 + 4 * qq);
-                        const f32x4 st = *reinterpret_cast<const f32x4*>(tbuf + (4 + km * 2 + qn) * 256 + x * 16 + 4 * qq);
+                        const f32x4 pt = *reinterpret_cast<const f32x4*>(tbuf + (km * 2 + qn) * 16 * kTP + x * kTP + 4 * qq);
+                        const f32x4 st = *reinterpret_cast<const f32x4*>(tbuf + (4 + km * 2 + qn) * 16 * kTP + x * kTP + 4 * qq);
                         dv = mfma4(ga[qn], pt, dv);
                         dk = mfma4(qa[qn], st, dk);
                     }
