@@ -93,16 +93,28 @@ class _GruWideFn(torch.autograd.Function):
             if dh0 is not None:
                 g_h0[:, l] = dh0
             dgi2, dgh2 = dgi.view(B * L, 3 * H), dgh.view(B * L, 3 * H)
-            ones = torch.ones(1, B * L, dtype=dt, device=dev)      # column sums as library products (fixed order)
             # h_{t-1} of every step: the state one step earlier (held at the initial state before a row's first step)
             h_first = (h0[:, l] if h0 is not None else torch.zeros(B, H, dtype=dt, device=dev)).unsqueeze(1)
             h_prev = torch.cat([h_first, h_raw[:, :-1]], dim=1).reshape(B * L, H)
-            if ctx.needs_input_grad[4 + 4 * l]:
-                g_w[4 * l] = dgi2.t() @ inp.reshape(B * L, -1)
-                g_w[4 * l + 2] = (ones @ dgi2).view(-1)
-            if ctx.needs_input_grad[4 + 4 * l + 1]:
-                g_w[4 * l + 1] = dgh2.t() @ h_prev
-                g_w[4 * l + 3] = (ones @ dgh2).view(-1)
+            inp2 = inp.reshape(B * L, -1)
+            if native.xty_supported(B * L, 3 * H, max(inp2.shape[1], H)):
+                # weight and bias gradients as products over the B * L rows, one MFMA launch each (`asac_xty`)
+                if ctx.needs_input_grad[4 + 4 * l]:
+                    g_w[4 * l] = torch.empty(3 * H, inp2.shape[1], dtype=dt, device=dev)
+                    g_w[4 * l + 2] = torch.empty(3 * H, dtype=dt, device=dev)
+                    native.xty(dgi2, inp2 if inp2.stride(1) == 1 else inp2.contiguous(), g_w[4 * l], g_w[4 * l + 2])
+                if ctx.needs_input_grad[4 + 4 * l + 1]:
+                    g_w[4 * l + 1] = torch.empty(3 * H, H, dtype=dt, device=dev)
+                    g_w[4 * l + 3] = torch.empty(3 * H, dtype=dt, device=dev)
+                    native.xty(dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3])
+            else:
+                ones = torch.ones(1, B * L, dtype=dt, device=dev)      # column sums as library products (fixed order)
+                if ctx.needs_input_grad[4 + 4 * l]:
+                    g_w[4 * l] = dgi2.t() @ inp2
+                    g_w[4 * l + 2] = (ones @ dgi2).view(-1)
+                if ctx.needs_input_grad[4 + 4 * l + 1]:
+                    g_w[4 * l + 1] = dgh2.t() @ h_prev
+                    g_w[4 * l + 3] = (ones @ dgh2).view(-1)
             from_above = None
             if l > 0 or ctx.needs_input_grad[0]:
                 from_above = (dgi2 @ w_ih).view(B, L, -1)

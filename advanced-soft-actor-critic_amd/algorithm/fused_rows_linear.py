@@ -1,0 +1,50 @@
+"""`nn.Linear` over thousands of rows with its parameter gradients from ONE MFMA launch.
+
+The building blocks of the plugin surface (`LinearLayers`, `ResBlock`, the attention projections) apply `nn.Linear(K <= 128,
+O <= 128)` to every row of the sampled windows: 9 216 ... 20 736 rows a pass.  Forward and input gradient are library GEMMs
+that suit their shape; the WEIGHT gradient grad_out^T x is a [O x K] product over the rows for which the library picks a
+32 x 6-style tile (measured 46-76 us per layer at 9 216 rows), and the bias gradient is an ATen split reduction plus the
+memset node that zeroes its semaphores.  `rows_linear` keeps the module (parameters, `state_dict`, the forward GEMM) and
+replaces the backward: `asac_xty` forms grad_weight and grad_bias in one launch (fixed summation order) — reference
+nn_models/layers/linear_layers.py:24-119 under autograd.
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get('ASAC_ROWS_LINEAR', '1') != '0'      # (0: plain nn.Linear — A/B runs)
+MIN_ROWS = 2048
+
+
+class _RowsLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.lead = x.shape[:-1]
+        return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        from asac_amd import native
+        x2, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        if g2.stride(1) != 1:
+            g2 = g2.contiguous()
+        gx = (g2 @ weight).view(*ctx.lead, weight.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
+            native.xty(g2, x2, gw, gb)
+        return gx, gw, gb
+
+
+def rows_linear(linear: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """`linear(x)`; on the device, over >= MIN_ROWS rows of a trainable layer of <= 128 x 128 features, with the
+    one-launch parameter gradients"""
+    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and linear.bias is not None
+            and linear.weight.requires_grad and linear.bias.requires_grad and linear.in_features <= 128
+            and linear.out_features <= 128 and x.dim() >= 2 and x.shape[-1] == linear.in_features
+            and x.numel() // linear.in_features >= MIN_ROWS and x.stride(-1) == 1):
+        return _RowsLinearFn.apply(x, linear.weight, linear.bias)
+    return linear(x)

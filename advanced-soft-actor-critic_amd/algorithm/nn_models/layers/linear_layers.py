@@ -7,6 +7,7 @@ keys: `dense.<2i>.linear.{weight,bias}`, final `dense.<2d>.{weight,bias}`) and i
 interchangeable.  The dense contractions run on rocBLAS/hipBLASLt (MFMA); the step's non-GEMM
 work is what the HIP kernels of this package fuse.
 """
+import torch
 from torch import nn
 
 __all__ = ['ResBlock', 'LinearLayers']
@@ -30,7 +31,8 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         assert x.shape[-1] == self.linear.in_features
-        y = self.act(self.linear(x))
+        from algorithm.fused_rows_linear import rows_linear      # lazy: avoids an import cycle
+        y = self.act(rows_linear(self.linear, x))
         return y + x if self.residual else y
 
 
@@ -66,4 +68,11 @@ class LinearLayers(nn.Module):
             out = fused_dense(self, x)    # one launch per pass (csrc/mlp.hip) when the stack and its buffers fit
             if out is not None:
                 return out
+        if x.is_cuda and torch.is_grad_enabled():
+            # the stack module by module: a plain Linear over thousands of rows takes its parameter gradients from one
+            # launch (`fused_rows_linear`); everything else is called as the Sequential would
+            from algorithm.fused_rows_linear import rows_linear
+            for mod in self.dense:
+                x = rows_linear(mod, x) if type(mod) is nn.Linear else mod(x)
+            return x
         return self.dense(x)

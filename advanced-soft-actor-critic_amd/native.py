@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 62
+ABI_VERSION = 63
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -300,6 +300,10 @@ _SIGNATURES = {
     'asac_normal_nll_kl_logstd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int64,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    'asac_xty_supported': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
+    'asac_xty_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    'asac_xty': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                           C.c_int, C.c_void_p, C.c_void_p]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -1801,3 +1805,27 @@ def attention_mh_backward(q, k, v, mask, heads, p_heads, grad_out, grad_weights,
     _check(load().asac_attention_mh_backward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(p_heads),
                                              _p(grad_out), _p(grad_weights), _p(grad_q), _p(grad_k), _p(grad_v), _stream()),
            'asac_attention_mh_backward')
+
+
+# ------------------------------------------------------------------------------------------------
+# products over the rows of two tall matrices (csrc/xty.hip)
+# ------------------------------------------------------------------------------------------------
+def xty_supported(rows, M, N) -> bool:
+    return bool(load().asac_xty_supported(int(rows), int(M), int(N)))
+
+
+@_profiled
+def xty(x, y, out, colsum_x=None, accumulate=False):
+    """out [M, N] (+)= x^T y over the rows of x [R, M] and y [R, N] (row strides allowed, dense last dim);
+    colsum_x [M] (+)= the column sums of x"""
+    global _last_work
+    R, M = x.shape
+    N = y.shape[1]
+    assert y.shape[0] == R and x.stride(1) == 1 and y.stride(1) == 1 and out.shape == (M, N) and out.is_contiguous()
+    assert x.dtype == y.dtype == out.dtype == torch.float32 and x.is_cuda
+    _last_work = 2.0 * R * M * N
+    ws = torch.empty(int(load().asac_xty_workspace(R, M, N)), dtype=torch.float32, device=x.device)
+    if colsum_x is not None:
+        assert colsum_x.numel() == M and colsum_x.is_contiguous()
+    _check(load().asac_xty(_p(x), x.stride(0), M, _p(y), y.stride(0), N, R, _p(out), _p(colsum_x), int(bool(accumulate)), _p(ws),
+                           _stream()), 'asac_xty')

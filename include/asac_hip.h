@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 62
+#define ASAC_ABI_VERSION 63
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -1072,6 +1072,17 @@ int asac_normal_nll_kl_logstd(const float* mean_logstd, int64_t stride_b, int64_
                               const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T, int K,
                               float kl_weight, float* grad_mean_logstd, float* loss_entropy_out, float* workspace,
                               void* stream);
+
+/* Products over the ROWS of two tall matrices (csrc/xty.hip, f32 MFMA):  out [M][N] = sum_r x[r][m] y[r][n]  and, optionally,
+ * colsum_x [M] = sum_r x[r][m] — the weight and bias gradients of a Linear over thousands of rows (x = grad_out, y = input:
+ * `nn.Linear` backward inside `LinearLayers` / `ResBlock`, nn_models/layers/linear_layers.py:24-119; the attention
+ * projections, seq_layers.py:239-333) and the input / recurrent weight gradients of the GRU (seq_layers.py:14-114) at the widths
+ * of the reference's environments (M <= 512, N <= 128).  Row strides in floats; accumulate != 0 adds to out / colsum_x;
+ * fixed summation order (per-workgroup partials in `workspace`, asac_xty_workspace floats, summed in workgroup order). */
+int asac_xty_supported(int64_t rows, int M, int N);
+int64_t asac_xty_workspace(int64_t rows, int M, int N);
+int asac_xty(const float* x, int64_t x_row_stride, int M, const float* y, int64_t y_row_stride, int N, int64_t rows, float* out,
+             float* colsum_x, int accumulate, float* workspace, void* stream);
 
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with
