@@ -106,7 +106,12 @@ def describe_q(q) -> 'native.MlpDesc | None':
     blocks, final = parsed
     desc, offs = native.MlpDesc(), _offsets(q)
     desc.in0, desc.in1 = q.state_size, q.c_action_size
-    if desc.in0 + desc.in1 > MAX_WIDTH or _fill_blocks(desc, blocks, offs, desc.in0 + desc.in1) is None:
+    k0 = desc.in0 + desc.in1
+    # (a first layer of up to 128 inputs — critics on a 64-wide state + the action — with <= 3 blocks, the first not residual:
+    # the wide instantiations of the forward / backward kernels, one launch per network; the one-launch chains need <= 64)
+    if k0 > MAX_INPUT or (k0 > MAX_WIDTH and (len(blocks) > 3 or blocks[0].residual)):
+        return None
+    if _fill_blocks(desc, blocks, offs, k0) is None:
         return None
     desc.head_cols[0], desc.head_cols[1] = 1, 0
     desc.head_w_off[0], desc.head_b_off[0] = offs[id(final.weight)], offs[id(final.bias)]
@@ -291,6 +296,7 @@ class StockMLP:
         """`param_tensors`: the networks' `nn.Parameter`s (views of `flat`, member by member) — the autograd inputs
         of the differentiable calls; may stay empty for inference-only instances"""
         self.desc, self.E, self.member_stride = desc, E, member_stride
+        self.wide = desc.in0 + desc.in1 > MAX_WIDTH      # first layer wider than 64 inputs: single-network launches only
         self.param_tensors = list(param_tensors)
         self.params = flat[start:start + E * member_stride]
         self.grad_params = None if grad_flat is None else grad_flat[start:start + E * member_stride]
@@ -424,6 +430,8 @@ class StockMLP:
     def job(self, x0, x1, out=None):
         """A forward pass of this network as one job of `native.mlp_forward_multi` -> (job, out)."""
         N = x0.shape[0] if isinstance(x0, native.WindowRows) else x0.shape[-2]
+        if self.wide and isinstance(x0, native.WindowRows):      # (the wide forward has no window addressing)
+            x0 = x0.t.reshape(N, x0.t.shape[-1])
         if out is None:
             out = torch.empty((self.E, N, self.out_cols), dtype=torch.float32, device=self.device)
         assert out.shape == (self.E, N, self.out_cols) and out.is_contiguous()

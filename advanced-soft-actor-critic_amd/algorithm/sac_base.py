@@ -453,6 +453,11 @@ class SAC_Base(AuxHeadsMixin):
             if dp is not None:
                 self._fpi = StockMLP(dp, self._params.flat, self._params.grad, seg['policy'][0],
                                      seg['policy'][1] - seg['policy'][0], 1, dev, list(self.model_policy.parameters()))
+        if self._fq is not None and self._fq.wide:
+            # critics whose first layer is wider than 64 inputs (64-wide state + action): one launch per network pass, the
+            # chains that pack several networks / sidecar jobs into one launch are not taken
+            self._use_sidecars = False
+            self._la_gather_sidecar = False
         self._logger.info(f'fused stock MLP path: Q={self._fq is not None} policy={self._fpi is not None}')
         # When the stock networks and the temperatures are the only trainable parameters, every gradient
         # slot is written exactly once per step by a kernel: overwrite instead of memset + accumulate.

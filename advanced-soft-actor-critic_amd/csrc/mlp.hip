@@ -2228,11 +2228,34 @@ int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const asac_si
     SidecarsDev sc{};
     if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_mlp_forward_multi: sidecar");
     int64_t groups16 = 0;       // workgroups of the whole launch with 16-row tiles
-    bool all_stock = true;
+    bool all_stock = true, any_wide = false;
+    for (int k = 0; k < n_jobs; ++k)
+        if (jobs[k].desc && desc_ok(*jobs[k].desc) && jobs[k].desc->in0 + jobs[k].desc->in1 > kMaxW) any_wide = true;
+    if (any_wide) {
+        // a first layer wider than 64 inputs (critics on a 64-wide state + the action): the jobs go one launch each through
+        // the wide instantiation of the single-network forward; no window addressing, no sidecars there
+        if (n_sidecars > 0) return bad_arg("asac_mlp_forward_multi: sidecars beside a wide job");
+        for (int k = 0; k < n_jobs; ++k) {
+            const asac_mlp_job_t& j = jobs[k];
+            if (j.desc && desc_ok(*j.desc) && j.desc->in0 + j.desc->in1 <= kMaxW) {       // a narrow job beside a wide one
+                if (int rc = asac_mlp_forward_multi(&j, 1, nullptr, 0, stream)) return rc;
+                continue;
+            }
+            if (!j.desc || !desc_ok(*j.desc) || j.E <= 0 || j.N <= 0 || !j.x0 || (j.desc->in1 > 0 && !j.x1) || !j.out ||
+                j.x0_window_T != 0)
+                return bad_arg("asac_mlp_forward_multi: wide job");
+            if (int rc = asac_mlp_forward(j.desc, static_cast<const float*>(j.params), j.member_stride, j.E,
+                                          static_cast<const float*>(j.x0), j.x0_row_stride, j.x0_member_stride,
+                                          static_cast<const float*>(j.x1), j.x1_row_stride, j.x1_member_stride, j.N,
+                                          static_cast<float*>(j.out), stream))
+                return rc;
+        }
+        return 0;
+    }
     for (int k = 0; k < n_jobs; ++k) {
         const asac_mlp_job_t& j = jobs[k];
         if (!j.desc || !desc_ok(*j.desc) || j.desc->in0 + j.desc->in1 > kMaxW)
-            return bad_arg("asac_mlp_forward_multi: job");          // (wide inputs: asac_mlp_forward only)
+            return bad_arg("asac_mlp_forward_multi: job");
         if (j.E <= 0 || j.N <= 0 || !j.x0 || (j.desc->in1 > 0 && !j.x1) || !j.out || j.x0_window_T < 0)
             return bad_arg("asac_mlp_forward_multi: job");
         groups16 += ((j.N + 15) / 16) * j.E;
