@@ -31,9 +31,11 @@ def _setup(E, state, A, policy=False):
     return mods, group, mlp
 
 
-@pytest.mark.parametrize('N', [256, 1280, 100, 33, 12345])    # 12345 rows: workgroups loop over row tiles
-def test_q_ensemble_forward_backward(N):
-    E, S, A = 3, 6, 2
+# (S = 64: critics on a 64-wide state + the action — a first layer of 66 inputs, the wide instantiations of the kernels,
+#  the reference environments' `m.GRU(..., 64, 1)` states)
+@pytest.mark.parametrize('N,S', [(256, 6), (1280, 6), (100, 6), (33, 6), (12345, 6), (256, 64), (1000, 64), (33, 126)])
+def test_q_ensemble_forward_backward(N, S):     # 12345 rows: workgroups loop over row tiles
+    E, A = 3, 2
     mods, group, mlp = _setup(E, S, A)
     x = torch.randn(N, S, device='cuda', requires_grad=True)
     a = torch.randn(N, A, device='cuda').tanh().requires_grad_()
@@ -46,7 +48,7 @@ def test_q_ensemble_forward_backward(N):
     x.grad = a.grad = None
     group.grad.zero_()
     out = mlp(x, a)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-6 if S <= 16 else 6e-6)
     (out * gout).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), ref_gx.cpu().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(a.grad.cpu().numpy(), ref_ga.cpu().numpy(), rtol=1e-4, atol=1e-5)
@@ -66,7 +68,7 @@ def test_q_ensemble_forward_backward(N):
     a3 = torch.randn(E, N, A, device='cuda')
     out = mlp(xs, a3, param_grads=False)
     ref = torch.stack([q(xs, a3[i], None)[1] for i, q in enumerate(mods)])
-    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-5, atol=2e-6 if S <= 16 else 6e-6)
 
 
 @pytest.mark.parametrize('N,weighted', [(256, True), (100, False), (33, True)])
@@ -429,3 +431,20 @@ def test_fused_dense_stack_matches_modules(N, in_size, widths, out):
     with native.LaunchProfiler() as prof:
         ref(x)          # parameters are separate allocations: no flat alias
     assert 'asac_mlp_forward' not in prof.summary()
+
+
+def test_wide_job_beside_a_narrow_one_goes_launch_by_launch():
+    """`mlp_forward_multi` with a critic whose first layer is wider than 64 inputs: the jobs are issued one launch each
+    (the narrow one keeps its window addressing), results those of the single-network forward"""
+    from asac_amd import native
+    _, _, fq = _setup(2, 64, 2)
+    _, _, fpi = _setup(1, 8, 2, policy=True)
+    assert fq.wide and not fpi.wide
+    B, T = 40, 5
+    xs, a = torch.randn(B * T, 64, device='cuda'), torch.randn(B * T, 2, device='cuda').tanh()
+    base = torch.randn(B, T + 2, 8, device='cuda')
+    job_q, q_out = fq.job(xs, a)
+    job_pi, pi_out = fpi.job(native.WindowRows(base[:, 2:]), None)
+    native.mlp_forward_multi([job_q, job_pi])
+    assert torch.equal(q_out, fq._launch_forward(xs, a))
+    assert torch.equal(pi_out, fpi._launch_forward(base[:, 2:].reshape(B * T, 8), None))
