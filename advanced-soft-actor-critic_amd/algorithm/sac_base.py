@@ -266,7 +266,7 @@ class SAC_Base(AuxHeadsMixin):
         self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
         self._fused_q_loss_with_aux = bool(hip_config.get('fused_q_loss_with_aux', True))
         self._head_sums_members = bool(hip_config.get('head_sums_members', True))
-        self._rep_epilogue = False      # (False: not looked at yet; None: not applicable)
+        self._rep_epilogue, self._rep_epilogue_hp = False, None      # (False: not looked at yet; None: not applicable)
         self._cat_mode = None
         self._g_state_base = None
         self._vtrace_sidecars = self._pending_alpha = None
@@ -1226,7 +1226,7 @@ class SAC_Base(AuxHeadsMixin):
                 # one GPU: the critics' tile reduction is folded into their Adam launch (as without a trainable
                 # representation), which then no longer waits for the representation's backward
                 opt = self.optimizer_q_list[0]
-                fold = self._dist is None and self._fold_rep_q_adam
+                fold = self._dist is None and self._fold_rep_q_adam and self._rep_q_adam_alike()
                 if ret is not None and self._fq.backward_qloss_return_ok(x0.shape[-2], ret[0]):
                     # (short windows: the return target is formed by the backward's own workgroups, no launch of its own)
                     g0 = self._fq.backward_qloss_return(x0, a0, t_q.view(self.ensemble_q_num, -1), ret[0], w,
@@ -1314,11 +1314,18 @@ class SAC_Base(AuxHeadsMixin):
                                   dict(n_padding_masks=n_padding_masks, nx_obses_list=nx_obses_list,
                                        nx_states=nx_states, nx_actions=nx_actions, n_rewards=n_rewards))
 
+    def _rep_q_adam_alike(self) -> bool:
+        """the representation's and the critics' optimizers have the same hyper-parameters: only then may ONE Adam launch
+        step both spans (`fold_rep_q_adam`); a schedule or a user edit that moves one of them un-folds the step"""
+        a, b = self.optimizer_rep, self.optimizer_q_list[0]
+        return a is None or (a.lr, tuple(a.betas), a.eps) == (b.lr, tuple(b.betas), b.eps)
+
     def _rep_adam_epilogue(self):
         """-> `native.adam_epilogue` for the representation's parameters when they are exactly one fused GRU layer's
         cell weights (then the launch that finishes their gradients can step them), else None"""
-        if self._rep_epilogue is False:
-            self._rep_epilogue = None
+        hp = (self.optimizer_rep.lr, *self.optimizer_rep.betas, self.optimizer_rep.eps) if self.optimizer_rep is not None else None
+        if self._rep_epilogue is False or self._rep_epilogue_hp != hp:      # (a changed learning rate rebuilds it)
+            self._rep_epilogue, self._rep_epilogue_hp = None, hp
             from .nn_models.layers.seq_layers import GRU
             grus = [m for m in self.model_rep.modules() if isinstance(m, GRU)]
             opt, (s, e) = self.optimizer_q_list[0], self._params.span('rep')
