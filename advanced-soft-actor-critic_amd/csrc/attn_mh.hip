@@ -4,7 +4,8 @@
 // envs/gym/toy_queue/nn_attn.py:28-45) — csrc/attn.hip (one lane per (batch, query) row) covers one head of <= 16 channels.
 // The q / k / v / output projections around it are plain Linears: library GEMMs on the host side (seq_layers.py here).
 //
-// One wave owns a batch entry and walks its heads (so the head average of the weights is a register sum, in head order).
+// One workgroup (4 waves) owns a batch entry; wave w walks heads w, w + 4, ... (the head average of the weights: per-wave
+// register sums, added in wave order through LDS).
 // Per head, with windows of <= 32 positions as <= 2 x 2 tiles of 16 and the QUERIES as the N dimension:
 //   S[key][query]  = K Q^T       A = a key row's 16 bytes of channels, B = a query row's (x 1/sqrt(d))
 //   P = softmax over the keys: the keys of a query live in 4 registers x 4 lanes x <= 2 tiles -> two shuffles
@@ -20,7 +21,7 @@ namespace asac {
 namespace amh {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int kThreads = 256;      // 4 waves = 4 batch entries
+constexpr int kThreads = 256;      // 4 waves = the heads of one batch entry, dealt round robin
 constexpr int kMaxL = 32;
 constexpr int kTP = 20;             // LDS pitch of a turned tile's rows
 
@@ -79,8 +80,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     // lane quarters of a store then fall into four different 16-bank groups, rows stay 16-byte aligned for the b128 reads
     __shared__ float s_t[4][8][16 * kTP];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, qq = l >> 4, x = l & 15;
-    const int b = blockIdx.x * 4 + wv;
-    if (b >= a.B) return;
+    const int b = blockIdx.x;
     const int Lq = a.Lq, Lk = a.Lk, H = a.H, d = a.d, E = H * d;
     const int QT = (Lq + 15) >> 4, KT = (Lk + 15) >> 4, CT = (d + 15) >> 4;
     const float scale = 1.f / sqrtf((float)d);
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         for (int qn = 0; qn < 2; ++qn) wsum[km][qn] = zero4();
     float* tbuf = &s_t[wv][0][0];
 
-    for (int h = 0; h < H; ++h) {
+    for (int h = wv; h < H; h += 4) {
         const int hc = h * d;
         f32x4 P[2][2];
         if (!BWD) {
@@ -341,6 +341,14 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         }
     }
     if (!BWD) {
+        // the waves' sums over their heads, added in wave order by wave 0 (s_t is free in the forward)
+        f32x4* ws = reinterpret_cast<f32x4*>(&s_t[0][0][0]);
+#pragma unroll
+        for (int km = 0; km < 2; ++km)
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) ws[(wv * 4 + km * 2 + qn) * 64 + l] = wsum[km][qn];
+        __syncthreads();
+        if (wv != 0) return;
         const float invH = 1.f / (float)H;
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn) {
@@ -349,12 +357,16 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             const float kp = dead[qn] ? 0.f : 1.f;
             if (qq == 0) a.keep[(int64_t)b * Lq + qi] = kp;
 #pragma unroll
-            for (int km = 0; km < 2; ++km)
+            for (int km = 0; km < 2; ++km) {
+                f32x4 t = wsum[km][qn];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) t += ws[(w2 * 4 + km * 2 + qn) * 64 + l];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kj = 16 * km + 4 * qq + r;
-                    if (kj < Lk) a.w_avg[((int64_t)b * Lq + qi) * Lk + kj] = wsum[km][qn][r] * invH * kp;
+                    if (kj < Lk) a.w_avg[((int64_t)b * Lq + qi) * Lk + kj] = t[r] * invH * kp;
                 }
+            }
         }
     }
 }
@@ -379,7 +391,7 @@ int asac_attention_mh_forward(const float* q, const float* k, const float* v, co
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = weights, a.keep = keep, a.p_heads = p_heads;
-    ASAC_LAUNCH(k_attn_mh<false>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, as_stream(stream), a);
+    ASAC_LAUNCH(k_attn_mh<false>, dim3((unsigned)B), dim3(kThreads), 0, as_stream(stream), a);
     return finish_launch("asac_attention_mh_forward");
 }
 
@@ -394,7 +406,7 @@ int asac_attention_mh_backward(const float* q, const float* k, const float* v, c
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim;
     a.p_heads = const_cast<float*>(p_heads), a.g_out = grad_out, a.g_w = grad_weights, a.g_q = grad_q, a.g_k = grad_k, a.g_v = grad_v;
-    ASAC_LAUNCH(k_attn_mh<true>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, as_stream(stream), a);
+    ASAC_LAUNCH(k_attn_mh<true>, dim3((unsigned)B), dim3(kThreads), 0, as_stream(stream), a);
     return finish_launch("asac_attention_mh_backward");
 }
 

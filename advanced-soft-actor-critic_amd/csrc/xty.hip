@@ -67,17 +67,29 @@ __global__ void __launch_bounds__(kThreads) k_xty(const Args a) {
     if (q == 0 && m_on) part[(int64_t)a.M * a.N + m0 + c] = csum;
 }
 
-// out[i] (+)= sum over the workgroups' partials, in workgroup order; the first M * N entries go to `out`, the M after them to
-// `colsum` (skipped when NULL)
-__global__ void __launch_bounds__(256) k_xty_reduce(const float* __restrict__ part, int blocks, int mn, int m,
-                                                    float* __restrict__ out, float* __restrict__ colsum, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= mn + m) return;
+// out[i] (+)= sum over the workgroups' partials in a fixed order: 16 slices of the workgroup list summed side by side (slice
+// s takes workgroups s, s + 16, ...: the loads of a thread are independent), then the slices in order; the first M * N entries
+// go to `out`, the M after them to `colsum` (skipped when NULL)
+constexpr int kRedSlices = 16;
+__global__ void __launch_bounds__(64 * kRedSlices) k_xty_reduce(const float* __restrict__ part, int blocks, int mn, int m,
+                                                               float* __restrict__ out, float* __restrict__ colsum,
+                                                               int accumulate) {
+    __shared__ float red[kRedSlices][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (i < mn + m)
+#pragma unroll 8
+        for (int g = sl; g < blocks; g += kRedSlices) s += part[(int64_t)g * (mn + m) + i];
+    red[sl][o] = s;
+    __syncthreads();
+    if (sl != 0 || i >= mn + m) return;
     float* dst = i < mn ? out + i : (colsum ? colsum + (i - mn) : nullptr);
     if (!dst) return;
-    float s = 0.f;
-    for (int g = 0; g < blocks; ++g) s += part[(int64_t)g * (mn + m) + i];
-    *dst = accumulate ? *dst + s : s;
+    float t = red[0][o];
+#pragma unroll
+    for (int q = 1; q < kRedSlices; ++q) t += red[q][o];
+    *dst = accumulate ? *dst + t : t;
 }
 
 inline int row_blocks(int64_t rows) {
@@ -117,7 +129,7 @@ int asac_xty(const float* x, int64_t x_row_stride, int M, const float* y, int64_
     else ASAC_LAUNCH(k_xty<8>, grid, dim3(kThreads), 0, s, a);
     const int total = M * N + M;
     // launched once (not under the measurement repeat knob: it may accumulate)
-    hipLaunchKernelGGL(k_xty_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, blocks, M * N, M, out,
+    hipLaunchKernelGGL(k_xty_reduce, dim3((unsigned)((total + 63) / 64)), dim3(64 * kRedSlices), 0, s, workspace, blocks, M * N, M, out,
                        colsum_x, accumulate);
     return finish_launch("asac_xty");
 }

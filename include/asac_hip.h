@@ -888,7 +888,7 @@ int asac_obs_decoder_backward(const float* state, int64_t state_stride, int64_t 
  *   mean over the heads of softmax(s) * keep;  keep [B][Lq] = 1 - dead;  p_heads [B][heads][Lq][Lk] (or NULL): every head's
  *   softmax, saved for the backward.
  * Backward: grad_out [B][Lq][E], grad_weights [B][Lq][Lk] (w.r.t. the returned weights) or NULL -> grad_q / grad_k / grad_v.
- * One wave per batch entry, heads in order: deterministic.
+ * One workgroup per batch entry, its heads dealt over four waves; sums in a fixed order: deterministic.
  * ------------------------------------------------------------------------------------------- */
 int asac_attention_mh_supported(int Lq, int Lk, int heads, int head_dim);
 int asac_attention_mh_forward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
