@@ -22,6 +22,7 @@ class _RowsLinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, weight)
         ctx.lead = x.shape[:-1]
+        ctx.weight_param, ctx.bias_param = weight, bias
         return torch.addmm(bias, x2, weight.t()).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -34,8 +35,16 @@ class _RowsLinearFn(torch.autograd.Function):
         gx = (g2 @ weight).view(*ctx.lead, weight.shape[1]) if ctx.needs_input_grad[0] else None
         gw = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
-            native.xty(g2, x2, gw, gb)
+            from algorithm.fused_mlp import direct_enabled
+            w_grad, b_grad = ctx.weight_param.grad, ctx.bias_param.grad
+            if (direct_enabled() and w_grad is not None and b_grad is not None and w_grad.is_contiguous()
+                    and b_grad.is_contiguous()):
+                # `loss.backward()` of the learner's step: added straight into the `.grad` views of the flat buffer (no
+                # gradient tensors handed to autograd, no accumulation launches)
+                native.xty(g2, x2, w_grad, b_grad, accumulate=True)
+            else:
+                gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
+                native.xty(g2, x2, gw, gb)
         return gx, gw, gb
 
 
