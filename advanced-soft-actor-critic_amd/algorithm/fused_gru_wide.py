@@ -26,7 +26,9 @@ def fused_gru_wide_supported(x: torch.Tensor, cells) -> bool:
 
 class _GruWideFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, padding_mask, grad_mode, *weights):
+    def forward(ctx, x, h0, padding_mask, grad_mode, twin, *weights):
+        """`twin`: None, or a list holding the target copy's cell weights (one layer): its recurrence runs in the same
+        launch over the same windows and its (output, hn) are appended to the list for the caller to park"""
         B, L, _ = x.shape
         layers = len(weights) // 4
         H = weights[1].shape[1]
@@ -37,7 +39,28 @@ class _GruWideFn(torch.autograd.Function):
             mask = mask.contiguous()
         if h0 is not None and h0.stride(2) != 1:
             h0 = h0.contiguous()
-        need_grad = grad_mode and (any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[4:]))
+        need_grad = grad_mode and (any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[5:]))
+        if twin is not None:
+            # one layer, two networks: the input products side by side in one [2B, L, 3H] buffer, ONE recurrence launch
+            w_ih, w_hh, b_ih, b_hh = (t.detach() for t in weights[:4])
+            tw_ih, tw_hh, tb_ih, tb_hh = (t.detach() for t in twin[0])
+            x2 = x.reshape(B * L, -1)
+            gi2 = torch.empty(2 * B, L, 3 * H, dtype=x.dtype, device=x.device)
+            torch.addmm(b_ih, x2, w_ih.t(), out=gi2[:B].view(B * L, 3 * H))
+            torch.addmm(tb_ih, x2, tw_ih.t(), out=gi2[B:].view(B * L, 3 * H))
+            hn2 = torch.empty(2 * B, L, 1, H, dtype=x.dtype, device=x.device)
+            h_raw = torch.empty(B, L, H, dtype=x.dtype, device=x.device) if need_grad else None
+            gates = torch.empty(B, L, 4 * H, dtype=x.dtype, device=x.device) if need_grad else None
+            native.gru_wide_forward_twin(gi2, w_hh.contiguous(), b_hh.contiguous(), tw_hh.contiguous(), tb_hh.contiguous(),
+                                         None if h0 is None else h0[:, 0], mask, hn2[:, :, 0], h_raw, gates)
+            hn, t_hn = hn2[:B], hn2[B:]
+            twin += [t_hn[:, :, 0], t_hn]
+            if need_grad:
+                ctx.layers, ctx.H = 1, H
+                ctx.has_h0, ctx.has_mask = h0 is not None, mask is not None
+                ctx.save_for_backward(x, h_raw, gates, *([h0] if h0 is not None else []), *([mask] if mask is not None else []),
+                                      *weights)
+            return hn[:, :, 0], hn
         hn = torch.empty(B, L, layers, H, dtype=x.dtype, device=x.device)
         saved, inp = [], x
         for l in range(layers):
@@ -60,7 +83,7 @@ class _GruWideFn(torch.autograd.Function):
     def backward(ctx, grad_out, grad_hn):
         layers, H = ctx.layers, ctx.H
         if grad_out is None and grad_hn is None:
-            return (None,) * (4 + 4 * layers)
+            return (None,) * (5 + 4 * layers)
         saved = list(ctx.saved_tensors)
         per_layer = [saved[3 * l:3 * l + 3] for l in range(layers)]
         rest = saved[3 * layers:]
@@ -99,34 +122,48 @@ class _GruWideFn(torch.autograd.Function):
             inp2 = inp.reshape(B * L, -1)
             if native.xty_supported(B * L, 3 * H, max(inp2.shape[1], H)):
                 # weight and bias gradients as products over the B * L rows, one MFMA launch each (`asac_xty`)
-                if ctx.needs_input_grad[4 + 4 * l]:
+                if ctx.needs_input_grad[5 + 4 * l]:
                     g_w[4 * l] = torch.empty(3 * H, inp2.shape[1], dtype=dt, device=dev)
                     g_w[4 * l + 2] = torch.empty(3 * H, dtype=dt, device=dev)
                     native.xty(dgi2, inp2 if inp2.stride(1) == 1 else inp2.contiguous(), g_w[4 * l], g_w[4 * l + 2])
-                if ctx.needs_input_grad[4 + 4 * l + 1]:
+                if ctx.needs_input_grad[5 + 4 * l + 1]:
                     g_w[4 * l + 1] = torch.empty(3 * H, H, dtype=dt, device=dev)
                     g_w[4 * l + 3] = torch.empty(3 * H, dtype=dt, device=dev)
                     native.xty(dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3])
             else:
                 ones = torch.ones(1, B * L, dtype=dt, device=dev)      # column sums as library products (fixed order)
-                if ctx.needs_input_grad[4 + 4 * l]:
+                if ctx.needs_input_grad[5 + 4 * l]:
                     g_w[4 * l] = dgi2.t() @ inp2
                     g_w[4 * l + 2] = (ones @ dgi2).view(-1)
-                if ctx.needs_input_grad[4 + 4 * l + 1]:
+                if ctx.needs_input_grad[5 + 4 * l + 1]:
                     g_w[4 * l + 1] = dgh2.t() @ h_prev
                     g_w[4 * l + 3] = (ones @ dgh2).view(-1)
             from_above = None
             if l > 0 or ctx.needs_input_grad[0]:
                 from_above = (dgi2 @ w_ih).view(B, L, -1)
         g_x = from_above if ctx.needs_input_grad[0] else None
-        return (g_x, g_h0, None, None, *g_w)
+        return (g_x, g_h0, None, None, None, *g_w)
 
 
-def fused_gru_wide(x, h0, padding_mask, cells):
-    """x [B, L, I]; h0 [B, layers, H] | None; padding_mask bool [B, L] | None -> (output [B, L, H], hn [B, L, layers, H])"""
-    weights = []
-    for c in cells:
-        weights += [c.weight_ih_l0, c.weight_hh_l0, c.bias_ih_l0, c.bias_hh_l0]
+def fused_gru_wide(x, h0, padding_mask, cells, layer=None):
+    """x [B, L, I]; h0 [B, layers, H] | None; padding_mask bool [B, L] | None -> (output [B, L, H], hn [B, L, layers, H]).
+    `layer` (the GRU module itself): inside the learner's `TwinPass` the online module's one-layer recurrence runs its
+    target namesake over the same windows in the same launch and parks the result (`fused_gru.TwinPass`)."""
+    from .fused_gru import TwinPass, _cell_weights
+    weights = _cell_weights(cells)
     if x.stride(2) != 1:
         x = x.contiguous()
-    return _GruWideFn.apply(x, h0, padding_mask, torch.is_grad_enabled(), *weights)
+    tp = TwinPass._active
+    if tp is not None and layer is not None and len(cells) == 1:
+        got = tp.claim(layer, x, h0, padding_mask,
+                       lambda: _GruWideFn.apply(x, h0, padding_mask, torch.is_grad_enabled(), None, *weights))
+        if got is not None:
+            return got
+        other = tp.wants(layer, x, h0)
+        if (other is not None and len(other._grus) == 1 and other._fusable and x.shape[0] % 16 == 0
+                and (other._grus[0].input_size, other._grus[0].hidden_size) == (cells[0].input_size, cells[0].hidden_size)):
+            twin = [_cell_weights(other._grus)]
+            res = _GruWideFn.apply(x, h0, padding_mask, torch.is_grad_enabled(), twin, *weights)
+            tp.parked[id(other)] = (x, h0, padding_mask, twin[1], twin[2])
+            return res
+    return _GruWideFn.apply(x, h0, padding_mask, torch.is_grad_enabled(), None, *weights)

@@ -76,7 +76,7 @@ class GRU(nn.Module):
             from algorithm.fused_gru_wide import fused_gru_wide, fused_gru_wide_supported
             if fused_gru_wide_supported(x, list(self._grus)):
                 # hidden 32 / 64 / 128: the recurrence of each layer as one MFMA launch (csrc/gru_wide.hip)
-                return fused_gru_wide(x, h0, padding_mask, list(self._grus))
+                return fused_gru_wide(x, h0, padding_mask, list(self._grus), layer=self)
 
         if h0 is not None:
             h0 = h0.transpose(0, 1).contiguous()  # [layers, batch, hidden]

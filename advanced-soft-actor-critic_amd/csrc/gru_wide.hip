@@ -55,6 +55,10 @@ struct FwdArgs {
     float* hraw;                                // [B][L][H] the unmasked state after every step, or NULL
     float* gates;                               // [B][L][4H]: r | z | n | W_hn h + b_hn, or NULL
     int32_t B, L;
+    // twin form (twin_B > 0): rows [twin_B, B) are the SAME windows under a second network's recurrent weights (the target
+    // representation beside the online one): gi / out hold 2 x twin_B rows, h0 / pad / hraw / gates twin_B rows
+    const float* w_hh2; const float* b_hh2;
+    int32_t twin_B;
 };
 
 // first unpadded step of a row (0 without a mask or when the whole row is padded)
@@ -73,6 +77,12 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
     const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
     const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
+    const bool second = a.twin_B > 0 && (int64_t)blockIdx.x * 16 >= a.twin_B;      // (workgroup-uniform: twin_B % 16 == 0)
+    const float* w_hh = second ? a.w_hh2 : a.w_hh;
+    const float* b_hh = second ? a.b_hh2 : a.b_hh;
+    const int64_t srow = second ? row - a.twin_B : row;      // the row of h0 / pad (shared by the two networks)
+    float* const hraw = second ? nullptr : a.hraw;
+    float* const gates = second ? nullptr : a.gates;
     f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
@@ -82,13 +92,13 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
         for (int gate = 0; gate < 3; ++gate) {
 #pragma unroll
             for (int kt = 0; kt < HB; ++kt)
-                wr[i][gate][kt] = *reinterpret_cast<const f32x4*>(a.w_hh + (int64_t)(gate * H + 16 * ub + x) * H + 16 * kt + 4 * q);
-            bh[i][gate] = *reinterpret_cast<const f32x4*>(a.b_hh + gate * H + 16 * ub + 4 * q);
+                wr[i][gate][kt] = *reinterpret_cast<const f32x4*>(w_hh + (int64_t)(gate * H + 16 * ub + x) * H + 16 * kt + 4 * q);
+            bh[i][gate] = *reinterpret_cast<const f32x4*>(b_hh + gate * H + 16 * ub + 4 * q);
         }
-        h[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + 16 * ub + 4 * q) : zero4();
+        h[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + srow * a.h0_sb + 16 * ub + 4 * q) : zero4();
         s_h[0][ub][l] = h[i];
     }
-    const int lead = lead_of(a.pad, a.pad_sb, row, a.L);
+    const int lead = lead_of(a.pad, a.pad_sb, srow, a.L);
     // the step's inputs are requested one step ahead
     f32x4 gi_n[NBW][3];
     uint8_t pad_n = 0;
@@ -101,7 +111,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
             for (int gate = 0; gate < 3; ++gate)
                 gi_n[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
         }
-        pad_n = a.pad ? a.pad[row * a.pad_sb + t] : 0;
+        pad_n = a.pad ? a.pad[srow * a.pad_sb + t] : 0;
     };
     request(0);
     __syncthreads();
@@ -146,9 +156,9 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
             if (live) {
                 const int col = 16 * ub + 4 * q;
                 *reinterpret_cast<f32x4*>(a.out + row * a.out_sb + t * a.out_st + col) = ov;
-                if (a.hraw) *reinterpret_cast<f32x4*>(a.hraw + (row * a.L + t) * H + col) = hv;
-                if (a.gates) {
-                    float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
+                if (hraw) *reinterpret_cast<f32x4*>(hraw + (row * a.L + t) * H + col) = hv;
+                if (gates) {
+                    float* gp = gates + (row * a.L + t) * (4 * H) + col;
                     *reinterpret_cast<f32x4*>(gp) = rg;
                     *reinterpret_cast<f32x4*>(gp + H) = zg;
                     *reinterpret_cast<f32x4*>(gp + 2 * H) = ng;
@@ -286,12 +296,36 @@ int asac_gru_wide_forward(const float* gi, int64_t gi_stride_b, int64_t gi_strid
     a.gi = gi, a.gi_sb = gi_stride_b, a.gi_st = gi_stride_t, a.w_hh = w_hh, a.b_hh = b_hh, a.h0 = h0, a.h0_sb = h0_stride_b;
     a.pad = padding_mask, a.pad_sb = mask_stride_b, a.out = out, a.out_sb = out_stride_b, a.out_st = out_stride_t;
     a.hraw = h_raw, a.gates = gates, a.B = B, a.L = L;
+    a.w_hh2 = a.b_hh2 = nullptr, a.twin_B = 0;
     const dim3 grid((unsigned)((B + 15) / 16)), block(kThreads);
     hipStream_t s = as_stream(stream);
     if (hidden == 32) ASAC_LAUNCH(k_gruw_fwd<2>, grid, block, 0, s, a);
     else if (hidden == 64) ASAC_LAUNCH(k_gruw_fwd<4>, grid, block, 0, s, a);
     else ASAC_LAUNCH(k_gruw_fwd<8>, grid, block, 0, s, a);
     return finish_launch("asac_gru_wide_forward");
+}
+
+int asac_gru_wide_forward_twin(const float* gi, int64_t gi_stride_b, int64_t gi_stride_t, const float* w_hh, const float* b_hh,
+                               const float* w_hh_twin, const float* b_hh_twin, const float* h0, int64_t h0_stride_b,
+                               const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, int hidden, float* out,
+                               int64_t out_stride_b, int64_t out_stride_t, float* h_raw, float* gates, void* stream) {
+    if (!gi || !w_hh || !b_hh || !w_hh_twin || !b_hh_twin || !out || B <= 0 || (B & 15) || L <= 0 ||
+        !asac_gru_wide_supported(hidden) || !aligned16(gi) || !aligned16(w_hh) || !aligned16(b_hh) || !aligned16(w_hh_twin) ||
+        !aligned16(b_hh_twin) || !aligned16(out) || (h0 && !aligned16(h0)) || (gi_stride_b & 3) || (gi_stride_t & 3) ||
+        (out_stride_b & 3) || (out_stride_t & 3) || (h0_stride_b & 3) || (h_raw && !aligned16(h_raw)) ||
+        (gates && !aligned16(gates)))
+        return bad_arg("asac_gru_wide_forward_twin");
+    FwdArgs a;
+    a.gi = gi, a.gi_sb = gi_stride_b, a.gi_st = gi_stride_t, a.w_hh = w_hh, a.b_hh = b_hh, a.h0 = h0, a.h0_sb = h0_stride_b;
+    a.pad = padding_mask, a.pad_sb = mask_stride_b, a.out = out, a.out_sb = out_stride_b, a.out_st = out_stride_t;
+    a.hraw = h_raw, a.gates = gates, a.B = 2 * B, a.L = L;
+    a.w_hh2 = w_hh_twin, a.b_hh2 = b_hh_twin, a.twin_B = B;
+    const dim3 grid((unsigned)(2 * B / 16)), block(kThreads);
+    hipStream_t s = as_stream(stream);
+    if (hidden == 32) ASAC_LAUNCH(k_gruw_fwd<2>, grid, block, 0, s, a);
+    else if (hidden == 64) ASAC_LAUNCH(k_gruw_fwd<4>, grid, block, 0, s, a);
+    else ASAC_LAUNCH(k_gruw_fwd<8>, grid, block, 0, s, a);
+    return finish_launch("asac_gru_wide_forward_twin");
 }
 
 int asac_gru_wide_backward(const float* grad_out, int64_t go_stride_b, int64_t go_stride_t, const float* w_hh_t,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 63
+ABI_VERSION = 64
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -364,6 +364,9 @@ _SIGNATURES = {
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_gru_wide_supported': (C.c_int, [C.c_int]),
+    'asac_gru_wide_forward_twin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_gru_wide_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -1751,6 +1754,23 @@ def gru_wide_forward(gi, w_hh, b_hh, h0, mask, out, h_raw, gates):
     _check(load().asac_gru_wide_forward(_p(gi), gi.stride(0), gi.stride(1), _p(w_hh), _p(b_hh), _p(h0),
                                         0 if h0 is None else h0.stride(0), pm, ms, B, L, H, _p(out), out.stride(0),
                                         out.stride(1), _p(h_raw), _p(gates), _stream()), 'asac_gru_wide_forward')
+
+
+@_profiled
+def gru_wide_forward_twin(gi2, w_hh, b_hh, w_hh_twin, b_hh_twin, h0, mask, out2, h_raw, gates):
+    """the recurrence of ONE layer of two networks over the same B windows: gi2 / out2 [2B, L, .] (network 1 then its twin),
+    h0 / mask [B, .], h_raw / gates [B, L, .] (network 1) or None"""
+    global _last_work
+    B2, L, H3 = gi2.shape
+    B, H = B2 // 2, H3 // 3
+    _last_work = 2.0 * B2 * L * 3 * H * H
+    assert gi2.stride(2) == 1 and out2.stride(2) == 1 and out2.shape == (B2, L, H) and B % 16 == 0
+    _dense_f32(w_hh, b_hh, w_hh_twin, b_hh_twin, h_raw, gates)
+    pm, ms = _mask_ptr(mask)
+    _check(load().asac_gru_wide_forward_twin(_p(gi2), gi2.stride(0), gi2.stride(1), _p(w_hh), _p(b_hh), _p(w_hh_twin),
+                                             _p(b_hh_twin), _p(h0), 0 if h0 is None else h0.stride(0), pm, ms, B, L, H,
+                                             _p(out2), out2.stride(0), out2.stride(1), _p(h_raw), _p(gates), _stream()),
+           'asac_gru_wide_forward_twin')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 63
+#define ASAC_ABI_VERSION 64
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -774,6 +774,13 @@ int asac_gru_wide_forward(const float* gi, int64_t gi_stride_b, int64_t gi_strid
                           const float* h0, int64_t h0_stride_b, const uint8_t* padding_mask, int64_t mask_stride_b, int B,
                           int L, int hidden, float* out, int64_t out_stride_b, int64_t out_stride_t, float* h_raw,
                           float* gates, void* stream);
+/* Twin form: the same B windows under TWO networks' recurrent weights in one launch (the online representation and its target
+ * copy over the sampled windows, reference sac_base.py:2066-2079): gi / out hold 2B rows (network 1 then network 2),
+ * h0 / padding_mask B rows (shared), h_raw / gates B rows (network 1 only: the target pass is not differentiated).  B % 16 == 0. */
+int asac_gru_wide_forward_twin(const float* gi, int64_t gi_stride_b, int64_t gi_stride_t, const float* w_hh, const float* b_hh,
+                               const float* w_hh_twin, const float* b_hh_twin, const float* h0, int64_t h0_stride_b,
+                               const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, int hidden, float* out,
+                               int64_t out_stride_b, int64_t out_stride_t, float* h_raw, float* gates, void* stream);
 int asac_gru_wide_backward(const float* grad_out, int64_t go_stride_b, int64_t go_stride_t, const float* w_hh_t,
                            const float* gates, const float* h_raw, const float* h0, int64_t h0_stride_b,
                            const uint8_t* padding_mask, int64_t mask_stride_b, int B, int L, int hidden, float* grad_gi,

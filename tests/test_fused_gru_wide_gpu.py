@@ -79,3 +79,45 @@ def test_other_hidden_sizes_keep_their_paths():
     assert not fused_gru_wide_supported(x, list(m.GRU(8, 8, 2).cuda()._grus))        # csrc/gru.hip
     out, hn = m.GRU(8, 48, 1).cuda()(x)
     assert out.shape == (4, 5, 48) and hn.shape == (4, 5, 1, 48)
+
+
+@pytest.mark.parametrize('H,B,L', [(64, 256, 81), (32, 48, 7), (128, 16, 5)])
+def test_wide_twin_pass_equals_two_passes(H, B, L):
+    """online + target representation over the same windows as ONE recurrence launch (`asac_gru_wide_forward_twin`):
+    bit-identical to the two separate launches, gradients of the online pass unchanged, taken only after verification; a
+    batch that is not a multiple of 16 rows keeps two launches."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm.fused_gru import TwinPass
+    from tests.test_fused_gru_gpu import _Rep
+    torch.manual_seed(3)
+    online, target = _Rep(9, H, 1).cuda(), _Rep(9, H, 1).cuda()
+    a, b = torch.randn(B, L, 5, device='cuda'), torch.randn(B, L, 4, device='cuda')
+    h0 = torch.randn(B, 1, H, device='cuda')
+    mask = torch.arange(L, device='cuda').unsqueeze(0) < torch.randint(0, L - 1, (B, 1), device='cuda')
+
+    def both(twin, aa=a, bb=b, hh=h0, mm=mask):
+        online.zero_grad()
+        ctx = twin if twin is not None else __import__('contextlib').nullcontext()
+        with native.LaunchProfiler(repeat=1) as prof:
+            with ctx:
+                out, hn = online(aa, bb, hh, mm)
+                with torch.no_grad():
+                    t_out, t_hn = target(aa, bb, hh, mm)
+            (out.sum() + (hn * 0.5).sum()).backward()
+        grads = [p.grad.clone() for p in online.parameters()]
+        return (out, hn, t_out, t_hn, *grads), prof.summary()
+
+    want, _ = both(None)
+    twin = TwinPass(online, target, verify_steps=2)
+    for step in range(4):
+        got, launches = both(twin)
+        for w, g in zip(want, got):
+            assert torch.equal(w, g)
+        if step < 2:
+            assert launches['asac_gru_wide_forward_twin']['calls'] == 1 and launches['asac_gru_wide_forward']['calls'] == 1
+        else:
+            assert twin.trusted and 'asac_gru_wide_forward' not in launches
+            assert launches['asac_gru_wide_forward_twin']['calls'] == 1
+    got, launches = both(twin, a[:B - 3], b[:B - 3], h0[:B - 3], mask[:B - 3])
+    assert 'asac_gru_wide_forward_twin' not in launches and launches['asac_gru_wide_forward']['calls'] == 2
