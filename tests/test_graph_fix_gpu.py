@@ -105,3 +105,25 @@ def test_train_step_graph_reports_its_memset_nodes():
     replaced, kept = agent._graph_memsets
     assert kept == 0
     agent.close()
+
+
+def test_two_dimensional_memset_nodes_are_left_alone_and_reported():
+    """the pass rewrites 1-D memsets only (what ATen and the runtime issue inside a train step); a pitched 2-D memset stays a
+    memset node and is counted, so that a learner can log it"""
+    import asac_amd  # noqa: F401
+    hip = ctypes.CDLL('libamdhip64.so')
+    hip.hipMemset2DAsync.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t,
+                                     ctypes.c_void_p]
+    buf = torch.full((64, 256), 7, dtype=torch.uint8, device='cuda')
+
+    def body():
+        buf.add_(0)
+        assert hip.hipMemset2DAsync(buf.data_ptr(), 256, 3, 100, 16, torch.cuda.current_stream().cuda_stream) == 0
+        buf.add_(0)
+
+    graph, (replaced, kept) = _capture(body)
+    assert (replaced, kept) == (0, 1)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert (got[:16, :100] == 3).all() and (got[:16, 100:] == 7).all() and (got[16:] == 7).all()
