@@ -138,14 +138,15 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_masked_mse': 'asac::k_masked_mse'}
 SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
-ROUND = 'r04'
+ROUND = 'r05'
+_ROUNDS = ('r05', 'r04')      # newest committed summary wins; the source file is named in the line
 
 
 def pmc_traffic(config: str, kernel: str):
     """(HBM bytes per launch, source) of a kernel (all template instances, launch-weighted), or (None, None): the PMC
     passes run under rocprofv3, not inside this process, so the committed summary of the same command is read
     (profiles/<round>_<config>_pmc_traffic.json, tools/summarize_pmc.py: FETCH_SIZE x2 (gfx950) + WRITE_SIZE)."""
-    for rnd in (ROUND, 'r02', 'r01'):
+    for rnd in (*_ROUNDS, 'r02', 'r01'):
         path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_pmc_traffic.json'
         if not path.exists():
             continue
@@ -164,8 +165,11 @@ def in_situ(config: str, kernel: str):
     """(mean launch duration in us, launches per step, source) of a kernel INSIDE the replayed hipGraph step, from the
     committed rocprofv3 --kernel-trace --stats summary of `bench.py --config <config>` (profiles/<round>_<config>_
     kernel_stats.json, tools/summarize_rocprof.py); `a+b`: a launch group, durations added.  (None, None, None) without it."""
-    path = Path(__file__).resolve().parent / 'profiles' / f'{ROUND}_{config}_kernel_stats.json'
-    if not path.exists():
+    for rnd in _ROUNDS:
+        path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_kernel_stats.json'
+        if path.exists():
+            break
+    else:
         return None, None, None
     d = json.loads(path.read_text())
     us, per_step = 0.0, None
@@ -305,9 +309,89 @@ def cpu_baseline(budget_s=24.0, fill=None):
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     return {'value': round(k / dt, 3), 'unit': 'train_steps/s', 'cores': best, 'kind': 'port',
-            'sample': f'{k} steps of the same workload ({CFG["desc"]}, B={CFG["batch_size"]}, '
-                      f'{fill} transitions resident) in {dt:.1f}s with torch threads={best} (best of sweep '
-                      f'{ {t: round(v, 1) for t, v in sweep.items()} }), host cpu_count={os.cpu_count()}'}
+            'sample': f'{k} steps in {dt:.1f}s, {best} torch thread(s) (sweep { {t: round(v, 1) for t, v in sweep.items()} } steps/s), '
+                      f'host cpu_count={os.cpu_count()}; same workload: {CFG["desc"]}, B={CFG["batch_size"]}, {fill} rows resident'}
+
+
+# ---- the line the driver parses ---------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096      # the driver keeps a tail of stdout: the LAST line must fit in it whole (round 4's 21 KB line did not)
+_ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernels', 'avg_launch_us', 'us_per_step',
+              'launches_per_step', 'alg_flops_per_launch', 'alg_bytes_per_launch', 'alg_bytes_per_step',
+              'traffic_over_algorithmic', 'achieved_hip_events', 'frac_hip_events', 'frac_source')
+
+
+def _clip(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 1] + '…'
+
+
+def compact_line(full: dict, details_path: str = 'bench_details.json') -> str:
+    """The ONE JSON line the driver reads (last line of stdout, < LINE_LIMIT bytes): the contract fields, `config`, ONE
+    `roofline` (dominant kernel), ONE `roofline_hbm` (K1-K4), `cpu_baseline`, the side configurations as bare rates.
+    Everything else (`kernels`, `sweep`, the side configurations' own rooflines) is in `details_path`."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data')
+    out = {k: full.get(k) for k in keep}
+    for k, v in full.items():
+        if k.startswith('value_') and v is not None:
+            out[k] = v
+    cfg = dict(full.get('config') or {})
+    cfg['workload'] = _clip(cfg.get('workload', ''), 160)
+    out['config'] = {k: cfg[k] for k in ('workload', 'per_gpu_batch', 'global_batch', 'replay_shard_capacity', 'parallelism',
+                                         'ranks', 'collectives', 'hipgraph') if k in cfg}
+    for name in ('roofline', 'roofline_hbm'):
+        r = full.get(name)
+        out[name] = None if r is None else {k: (_clip(r[k], 80) if isinstance(r[k], str) else r[k])
+                                            for k in _ROOF_KEYS if k in r and r[k] is not None or k == 'traffic' and k in r}
+    c = full.get('cpu_baseline')
+    out['cpu_baseline'] = None if c is None else {**{k: c.get(k) for k in ('value', 'unit', 'cores', 'kind')},
+                                                  'sample': _clip(c.get('sample', ''), 140)}
+    side = {}
+    for name, d in (full.get('configs') or {}).items():
+        if 'error' in d:
+            side[name] = None
+            continue
+        e = {'steps_per_s': d.get('value')}
+        h = d.get('roofline_hbm') or {}
+        if h.get('frac') is not None:
+            e['k1_k4_hbm_frac'] = h['frac']
+        side[name] = e
+    if side:
+        out['side_configs'] = side
+    out['details'] = details_path
+    line = json.dumps(out, ensure_ascii=True, separators=(',', ':'))
+    if len(line) >= LINE_LIMIT:        # never expected; shed the optional parts rather than lose the headline again
+        for k in ('side_configs', 'roofline_hbm'):
+            out.pop(k, None)
+            line = json.dumps(out, ensure_ascii=True, separators=(',', ':'))
+            if len(line) < LINE_LIMIT:
+                break
+    assert len(line) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(full: dict, mode: str) -> None:
+    """mode 'full': the whole record on one line (what `other_configs` and tools/ read from a child process);
+    'compact' (default): the record goes to bench_details.json (repo root and, where present, gpurun_out/), the compact
+    line is the last line of stdout."""
+    import ctypes
+    # libraries (RCCL's version banner) hold text in the C stdio buffer until exit: push it out first so
+    # the JSON record is the last line on stdout
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    if mode == 'full':
+        print(json.dumps(full), flush=True)
+        return
+    text = json.dumps(full, indent=1)
+    written = None
+    for d in (ROOT, ROOT / 'gpurun_out'):
+        try:
+            if d.is_dir():
+                (d / 'bench_details.json').write_text(text)
+                written = written or str((d / 'bench_details.json').relative_to(ROOT))
+        except OSError:
+            pass
+    print(compact_line(full, written or 'not written'), flush=True)
 
 
 def _free_port() -> int:
@@ -326,11 +410,11 @@ def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', '
         env = dict(os.environ)
         if name.endswith('_lookahead'):       # the headline workload with one sampled batch in flight (hip_config['lookahead'])
             cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name[:-len('_lookahead')], '--steps', '2000',
-                   '--warmup', '100', '--no-cpu-baseline', '--profile-steps', '0', '--no-extras', '--run-length', '0']
+                   '--warmup', '100', '--no-cpu-baseline', '--profile-steps', '0', '--no-extras', '--run-length', '0', '--emit', 'full']
             env['ASAC_BENCH_HIP_CONFIG'] = json.dumps({**json.loads(env.get('ASAC_BENCH_HIP_CONFIG', '{}')), 'lookahead': 1})
         else:
             cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name, '--steps', str(steps), '--warmup',
-                   str(warmup), '--cpu-budget', '8', '--profile-steps', '12', '--no-extras', '--run-length', '0']
+                   str(warmup), '--cpu-budget', '8', '--profile-steps', '12', '--no-extras', '--run-length', '0', '--emit', 'full']
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
@@ -363,6 +447,8 @@ def main():
     ap.add_argument('--fill', type=int, default=None, help='transitions resident before timing')
     ap.add_argument('--force-dist', action='store_true',
                     help='take the multi-rank code path (process group, RCCL collectives in the step) even with one rank')
+    ap.add_argument('--emit', choices=('compact', 'full'), default='compact',
+                    help='compact: the < 4 KB line the driver parses + bench_details.json; full: the whole record on one line')
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2',
                     help='cfg2 = the BASELINE metric configuration; the others are informational')
     args = ap.parse_args()
@@ -528,8 +614,13 @@ def main():
                 work = roofline.get('alg_flops_per_launch') or roofline.get('alg_bytes_per_launch')
                 scale = 1e12 if roofline['bound'] == 'mfma' else 1e9
                 ach_situ = work / (us_situ * 1e-6) / scale
-                roofline.update({'avg_launch_us_in_situ': round(us_situ, 3), 'achieved_in_situ': round(ach_situ, 4),
-                                 'frac_in_situ': round(ach_situ / roofline['peak'], 6), 'in_situ_source': src})
+                # THE figure is the in-situ one; the back-to-back HIP-event one (warm caches) stays beside it
+                roofline.update({'achieved_hip_events': roofline['achieved'], 'frac_hip_events': roofline['frac'],
+                                 'avg_launch_us_hip_events': roofline['avg_launch_us'],
+                                 'achieved': round(ach_situ, 4), 'frac': round(ach_situ / roofline['peak'], 6),
+                                 'avg_launch_us': round(us_situ, 3), 'frac_source': src})
+            else:
+                roofline['frac_source'] = 'hip_events (no committed rocprofv3 summary for this config)'
 
         # the north-star's "sample + return kernels" (K1-K4) as ONE group at this batch size
         members = [n_ for n_ in SAMPLE_RETURN if n_ in kernels]
@@ -547,22 +638,21 @@ def main():
             ach = by_step / (us_step * 1e-6) / 1e9
             situ = [in_situ(args.config, _KERNEL_OF[m]) for m in members]
             us_situ = None if any(x[0] is None for x in situ) else sum(x[0] * kernels[m]['launches_per_step'] for x, m in zip(situ, members))
-            roofline_hbm = {'kernels': [_KERNEL_OF[m] for m in members], 'bound': 'hbm', 'achieved': round(ach, 3),
-                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 6),
-                            'alg_bytes_per_step': int(by_step), 'us_per_step': round(us_step, 2),
+            ach_situ = None if us_situ is None else by_step / (us_situ * 1e-6) / 1e9
+            roofline_hbm = {'kernels': [_KERNEL_OF[m] for m in members], 'bound': 'hbm',
+                            'achieved': round(ach if ach_situ is None else ach_situ, 3),
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': round((ach if ach_situ is None else ach_situ) / HBM_PEAK_GBS, 6),
+                            'alg_bytes_per_step': int(by_step),
+                            'us_per_step': round(us_step if us_situ is None else us_situ, 2),
                             'traffic': None if traffic is None else int(traffic),
                             'traffic_over_algorithmic': None if traffic is None else round(traffic / by_step, 2),
                             'traffic_source': sorted(srcs) if traffic is not None else None,
-                            'us_per_step_in_situ': None if us_situ is None else round(us_situ, 2),
-                            'achieved_in_situ': None if us_situ is None else round(by_step / (us_situ * 1e-6) / 1e9, 3),
-                            'frac_in_situ': None if us_situ is None else round(by_step / (us_situ * 1e-6) / 1e9 / HBM_PEAK_GBS, 6),
-                            'in_situ_source': None if us_situ is None else situ[0][2],
-                            'note': 'K1+K2 sample / IS weights (with the step prologue fused into the same launch: Polyak '
-                                    'and the draws are counted in its bytes), K3 window gather, K4 return + ensemble min '
-                                    '(the launches that exist as such: where the return target is formed inside the Q-loss '
-                                    'backward and the TD error\'s return inside the priority update, the latter launch is '
-                                    'listed with its K4 + K6 bytes and the former is part of k_mlp_bwd); SURVEY.md §8d: at this batch the group moves < 1 MB per step, '
-                                    'three orders below what HBM delivers in one launch latency — see `sweep`'}
+                            'achieved_hip_events': round(ach, 3), 'frac_hip_events': round(ach / HBM_PEAK_GBS, 6),
+                            'us_per_step_hip_events': round(us_step, 2),
+                            'frac_source': situ[0][2] if us_situ is not None else 'hip_events (no committed rocprofv3 summary for this config)',
+                            'note': 'K1+K2 sample / IS weights (with the step prologue), K3 window gather, K4 return + min; '
+                                    'in situ = inside the replayed hipGraph step'}
 
     sweep = configs = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -591,19 +681,14 @@ def main():
                        'global_batch': CFG['batch_size'] * world,
                        'replay_shard_capacity': CFG['capacity'] // world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'ranks': world, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
+                       'ranks': torch.distributed.get_world_size() if dist_ctx is not None else 1, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
                        'hipgraph': bool(graph_used),
                        'hipgraph_memset_nodes_replaced': None if graph_memsets is None else graph_memsets[0],
                        'steps_per_graph_launch': 1},
             'roofline': roofline, 'roofline_hbm': roofline_hbm, 'sweep': sweep, 'configs': configs,
             'kernels': kernels, 'cpu_baseline': cpu,
         }
-        # libraries (RCCL's version banner) hold text in the C stdio buffer until exit: push it out first so
-        # the JSON record is the last line on stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out, args.emit)
     agent.close()
     if dist_ctx is not None:
         torch.distributed.destroy_process_group()
