@@ -321,23 +321,33 @@ class DeviceNoise:
                            for t in (u, flat, subsets) if t is not None]
 
     def begin_step_with_sample(self, step_counter, rb, flat, subsets=None, ensemble: int = 0, polyak=None,
-                               zero=None) -> bool:
+                               zero=None, gather: bool = False) -> int:
         """`begin_step` and the replay buffer's stratified sample (`rb.sample_into_static`'s tree walk) as ONE launch
         when that form applies (this source feeds the sampler, batch <= 1024); with a sharded replay
         (`rb.min_ratio_reducer`) the launch leaves the IS weights to `rb.sample_into_static`, which needs the MIN over
-        ranks first;  -> whether it did (the caller then runs only the buffer's weights / gather)."""
+        ranks first;  -> 0 (not applicable), 1 (sampled: the caller runs only the buffer's weights / gather) or, with
+        `gather`, 2: the window gather of the drawn batch was part of the same launch too
+        (`asac_step_prologue_sample_gather`)."""
         if (rb.uniform_source is not self or rb.sharded is not None
                 or rb.batch_size > native.PROLOGUE_SAMPLE_MAX_BATCH):
-            return False
+            return 0
         if subsets is not None and subsets.shape[1] == ensemble:
             subsets = None
-        native.step_prologue_sample(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
-                                    rb.capacity, rb.batch_size, rb._slot_ids, rb._beta, rb.beta_increment_per_sampling,
-                                    rb._leaf, rb._p, rb._ids, rb._w if rb.min_ratio_reducer is None else None,
-                                    rb._min_p)
+        gather = gather and rb._gather_keys is not None
+        if gather:
+            native.step_prologue_sample_gather(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
+                                               rb.capacity, rb.batch_size, rb._slot_ids, rb._beta,
+                                               rb.beta_increment_per_sampling, rb._leaf, rb._p, rb._ids,
+                                               rb._w if rb.min_ratio_reducer is None else None, rb._min_p,
+                                               rb._gather_keys, rb.prev_n, rb.post_n, rb._index_ring())
+        else:
+            native.step_prologue_sample(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
+                                        rb.capacity, rb.batch_size, rb._slot_ids, rb._beta, rb.beta_increment_per_sampling,
+                                        rb._leaf, rb._p, rb._ids, rb._w if rb.min_ratio_reducer is None else None,
+                                        rb._min_p)
         self._prefilled = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
                            for t in (rb._u, flat, subsets) if t is not None]
-        return True
+        return 2 if gather else 1
 
     def uniform_(self, buf: torch.Tensor) -> None:
         if not self._covered(buf):

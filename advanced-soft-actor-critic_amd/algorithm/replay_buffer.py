@@ -95,7 +95,7 @@ class PrioritizedReplayBuffer:
             self._nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
             self._beta = torch.tensor([beta], dtype=torch.float64, device=dev)
             self._max_p = torch.zeros(1, dtype=torch.float32, device=dev)
-            self._min_p = torch.zeros(2, dtype=torch.float32, device=dev)
+            self._min_p = torch.zeros(528, dtype=torch.float32, device=dev)    # [2..9], [16 (1 + f)]: exchange of the step prologue's workgroups (kept zero)
             B = batch_size
             self._u = torch.zeros(B, dtype=torch.float64, device=dev)
             self._leaf = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -389,9 +389,10 @@ class PrioritizedReplayBuffer:
         self.sample_into_static()
         return self._ids, self._batch, self._w.unsqueeze(-1)
 
-    def sample_into_static(self, sampled: bool = False) -> None:
-        """The device part of `sample()` (no host logic; safe inside graph capture).  `sampled`: the tree walk
-        (leaf, p, ids, IS weights) has already been done by the caller's fused prologue launch."""
+    def sample_into_static(self, sampled: int = 0) -> None:
+        """The device part of `sample()` (no host logic; safe inside graph capture).  `sampled`: 1 — the tree walk
+        (leaf, p, ids, IS weights) has already been done by the caller's fused prologue launch; 2 — and the window gather
+        too (`NoiseSource.begin_step_with_sample(..., gather=True)`)."""
         B, C = self.batch_size, self.capacity
         if self.sharded is not None:       # "parity" mode: the batch is drawn over every rank's shard (host logic)
             self.sharded.sample_into(self)
@@ -410,7 +411,8 @@ class PrioritizedReplayBuffer:
             reducer(self._min_p[1:2])
             native.per_is_weights(self._p, B, self._tree, self._min_p[1:2], self._beta,
                                   self.beta_increment_per_sampling, self._w)
-        native.window_gather_pad(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, self._index_ring())
+        if sampled != 2:
+            native.window_gather_pad(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, self._index_ring())
 
     # ------------------------------------------------------------------------------------------
     # priority / transition write-backs

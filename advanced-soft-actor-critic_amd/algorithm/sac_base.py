@@ -237,6 +237,7 @@ class SAC_Base(AuxHeadsMixin):
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
+        self._prologue_gather = bool(hip_config.get('prologue_gather', True))     # asac_step_prologue_sample_gather
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
@@ -1781,8 +1782,10 @@ class SAC_Base(AuxHeadsMixin):
                 else:
                     rb.sample_next_into_static(sampled=sampled)      # same launches, in line (no graph branch)
         else:
+            # ... and the sampler and the window gather of the batch it draws (`prologue_gather`): one launch for K1-K3 + K5
             sampled = self._use_sidecars and self.noise.begin_step_with_sample(
-                self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
+                self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero,
+                gather=self._prologue_gather)
             if not sampled:
                 self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
                                       self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)

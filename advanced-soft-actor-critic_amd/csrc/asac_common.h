@@ -123,4 +123,12 @@ __device__ __forceinline__ const ASAC_KARG void* kernarg_base() {
 #endif
 }
 
+// a by-value copy of (a part of) the kernel arguments, fetched where the copy is made
+template <typename T>
+__device__ __forceinline__ T karg_copy(const ASAC_KARG T* p) {
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+
 }  // namespace asac

@@ -96,7 +96,11 @@ __device__ __forceinline__ void prologue_block(const PrologueArgs& a, int block,
             if ((e & 3) == 0)      // a distinct counter block per subset lane: bit 63 of the lane index set
                 x = philox4x32_10((uint32_t)k, 0x80000000u | (uint32_t)(e >> 2), (uint32_t)s, (uint32_t)(s >> 32),
                                   (uint32_t)seed, (uint32_t)(seed >> 32));
-            const int j = e + (int)(x.c[e & 3] % (uint32_t)(a.E - e));
+            // (a select chain, not `x.c[e & 3]`: the dynamic index put the four words into scratch memory — 20 bytes per lane
+            // of scratch for every workgroup of the launches this is inlined into)
+            const int sel = e & 3;
+            const uint32_t word = sel == 0 ? x.c[0] : sel == 1 ? x.c[1] : sel == 2 ? x.c[2] : x.c[3];
+            const int j = e + (int)(word % (uint32_t)(a.E - e));
             const int tmp = perm[e];
             perm[e] = perm[j];
             perm[j] = tmp;

@@ -52,12 +52,8 @@ __global__ __launch_bounds__(256) void k_window_aux(const int32_t* __restrict__ 
     for (int d = 0; d < A; ++d) dst[d] = t == 0 ? 0.f : src[d];
 }
 
-}  // namespace asac
-
-using namespace asac;
-
 // the launch description of a window gather (key table, shared arguments, workgroups per key); force_unroll 0: chosen by size
-static int gather_fill(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int batch, int prev_n, int post_n,
+int gather_fill(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int batch, int prev_n, int post_n,
                        int capacity, const int32_t* index_ring, int force_unroll, GatherLaunch<ASAC_MAX_GATHER_KEYS>& m,
                        uint64_t* blocks_out, int* unroll_out) {
     if (n_keys <= 0 || n_keys > ASAC_MAX_GATHER_KEYS || batch <= 0 || prev_n < 0 || post_n < 0 ||
@@ -119,8 +115,9 @@ static int gather_fill(const asac_gather_key_t* keys_host, int n_keys, const int
     for (int q = 0; q < n_keys; ++q) small_blocks += (rows * m.key[q].units_per_row + kGatherBlock - 1) / kGatherBlock;
     const int unroll = force_unroll ? force_unroll : (small_blocks <= kSmallGatherBlocks ? 1 : kUnrollLarge);
     for (int q = 0; q < n_keys; ++q) {
-        m.key[q].first_block = (uint32_t)blocks;
-        const int64_t units = rows * m.key[q].units_per_row;
+        GatherKeyDev& d = m.key[q];
+        d.first_block = (uint32_t)blocks;
+        const int64_t units = rows * d.units_per_row;
         blocks += (uint64_t)((units + kGatherBlock * unroll - 1) / (kGatherBlock * unroll));
     }
     if (blocks == 0 || blocks > 0x7fffffffull) return bad_arg("asac_window_gather_pad: grid");
@@ -128,6 +125,10 @@ static int gather_fill(const asac_gather_key_t* keys_host, int n_keys, const int
     *unroll_out = unroll;
     return 0;
 }
+
+}  // namespace asac
+
+using namespace asac;
 
 extern "C" {
 

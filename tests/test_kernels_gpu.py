@@ -183,6 +183,10 @@ def test_window_gather_pad_matches_oracle(nat, prev_n, post_n, B):
               'obs_img': rng.integers(0, 255, (T, 3, 4, 4)).astype(np.uint8),
               'obs_flag': rng.integers(0, 2, (T, 5)).astype(bool),
               'obs_wide': rng.standard_normal((T, 36)).astype(np.float32),   # 144 B rows: 16 B units
+              # 2 000 B rows (125 units: windows of >= 512 units take the span form, a workgroup per window chunk), one
+              # kept as stored, one padded like a hidden state
+              'obs_frame': rng.standard_normal((T, 500)).astype(np.float32),
+              'hid_frame': rng.standard_normal((T, 2, 250)).astype(np.float32),
               'action': rng.random((T, 3)).astype(np.float32),
               'reward': rng.standard_normal(T).astype(np.float32), 'done': rng.integers(0, 2, T).astype(bool),
               'mu_prob': rng.random((T, 3)).astype(np.float32),
@@ -196,6 +200,7 @@ def test_window_gather_pad_matches_oracle(nat, prev_n, post_n, B):
     batch = {k: torch.as_tensor(v.reshape(B, L, *v.shape[1:]).copy()) for k, v in win.items()}
     pad_action = torch.tensor([1., 0., 0.])
     sac_ref.pad_window(batch, prev_n, pad_action)
+    batch['hid_frame'][batch['padding_mask']] = 0.
     batch['obs_img'] = batch['obs_img'].float() / 255.
     batch['obs_flag'] = batch['obs_flag'].float()
 
@@ -204,7 +209,8 @@ def test_window_gather_pad_matches_oracle(nat, prev_n, post_n, B):
     pad_row = pad_action.cuda()
     f32 = lambda x: int(np.float32(x).view(np.uint32))  # noqa: E731
     spec = {'index': (nat.PAD_WORD, 0xffffffff), 'last_mask': (nat.PAD_KEEP, 0), 'obs_vec': (nat.PAD_KEEP, 0),
-            'obs_wide': (nat.PAD_KEEP, 0), 'action': (nat.PAD_ROW, 0), 'reward': (nat.PAD_WORD, f32(0.)),
+            'obs_wide': (nat.PAD_KEEP, 0), 'obs_frame': (nat.PAD_KEEP, 0), 'hid_frame': (nat.PAD_WORD, f32(0.)),
+            'action': (nat.PAD_ROW, 0), 'reward': (nat.PAD_WORD, f32(0.)),
             'done': (nat.PAD_BYTE, 1), 'mu_prob': (nat.PAD_WORD, f32(1.)),
             'pre_seq_hidden_state': (nat.PAD_WORD, f32(0.))}
     specs = [dict(src=ring[k], dst=out[k], row_bytes=ring[k][0].numel() * ring[k].element_size(),
@@ -603,7 +609,7 @@ def test_step_prologue_is_polyak_plus_memset_plus_noise(nat, with_polyak, with_z
         assert whole.all()
 
 
-@pytest.mark.parametrize('B', [256, 700])
+@pytest.mark.parametrize('B', [256, 257, 512, 700, 1024])
 def test_step_prologue_with_sampler_is_prologue_then_sampler(nat, B):
     """`asac_step_prologue_sample` == `asac_step_prologue` followed by `asac_sumtree_sample` on the uniforms it drew:
     leaves, priorities, ids, IS weights, beta, minimum, and the prologue's own outputs, bit for bit.  With the weights
@@ -623,7 +629,7 @@ def test_step_prologue_with_sampler_is_prologue_then_sampler(nat, B):
     def outs():
         return dict(leaf=torch.zeros(B, dtype=torch.int32, device='cuda'), p=torch.zeros(B, device='cuda'),
                     ids=torch.zeros(B, dtype=torch.int64, device='cuda'), w=torch.zeros(B, device='cuda'),
-                    beta=torch.tensor([0.4], dtype=torch.float64, device='cuda'), minp=torch.zeros(2, device='cuda'),
+                    beta=torch.tensor([0.4], dtype=torch.float64, device='cuda'), minp=torch.zeros(528, device='cuda'),
                     u=torch.zeros(B, dtype=torch.float64, device='cuda'), z=torch.zeros(1001, device='cuda'),
                     target=target0.clone(), grad=torch.ones(777, device='cuda'))
 
@@ -645,6 +651,101 @@ def test_step_prologue_with_sampler_is_prologue_then_sampler(nat, B):
     nat.per_is_weights(c['p'], B, t.tree, c['minp'][1:2], c['beta'], 0.001, c['w'])
     for k in ('leaf', 'p', 'ids', 'w', 'beta'):
         assert torch.equal(a[k], c[k]), k
+    # the sampler workgroups' exchange (minp[2..7]: partial minima, arrivals, departures) is left ready for the next launch:
+    # a second launch on the same buffers — and replays of it inside a hipGraph — draw the same batch again
+    assert not b['minp'][6:8].view(torch.int32).any() and not c['minp'][6:8].view(torch.int32).any()
+    first = {k: b[k].clone() for k in ('leaf', 'p', 'ids', 'w')}
+    beta1 = float(b['beta'])
+    nat.step_prologue_sample(None, b['grad'], 99, step, b['u'], b['z'], None, 0, t.tree, C, B,
+                             slot_ids, b['beta'], 0.0, b['leaf'], b['p'], b['ids'], b['w'], b['minp'])
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            nat.step_prologue_sample(None, b['grad'], 99, step, b['u'], b['z'], None, 0, t.tree, C, B,
+                                     slot_ids, b['beta'], 0.0, b['leaf'], b['p'], b['ids'], b['w'], b['minp'])
+        for _ in range(5):
+            for k in ('leaf', 'p', 'ids', 'w'):
+                b[k].zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert float(b['beta']) == beta1
+            # (weights: beta has advanced once since `first` was drawn, so only the draw itself is compared bit for bit)
+            for k in ('leaf', 'p', 'ids'):
+                assert torch.equal(first[k], b[k]), k
+            assert not b['minp'][6:8].view(torch.int32).any()
+
+
+@pytest.mark.parametrize('B,row', [(256, 24), (512, 2000), (1000, 10800)])
+def test_step_prologue_sample_gather_is_the_two_launches(nat, B, row):
+    """`asac_step_prologue_sample_gather` == `asac_step_prologue_sample` followed by `asac_window_gather_pad` on the ids it
+    drew, bit for bit (the gather's workgroups wait inside the launch for the sampler workgroups' ids), launch after
+    launch on a tree that changes in between, eagerly and as hipGraph replays; the exchange words are left zero."""
+    C, prev_n, post_n = 8192, 2, 3
+    L = prev_n + 1 + post_n
+    rng = np.random.default_rng(B)
+    t = DevTree(nat, C, extra=2 * C)
+    t.set_priorities(np.arange(C), (rng.random(C) + 0.01).astype(np.float32))
+    slot_ids = torch.arange(C, dtype=torch.int64, device='cuda') + 7 * C        # ids whose slot is id % C
+    step = torch.full((1,), 3, dtype=torch.int64, device='cuda')
+    g = torch.Generator().manual_seed(2)
+    wide = torch.randn(C, row // 4, generator=g).cuda()
+    vec = torch.randn(C, 3, generator=g).cuda()
+    index = (torch.arange(C, dtype=torch.int32) % 37).cuda()
+    source, target0 = torch.randn(30_000, generator=g).cuda(), torch.randn(30_000, generator=g).cuda()
+
+    def outs():
+        o = dict(leaf=torch.zeros(B, dtype=torch.int32, device='cuda'), p=torch.zeros(B, device='cuda'),
+                 ids=torch.zeros(B, dtype=torch.int64, device='cuda'), w=torch.zeros(B, device='cuda'),
+                 beta=torch.tensor([0.4], dtype=torch.float64, device='cuda'), minp=torch.zeros(528, device='cuda'),
+                 u=torch.zeros(B, dtype=torch.float64, device='cuda'), z=torch.zeros(999, device='cuda'),
+                 target=target0.clone(), grad=torch.ones(555, device='cuda'),
+                 wide=torch.zeros(B, L, row // 4, device='cuda'), vec=torch.zeros(B, L, 3, device='cuda'),
+                 index=torch.zeros(B, L, dtype=torch.int32, device='cuda'), mask=torch.zeros(B, L, dtype=torch.bool, device='cuda'))
+        o['keys'] = nat.make_gather_keys([
+            dict(src=wide, dst=o['wide'], row_bytes=row, pad_mode=nat.PAD_KEEP),
+            dict(src=vec, dst=o['vec'], row_bytes=12, pad_mode=nat.PAD_WORD, pad_word=0),
+            dict(src=index, dst=o['index'], row_bytes=4, pad_mode=nat.PAD_WORD, pad_word=0xffffffff),
+            dict(src=None, dst=o['mask'], pad_mode=nat.PAD_EMIT_MASK)])
+        return o
+
+    def two(o):
+        nat.step_prologue_sample((o['target'], source, 0.005), o['grad'], 99, step, o['u'], o['z'], None, 0, t.tree, C, B,
+                                 slot_ids, o['beta'], 0.001, o['leaf'], o['p'], o['ids'], o['w'], o['minp'])
+        nat.window_gather_pad(o['keys'], o['ids'], B, prev_n, post_n, C, index)
+
+    def one(o):
+        nat.step_prologue_sample_gather((o['target'], source, 0.005), o['grad'], 99, step, o['u'], o['z'], None, 0, t.tree, C,
+                                        B, slot_ids, o['beta'], 0.001, o['leaf'], o['p'], o['ids'], o['w'], o['minp'],
+                                        o['keys'], prev_n, post_n, index)
+
+    names = ('u', 'z', 'target', 'grad', 'leaf', 'p', 'ids', 'w', 'beta', 'wide', 'vec', 'index', 'mask')
+    a, b = outs(), outs()
+    stream = torch.cuda.Stream()
+    graph = None
+    for it in range(6):
+        if it == 3:      # from here on: replays of the captured launch
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    one(b)
+            torch.cuda.synchronize()
+        two(a)
+        if graph is None:
+            one(b)
+        else:
+            graph.replay()
+        torch.cuda.synchronize()
+        for k in names:
+            assert torch.equal(a[k], b[k]), (it, k)
+        assert not b['minp'][6:].view(torch.int32).any()
+        assert a['mask'].any() and not a['mask'].all()
+        # another tree and another step counter for the next launch
+        idx = rng.permutation(C)[:500]
+        t.set_priorities(idx, (rng.random(500) * 3).astype(np.float32))
+        step += 1
 
 
 def test_window_aux_matches_get_bnx_data_concatenations(nat):
