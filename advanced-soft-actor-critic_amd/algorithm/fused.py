@@ -222,7 +222,11 @@ def _zero_block(shape, like):
     key = (tuple(shape), like.dtype, like.device)
     z = _ZERO_BLOCKS.get(key)
     if z is None:
-        z = _ZERO_BLOCKS[key] = torch.zeros(shape, dtype=like.dtype, device=like.device)
+        z = torch.zeros(shape, dtype=like.dtype, device=like.device)
+        # a tensor first made DURING capture lives in that graph's private pool and is filled by a captured node only:
+        # it serves this graph (whose replays re-run the fill) and is not cached for others or for eager steps
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _ZERO_BLOCKS[key] = z
     return z
 
 

@@ -14,7 +14,7 @@ from torch import nn
 
 from asac_amd import native
 
-from .fused_mlp import direct_enabled
+from .fused_mlp import direct_enabled, direct_skips
 
 __all__ = ['decoder_params', 'fused_obs_decoder']
 
@@ -81,7 +81,8 @@ class _ObsDecoderFn(torch.autograd.Function):
         ws = torch.empty(native.obs_decoder_workspace_floats(N), dtype=torch.float32, device=dev)
         gx = torch.empty(N, S, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         grad_frames = grad_frames.contiguous()
-        if direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
+        if direct_enabled() and any(ctx.needs_input_grad[1:]) and not direct_skips(*params) \
+                and all(p.requires_grad and p.grad is not None for p in params):
             # inside the learner the ten gradients are views of the flat gradient buffer: the reduction adds into them
             grads = [p.grad for p in params]
             if all(g.is_contiguous() and g.dtype == torch.float32 for g in grads):

@@ -29,21 +29,33 @@ FUSED_DENSE = True      # `LinearLayers` stacks that opt in (`fuse = True`: the 
 # around a backward pass that is meant to accumulate into every parameter it reaches — the learner wraps exactly
 # those (the Q loss, the policy objective, the curiosity loss).  A plain global: the autograd engine runs backward
 # nodes on its own device thread while the caller blocks inside the `with`.
+# `only`: the backward is restricted to these tensors (`backward(inputs=...)`): `ctx.needs_input_grad` is fixed at
+# forward time and does not know about that restriction, so a direct-mode backward consults `direct_skips` and leaves
+# the parameters outside the set alone (no launch, no accumulation) — what autograd does with their gradients anyway.
 _direct_depth = 0
+_direct_only = []
 
 
 @contextlib.contextmanager
-def direct_param_grads():
+def direct_param_grads(only=None):
     global _direct_depth
     _direct_depth += 1
+    _direct_only.append(None if only is None else {id(t) for t in only})
     try:
         yield
     finally:
+        _direct_only.pop()
         _direct_depth -= 1
 
 
 def direct_enabled() -> bool:
     return _direct_depth > 0
+
+
+def direct_skips(*params) -> bool:
+    """inside a restricted direct-mode backward: none of `params` is among the tensors the backward may reach"""
+    only = _direct_only[-1] if _direct_only else None
+    return only is not None and not any(id(p) in only for p in params)
 
 
 def _blocks_of(ll: LinearLayers):

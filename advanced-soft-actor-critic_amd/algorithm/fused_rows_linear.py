@@ -34,8 +34,8 @@ class _RowsLinearFn(torch.autograd.Function):
             g2 = g2.contiguous()
         gx = (g2 @ weight).view(*ctx.lead, weight.shape[1]) if ctx.needs_input_grad[0] else None
         gw = gb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            from algorithm.fused_mlp import direct_enabled
+        from algorithm.fused_mlp import direct_enabled, direct_skips
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not direct_skips(ctx.weight_param, ctx.bias_param):
             w_grad, b_grad = ctx.weight_param.grad, ctx.bias_param.grad
             if (direct_enabled() and w_grad is not None and b_grad is not None and w_grad.is_contiguous()
                     and b_grad.is_contiguous()):

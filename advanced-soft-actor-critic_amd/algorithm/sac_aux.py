@@ -73,7 +73,11 @@ def unit_gradient(like: torch.Tensor) -> torch.Tensor:
     key = (like.device, like.dtype)
     one = _UNIT.get(key)
     if one is None:
-        one = _UNIT[key] = torch.ones((), dtype=like.dtype, device=like.device)
+        one = torch.ones((), dtype=like.dtype, device=like.device)
+        # (made during capture: it belongs to that graph's pool and is filled by a captured node — not cached; `_is_unit`
+        # then does not recognise it and the loss functions multiply by it, which is the same value)
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _UNIT[key] = one
     return one
 
 
@@ -381,7 +385,7 @@ class AuxHeadsMixin:
         model_params = [list(mod.parameters()) for mod in (self.model_transition, self.model_reward, self.model_observation)]
         pred_params = list(chain(*model_params))
         losses = [loss_transition, loss_reward, loss_obs]
-        if grads_rep_main and self._rpm_single_backward and nx_states.requires_grad:
+        if grads_rep_main and self._rpm_single_backward and nx_states.requires_grad and self._rpm_models_disjoint():
             # Every loss reaches the representation through `nx_states` alone and only its own model's parameters, so
             # ONE walk through each model yields both what the reference's two walks do (1827: d loss_i / d rep for the
             # gates; 1831-1834: d (sum of losses) / d model_i = d loss_i / d model_i): the walk stops at `nx_states`,
@@ -428,6 +432,24 @@ class AuxHeadsMixin:
         if entropy_next is None:
             entropy_next = torch.mean(dist_next.entropy())
         return entropy_next.detach(), loss_reward.detach(), loss_obs.detach()
+
+    def _rpm_models_disjoint(self) -> bool:
+        """The one-walk form of `_train_rpm` assumes that a prediction loss touches only its own model's parameters and
+        reaches the representation through `nx_states` alone.  A plugin whose prediction models share a sub-module or a
+        parameter with each other, or with the representation (an encoder reused through `extra_obs`), breaks that: the
+        shared terms would drop out of the gates and of the models' gradients.  Checked once: parameter sets pairwise
+        disjoint and disjoint from the representation's — otherwise the reference's two-walk form
+        (`calculate_adaptive_weights` + the summed backward, reference sac_base.py:1827-1834) runs."""
+        ok = getattr(self, '_rpm_disjoint', None)
+        if ok is None:
+            sets = [{id(p) for p in m.parameters()}
+                    for m in (self.model_transition, self.model_reward, self.model_observation, self.model_rep)]
+            ok = all(not (sets[i] & sets[j]) for i in range(len(sets)) for j in range(i + 1, len(sets)))
+            if not ok:
+                self._logger.info('prediction models share parameters (with each other or the representation): '
+                                  '`_train_rpm` uses the two-walk form')
+            self._rpm_disjoint = ok
+        return ok
 
     def _train_rnd(self, n_padding_masks, n_states, n_actions):
         """Distil the frozen random target network on visited (state, action) pairs (1978-2025)."""

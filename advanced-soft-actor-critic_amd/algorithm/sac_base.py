@@ -312,6 +312,7 @@ class SAC_Base(AuxHeadsMixin):
         self._profiler = UnifiedElapsedTimer(self._logger)
         self.noise = DeviceNoise()
         self._graph = None
+        self._graph_hp, self._all_optimizers = None, None     # `_optimizer_hp()` the captured graphs were made with
         self._graph_runs = {}           # run length -> (the step graph it was captured beside, graph, exec handle)
         self._la_graphs, self._la_stream, self._la_pending = {}, None, False      # hip_config['lookahead']
         self._graph_failed = False
@@ -1483,7 +1484,7 @@ class SAC_Base(AuxHeadsMixin):
                                        sub if self.ensemble_q_sample != E else None, self.ensemble_q_sample,
                                        self.log_c_alpha, scale.detach(), self._stats['loss_policy'],
                                        self._grad_logp, self._grad_q, self._stats['c_entropy'])
-            with direct_param_grads():
+            with direct_param_grads(only=pi_inputs):
                 torch.autograd.backward([logp, c_qs], [self._grad_logp, self._grad_q], inputs=pi_inputs)
             if self._dist is not None:
                 self._dist.all_reduce_grads(self._params.grad, *self._params.span('policy'))
@@ -1513,7 +1514,7 @@ class SAC_Base(AuxHeadsMixin):
                                                       reduction='none').sum(-1, keepdim=True)
 
         loss = torch.mean(loss_c if loss_d is None else (loss_d if loss_c is None else loss_d + loss_c))
-        with direct_param_grads():
+        with direct_param_grads(only=pi_inputs):
             loss.backward(inputs=pi_inputs)
         if self._dist is not None:
             self._dist.all_reduce_grads(self._params.grad, *self._params.span('policy'))
@@ -2073,14 +2074,36 @@ class SAC_Base(AuxHeadsMixin):
         ROCm a captured hipMemsetAsync takes effect on the first launch only, and ATen's split reductions (every
         nn.Linear's bias gradient) zero their semaphores with one (csrc/graph_fix.hip)."""
         replaced, kept = native.graph_replace_memset_nodes(int(graph.raw_cuda_graph()))
+        if kept:
+            # a pitched (2-D) memset has the same replay fault the pass exists to repair and is not rewritten: a step that
+            # captured one must not be replayed (no kernel of the library or of ATen's step issues one today)
+            raise RuntimeError(f'{kept} 2-D memset node(s) in the captured step: not replayable on this ROCm')
         graph.instantiate()
         if replaced or kept:
             self._logger.info(f'captured graph: {replaced} memset node(s) replaced by fill kernels' +
                               (f', {kept} 2-D memset node(s) left as captured' if kept else ''))
         self._graph_memsets = (replaced, kept)
 
+    @staticmethod
+    def _graph_api_ok() -> bool:
+        """`CUDAGraph(keep_graph=True)` / `raw_cuda_graph()` / `instantiate()`: the memset-node repair needs the graph before
+        instantiation.  A torch build without them cannot replay a captured step correctly here."""
+        import inspect
+        try:
+            return ('keep_graph' in inspect.signature(torch.cuda.CUDAGraph.__new__).parameters or
+                    'keep_graph' in (torch.cuda.CUDAGraph.__new__.__doc__ or '') or
+                    hasattr(torch.cuda.CUDAGraph, 'raw_cuda_graph')) and hasattr(torch.cuda.CUDAGraph, 'instantiate')
+        except (TypeError, ValueError):
+            return hasattr(torch.cuda.CUDAGraph, 'raw_cuda_graph') and hasattr(torch.cuda.CUDAGraph, 'instantiate')
+
     def _try_capture(self) -> None:
         """Warm up on a side stream, then capture `_device_step` into one hipGraph."""
+        if not self._graph_api_ok():
+            self._graph_failed = True
+            self._logger.warning('this torch build has no CUDAGraph(keep_graph=True) / raw_cuda_graph() / instantiate(): captured '
+                                 'memset nodes could not be repaired (they take effect on the first replay only on this '
+                                 'ROCm), so the train step is NOT captured and runs eagerly — several times slower')
+            return
         try:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -2143,12 +2166,33 @@ class SAC_Base(AuxHeadsMixin):
         return self._dist_ready
 
     @unified_elapsed_timer('train a step', 10)
+    def _optimizer_hp(self) -> tuple:
+        """(lr, betas, eps) of every optimizer of the learner: host floats that a captured step holds as kernel arguments"""
+        opts = self._all_optimizers
+        if opts is None:      # (collected once: `train()` is the host's hot loop)
+            opts = self._all_optimizers = [o for o in vars(self).values() if isinstance(o, FlatAdam)] + \
+                [o for o in self.optimizer_q_list if o is not None]
+        return tuple((o.lr, o.betas, o.eps) for o in opts)
+
+    def _drop_graphs_if_hp_changed(self) -> None:
+        """a learning rate (betas, eps) changed after capture — a schedule, a user edit — would otherwise go unnoticed by
+        every replay: the graphs are dropped and the step is captured again with the new values"""
+        hp = self._optimizer_hp()
+        if hp != self._graph_hp:
+            if self._graph_hp is not None and (self._graph is not None or self._la_graphs or self._graph_runs):
+                self._logger.info('optimizer hyper-parameters changed: the captured step is dropped and captured again')
+                self._graph, self._graph_exec, self._graph_exec_checked = None, None, False
+                self._la_graphs = {}
+                self._graph_runs.clear()
+            self._graph_hp = hp
+
     def train(self) -> int:
         step = self.get_global_step()
         rb = self.replay_buffer
         if not self._ready_to_train():
             self._profiler('train a step').ignore()
             return step
+        self._drop_graphs_if_hp_changed()
         if rb._gather_keys is None:
             rb._build_batch()
             self._graph = None
@@ -2204,6 +2248,7 @@ class SAC_Base(AuxHeadsMixin):
         k = int(n_steps)
         step = self.get_global_step()
         rb = self.replay_buffer
+        self._drop_graphs_if_hp_changed()
         due = any((step + i) % self.write_summary_per_step == 0 or (step + i) % self.save_model_per_step == 0
                   for i in range(k))
         if (k <= 1 or due or self._lookahead or self._graph is None or self._graph_exec is None or self.update_target_per_step != 1

@@ -79,8 +79,18 @@ def test_sumtree_update_sample_bit_exact(nat, golden_dir, tag, C):
         # importance weights: float64 pow on device vs NumPy, allow 1 ulp of float32
         pr = g[f'{tag}_{p_key}']
         ratio = pr / ref.tree[0]
-        w_ref = np.power(ratio / np.min(ratio), -np.float64(0.401)).astype(np.float32)
-        np.testing.assert_allclose(w.cpu().numpy(), w_ref, rtol=2e-7, atol=0)
+        got_w = w.cpu().numpy()
+        if ratio.min() > 0:
+            w_ref = np.power(ratio / np.min(ratio), -np.float64(0.401)).astype(np.float32)
+            np.testing.assert_allclose(got_w, w_ref, rtol=2e-7, atol=0)
+            assert np.isfinite(got_w).all() and got_w.max() == 1.0
+        else:
+            # a zero-priority leaf was drawn (the `right == 0` rule of the descent): the reference divides by a minimum
+            # ratio of 0 (replay_buffer.py:352-354) — weight 0 for every row with p > 0 (inf ** -beta), NaN for the rows
+            # with p == 0 (0 / 0).  Asserted as such, not through NaN == NaN; non-degenerate weights are compared in
+            # test_sumtree_sample_multiblock_matches_oracle and in every step test
+            assert (pr == 0).any()
+            assert np.array_equal(np.isnan(got_w), pr == 0) and (got_w[pr > 0] == 0).all()
         assert beta.item() == pytest.approx(0.401, abs=0) and minp[0].item() == pr.min()
     mx = torch.zeros(1, dtype=torch.float32, device='cuda')
     nat.sumtree_leaf_max(t.tree, C, mx)
