@@ -169,6 +169,53 @@ def test_add_with_td_error_matches_oracle(ignore_size):
     rb.close()
 
 
+def test_packed_ingress_equals_per_key_copies_and_the_oracle():
+    """NumPy episodes enter through one pinned copy + one `asac_rows_move` scatter (`_store_rows_packed`): same ring
+    bytes, id map and tree as the per-key copies and as the oracle — across the ring seam, for an episode longer than
+    the ring, odd row sizes (bool / uint8 / 3-byte rows) and torch inputs mixed in (which keep the per-key path)."""
+    import asac_amd  # noqa: F401
+    from algorithm.replay_buffer import PrioritizedReplayBuffer
+    from asac_amd import native
+    C, B = 64, 8
+    packed = PrioritizedReplayBuffer(B, 1, 2, torch.device('cuda:0'), capacity=C)
+    plain = PrioritizedReplayBuffer(B, 1, 2, torch.device('cuda:0'), capacity=C)
+    plain.packed_ingress = False
+    ref = PrioritizedReplayRef(B, 1, 2, capacity=C)
+    rng = np.random.default_rng(3)
+    lengths = [5, 29, 17, 64, 3, 150, 41, 7, 63, 2]          # 150 > C: only the last C rows survive
+    for it, T in enumerate(lengths):
+        ep = {'index': np.arange(T, dtype=np.int32), 'obs_vec': rng.standard_normal((T, 3)).astype(np.float32),
+              'obs_img': rng.integers(0, 255, (T, 3, 5, 5)).astype(np.uint8),
+              'flag': rng.integers(0, 2, (T, 3)).astype(bool), 'done': rng.integers(0, 2, T).astype(bool),
+              'reward': rng.standard_normal(T).astype(np.float32),
+              'hidden': rng.standard_normal((T, 2, 4)).astype(np.float32), 'none': np.zeros((T, 0), np.float32)}
+        with native.LaunchProfiler(repeat=1) as prof:
+            packed.add(ep, ignore_size=1)
+        assert prof.summary()['asac_rows_move']['calls'] == 1
+        plain.add(ep, ignore_size=1)
+        ref.add(ep, ignore_size=1)
+        for k in ep:
+            got = packed._columns[k].cpu().numpy()
+            assert got.dtype == ep[k].dtype and np.array_equal(got, plain._columns[k].cpu().numpy()), (it, k)
+            assert np.array_equal(got, ref.storage.columns[k]), (it, k, 'oracle')
+        assert np.array_equal(packed._slot_ids.cpu().numpy(), ref.storage.columns['_id'])
+        assert np.array_equal(packed._tree.cpu().numpy().view(np.uint32), plain._tree.cpu().numpy().view(np.uint32))
+        assert packed.size == ref.size and packed.get_curr_id() == ref.get_curr_id()
+    # a torch tensor among the values: the per-key path (no packing), same result
+    T = 6
+    ep = {'index': np.arange(T, dtype=np.int32), 'obs_vec': torch.randn(T, 3), 'obs_img': np.zeros((T, 3, 5, 5), np.uint8),
+          'flag': np.zeros((T, 3), bool), 'done': np.zeros(T, bool), 'reward': np.zeros(T, np.float32),
+          'hidden': np.zeros((T, 2, 4), np.float32), 'none': np.zeros((T, 0), np.float32)}
+    with native.LaunchProfiler(repeat=1) as prof:
+        packed.add(ep, ignore_size=1)
+    assert 'asac_rows_move' not in prof.summary()
+    plain.add(ep, ignore_size=1)
+    assert torch.equal(packed._columns['obs_vec'], plain._columns['obs_vec'])
+    assert packed.check_tree_invariant() == 0
+    packed.close()
+    plain.close()
+
+
 def test_option_critic_replay_fields_and_random_reads():
     """the option-critic variant's storage dict (reference oc/option_selector_base.py:2029-2086:
     `option_index` int8, `option_changed_index` int32, `pre_low_seq_hidden_state` beside the usual keys) through
