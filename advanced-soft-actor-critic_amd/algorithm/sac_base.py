@@ -237,7 +237,10 @@ class SAC_Base(AuxHeadsMixin):
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
-        self._prologue_gather = bool(hip_config.get('prologue_gather', True))     # asac_step_prologue_sample_gather
+        # asac_step_prologue_sample_gather (sampler + window gather in one launch).  Off: A/B on one box (cfg2, 3 x 20 000
+        # steps each) 11 567 steps/s with it against 11 664 without, although the merged launch is 1.8 us shorter than the two
+        # under rocprofv3 — the gather's workgroups sleep and poll for the ids ~2.5 us, about what a launch boundary costs
+        self._prologue_gather = bool(hip_config.get('prologue_gather', False))
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))

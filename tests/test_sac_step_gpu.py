@@ -197,7 +197,7 @@ def test_full_step_unaligned_drift(golden_dir, case):
 # shapes take them).  Each switch, turned off, runs the recorded reference steps of a stock-network case and of a
 # trained-representation case under the same bounds — the chain forms are compared against the reference, not only
 # against the fused forms ("cover each surviving switch with one step-parity run").
-SWITCHES = ('sidecars', 'prologue_gather', 'fused_policy_step', 'fused_forward_chain', 'fused_td_chain', 'fused_td_update', 'fused_q_return',
+SWITCHES = ('sidecars', 'fused_policy_step', 'fused_forward_chain', 'fused_td_chain', 'fused_td_update', 'fused_q_return',
             'fused_q_state_grads', 'twin_rep', 'fused_linear_tanh', 'gru_backward_at', 'adjacent_cat', 'fold_rep_q_adam', 'rep_grad_one_position', 'deferred_cat',
             'head_sums_members', 'rep_from_burn_in')
 
