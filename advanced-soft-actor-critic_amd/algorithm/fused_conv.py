@@ -2,7 +2,8 @@
 
 The plugin layer `nn_models.layers.ConvLayers` (reference `image_layers.py:178-216`) routes its
 `conv_layers` here on the device when they are the two-layer pattern Conv2d GELU Conv2d GELU within the
-kernel's limits (the reference's `simple` preset on frames up to ~32x32) — the representation pass of
+kernel's limits (the reference's `simple` preset: small frames in one piece, frames up to 84 x 84 and beyond in tiles of
+the second-layer map, csrc/conv.hip) — the representation pass of
 `SAC_Base.get_l_states` (sac_base.py:1117-1146) over all B x L frames of the sampled windows then costs one
 launch for the convolutions instead of a dozen MIOpen / elementwise launches with layout transposes.
 Frames are data: the backward produces parameter gradients only (an input that requires grad keeps the
@@ -59,9 +60,7 @@ class _ConvStackFn(torch.autograd.Function):
             wd = [t.detach().contiguous() for t in (w1, b1, w2, b2)]
             z1 = z2 = None
             if train:
-                h1 = (desc.height - desc.kernel1) // desc.stride1 + 1
-                w1o = (desc.width - desc.kernel1) // desc.stride1 + 1
-                z1 = torch.empty(N, h1 * w1o, desc.out1, dtype=windows.dtype, device=windows.device)
+                z1 = torch.empty(native.conv2_z1_floats(desc, N), dtype=windows.dtype, device=windows.device)
                 z2 = torch.empty_like(y)
             native.conv2_forward_windows(desc, windows, *wd, y, z1, z2)
             if train:
@@ -76,7 +75,7 @@ class _ConvStackFn(torch.autograd.Function):
         h2, w2o = (h1 - desc.kernel2) // desc.stride2 + 1, (w1o - desc.kernel2) // desc.stride2 + 1
         out = desc.out2 * h2 * w2o
         y = torch.empty(N, out, dtype=x.dtype, device=x.device)
-        z1 = torch.empty(N, h1 * w1o, desc.out1, dtype=x.dtype, device=x.device) if train else None
+        z1 = torch.empty(native.conv2_z1_floats(desc, N), dtype=x.dtype, device=x.device) if train else None
         z2 = torch.empty(N, out, dtype=x.dtype, device=x.device) if train else None
         wd = [t.detach().contiguous() for t in (w1, b1, w2, b2)]
         native.conv2_forward(desc, x, *wd, y, z1, z2)

@@ -46,6 +46,16 @@ struct ConvDims {
     int O1, k1, s1, H1, W1, M1, K1;
     int O2, k2, s2, H2, W2, M2, K2;
     int G, rows1, RT1;                          // frames per group, layer-1 positions per group, their 16-row tiles
+    // TILED mode — frames whose second-layer map has more than 16 positions (84 x 84 frames of the reference's
+    // environments: 20 x 20 -> 9 x 9): the unit of work is a "virtual frame", the crop of a frame that ONE block of
+    // bh x bw <= 16 second-layer positions needs (C, H, W, H1 ... M2 above then describe the crop and its maps, G = 1),
+    // `tiles` of them per frame.  Blocks tile the map; a last block that would stick out is moved back inside and its
+    // rows / columns already covered by its neighbour are masked (`skip`), so every position is produced exactly once —
+    // the crops overlap (layer 1 is recomputed on the overlap: 1.44x at 84 x 84 with 3 x 3 blocks), the gradients are
+    // sums over positions and stay exact.  tiles == 1: the frame itself (everything below equals the fields above).
+    int tiles, nbx, bh, bw;
+    int FH, FW, FHW, FCHW, FH2, FW2, FM2;       // the real frame, its plane / frame strides, its second-layer map
+    int crop4, cw4;                             // float4s of a crop, of a crop row
 };
 
 struct ConvArgs {
@@ -65,15 +75,34 @@ struct ConvArgs {
     int32_t x_sample_groups;
 };
 
-// first frame of group g in memory
+// first frame of group g in memory (tiled mode: g = the frame's index, G = 1)
 __device__ __forceinline__ const float* group_frames(const ConvArgs& a, int64_t g) {
-    if (a.x_sample_groups == 0) return a.x + g * a.d.G * a.d.CHW;
+    if (a.x_sample_groups == 0) return a.x + g * a.d.G * a.d.FCHW;
     const int64_t s = g / a.x_sample_groups;
-    return a.x + s * a.x_sample_stride + (g - s * a.x_sample_groups) * a.d.G * a.d.CHW;
+    return a.x + s * a.x_sample_stride + (g - s * a.x_sample_groups) * a.d.G * a.d.FCHW;
+}
+
+// where group g's outputs live: first frame, the block's origin in the frame's second-layer map and the rows / columns of
+// the block that a neighbour already produced (tiled mode; otherwise frame g * G, origin (0, 0), nothing skipped)
+struct TileAt {
+    int64_t frame;
+    int r0, c0, skip_y, skip_x;
+};
+__device__ __forceinline__ TileAt tile_at(const ConvDims& d, int64_t g) {
+    TileAt t;
+    if (d.tiles == 1) {
+        t.frame = g * d.G, t.r0 = t.c0 = t.skip_y = t.skip_x = 0;
+        return t;
+    }
+    t.frame = g / d.tiles;
+    const int tile = (int)(g - t.frame * d.tiles), by = tile / d.nbx, bx = tile - by * d.nbx;
+    t.r0 = min(by * d.bh, d.FH2 - d.bh), t.c0 = min(bx * d.bw, d.FW2 - d.bw);
+    t.skip_y = by * d.bh - t.r0, t.skip_x = bx * d.bw - t.c0;
+    return t;
 }
 
 // LDS plan (floats).  fwd: frames | a1 | index tables | reduction slabs
-struct ConvFwdPlan { int img, a1, ktab, koff2, rowx, rowa, ktq, w1q, red, total; };
+struct ConvFwdPlan { int img, a1, ktab, koff2, rowx, rowa, ktq, w1q, red, croptab, total; };
 __host__ __device__ inline ConvFwdPlan conv_fwd_plan(const ConvDims& d) {
     ConvFwdPlan p;
     int off = 0;
@@ -84,6 +113,7 @@ __host__ __device__ inline ConvFwdPlan conv_fwd_plan(const ConvDims& d) {
     p.rowa = take(d.RT1 * 16);
     p.ktq = take(d.K1);
     p.w1q = take(d.K1 * 16);
+    p.croptab = take(d.tiles > 1 ? d.crop4 : 0);
     off = (off + 255) & ~255;
     p.img = take((d.G * d.CHW + 255) & ~255);   // whole KiB: the DMA path writes 1 KiB pieces
     p.a1 = take(d.G * d.O1 * d.M1);
@@ -142,10 +172,31 @@ __device__ __forceinline__ void async_copy_kib(const float* src, float* dst, int
     }
 }
 
+// tiled mode: float4 i of a crop [C][H][W] sits at croptab[i] floats behind the crop's first pixel in the frame
+__device__ __forceinline__ void build_croptab(const ConvDims& d, int* croptab) {
+    for (int i = threadIdx.x; i < d.crop4; i += kConvThreads) {
+        const int c = i / (d.H * d.cw4), rem = i - c * d.H * d.cw4, y = rem / d.cw4, x4 = rem - y * d.cw4;
+        croptab[i] = c * d.FHW + y * d.FW + 4 * x4;
+    }
+}
+
 // frames of group g -> LDS through the DMA path; frames beyond the batch re-read the last real one (their results
 // are never stored and their gradients are zero)
-__device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float* img, int wave, int lane) {
+__device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float* img, int wave, int lane,
+                                             const int* croptab = nullptr) {
     const ConvDims& d = a.d;
+    if (d.tiles > 1) {
+        // the crop of frame g / tiles that block g % tiles needs: a lane's 16 bytes come from wherever the table says
+        const TileAt t = tile_at(d, g);
+        const float* src = group_frames(a, t.frame) + (int64_t)(t.r0 * d.s2 * d.s1) * d.FW + t.c0 * d.s2 * d.s1;
+        const int chunks = (d.CHW + 255) >> 8;
+        for (int c = wave; c < chunks; c += kConvThreads / 64) {
+            const int i4 = min(c * 64 + lane, d.crop4 - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + croptab[i4]),
+                                             (__attribute__((address_space(3))) void*)(img + c * 256), 16, 0, 0);
+        }
+        return;
+    }
     const int64_t first = g * d.G;
     const int n_img = (int)min((int64_t)d.G, a.N - first);
     async_copy_kib(group_frames(a, g), img, (n_img * d.CHW) >> 2, (d.G * d.CHW + 255) >> 8, wave, lane);
@@ -255,6 +306,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     int* ktq = reinterpret_cast<int*>(lds + p.ktq);
     float* w1q = lds + p.w1q;
     float* red = lds + p.red;
+    int* croptab = reinterpret_cast<int*>(lds + p.croptab);
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows_pad = d.RT1 * 16;
@@ -278,6 +330,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
+    if (d.tiles > 1) build_croptab(d, croptab);
     // parameters pass through the (still free) work area: W1 | W2
     coop_copy2(a.w1, d.O1 * d.K1, a.w2, d.O2 * d.K2, img);
     __syncthreads();
@@ -311,15 +364,20 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // layer 2: this lane's A row (position lr of the 16) and the two output elements this thread finishes
     int base2;
     {
-        const int im = lr / d.M2, pos = lr - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
+        const int lrc = min(lr, d.G * d.M2 - 1);      // (rows beyond the group's positions — a 3 x 3 block — repeat the last)
+        const int im = lrc / d.M2, pos = lrc - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
         base2 = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
     }
-    int e_im[2], e_out[2];                      // frame within the group, offset inside the frame's output row
+    // the two output elements this thread finishes: frame within the group, channel offset (-1: none), position (y, x)
+    // inside the group's block of the map (the whole map unless tiled)
+    int e_im[2], e_out[2], e_py[2], e_px[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31;
         e_im[q] = row / d.M2;
-        e_out[q] = oc < d.O2 ? oc * d.M2 + (row - e_im[q] * d.M2) : -1;
+        const int pos = row - e_im[q] * d.M2;
+        e_py[q] = pos / d.W2, e_px[q] = pos - e_py[q] * d.W2;
+        e_out[q] = oc < d.O2 ? oc * d.FM2 : -1;
     }
     float b1s = b1v;
     const int qa = (Q1 * wave) / 4, qb = (Q1 * (wave + 1)) / 4;    // this wave's share of a split tail tile
@@ -329,10 +387,13 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
-    const bool dma = (d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0;
-    if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames(a, blockIdx.x, img, wave, lane);
+    // (tiled mode: the host has checked the 16-byte granularity the crops need)
+    const bool dma = d.tiles > 1 ||
+                     ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0);
+    if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames(a, blockIdx.x, img, wave, lane, croptab);
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         const int n_img = (int)min((int64_t)d.G, a.N - g * d.G);
+        const TileAt at = tile_at(d, g);
         const int z_rows = n_img * d.M1;
         if (dma) {
             dma_barrier();
@@ -364,7 +425,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
                 for (int r = 0; r < 4; ++r) red[(u * 4 + wave) * 256 + (4 * lk + r) * 16 + lr] = tail[u][r];
             }
         lds_barrier();             // the frames are consumed
-        if (dma && g + gridDim.x < a.n_groups) async_frames(a, g + gridDim.x, img, wave, lane);
+        if (dma && g + gridDim.x < a.n_groups) async_frames(a, g + gridDim.x, img, wave, lane, croptab);
         for (int u = 0; u < rem; ++u) {
             const float* ru = red + u * 4 * 256;
             const int e = threadIdx.x;                 // element (row e/16, channel e%16) of the tile
@@ -393,10 +454,11 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
             const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
-            if (e_out[q] >= 0 && e_im[q] < n_img) {
+            if (e_out[q] >= 0 && e_im[q] < n_img && e_py[q] >= at.skip_y && e_px[q] >= at.skip_x) {
                 const int i = row * 16 + (oc & 15);
                 const float z = (red[(2 * c2) * 256 + i] + red[(2 * c2 + 1) * 256 + i]) + e_bias[q];
-                const int64_t o = (g * d.G + e_im[q]) * (d.O2 * d.M2) + e_out[q];
+                const int64_t o = (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] + (at.r0 + e_py[q]) * d.FW2 +
+                                  at.c0 + e_px[q];
                 a.y[o] = gelu_f(z);
                 if (a.z2) a.z2[o] = z;
             }
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 //      position offsets.  Per-lane constants (patch offsets of the lane's gradient columns, the W2 elements of its
 //      da1 column tiles) live in registers; 76 KB for 30x30 frames: two workgroups per CU
 // ------------------------------------------------------------------------------------------------
-struct ConvBwdPlan { int img, img_size, zraw, g1, a1, da1, dz2, rowoff1, rowa, ktab, red, total; };
+struct ConvBwdPlan { int img, img_size, zraw, g1, a1, da1, dz2, rowoff1, rowa, ktab, red, croptab, total; };
 __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d) {
     ConvBwdPlan p;
     int off = 0;
@@ -428,6 +490,7 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d) {
     p.rowa = take(rows_pad);
     p.ktab = take(2 * kConvMaxK);
     p.red = take(kConvThreads);
+    p.croptab = take(d.tiles > 1 ? d.crop4 : 0);
     p.total = off;
     return p;
 }
@@ -451,10 +514,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     int* rowa = reinterpret_cast<int*>(lds + p.rowa);
     int* ktab = reinterpret_cast<int*>(lds + p.ktab);
     float* red = lds + p.red;
+    int* croptab = reinterpret_cast<int*>(lds + p.croptab);
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows_pad = d.RT1 * 16;
     const int NT1 = d.K1 / 16, NT2 = d.K2 / 16;
+    if (d.tiles > 1) build_croptab(d, croptab);
 
     // index tables, one entry per thread (see the note on integer division above)
     for (int row = threadIdx.x; row < rows_pad; row += kConvThreads) {
@@ -495,29 +560,42 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     float db1 = 0.f, db2 = 0.f;                  // thread (channel = tid % 16 | tid % 32, row slice) partial bias sums
     // layer-2 positions: row = frame*M2 + pos of the group's 16; this lane's B rows (4 step + lk) and accumulator
     // rows (4 lk + r), and the two dz2 elements (e / 32, e % 32) this thread forms
-    int rowbase[4], acc_pos[4], acc_base[4], e_im[2], e_out[2];
+    // (rows beyond the group's G * M2 positions — 7 of the 16 with a 3 x 3 block — carry dz2 = 0: their operand
+    // addresses repeat the last real row's, their col2im contributions are dropped)
+    const int last_row = d.G * d.M2 - 1;
+    const int reach = (d.k2 + d.s2 - 1) / d.s2, n_col = reach * reach;
+    int rowbase[4], acc_pos[4], acc_base[4], acc_col[4], e_im[2], e_out[2], e_py[2], e_px[2];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const int row = 4 * s + lk, im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
+        const int row = min(4 * s + lk, last_row), im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
         rowbase[s] = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 4 * lk + r, im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
-        acc_pos[r] = pos;
+        const int row = min(4 * lk + r, last_row), im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
+        acc_pos[r] = 4 * lk + r <= last_row ? pos : -1;
         acc_base[r] = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
+        // colour class of the position (frames of a group never overlap, but one pass per colour serves them all)
+        acc_col[r] = acc_pos[r] < 0 ? -1 : (oy % reach) * reach + (ox % reach);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31;
         e_im[q] = row / d.M2;
-        e_out[q] = oc < d.O2 ? oc * d.M2 + (row - e_im[q] * d.M2) : -1;
+        const int pos = row - e_im[q] * d.M2;
+        e_py[q] = pos / d.W2, e_px[q] = pos - e_py[q] * d.W2;
+        e_out[q] = oc < d.O2 ? oc * d.FM2 : -1;
     }
     // frames and saved z1 rows travel by LDS-DMA when 16-byte granular; the output-side operands (two elements of gy
     // and z2 per thread) are fetched into registers one group ahead
-    const bool dma = (d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 && (a.x_sample_stride & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0;
+    const bool dma = d.tiles > 1 ||
+                     ((d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 && (a.x_sample_stride & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0);
     auto request = [&](int64_t g, int buf) {
+        if (d.tiles > 1) {
+            async_frames(a, g, lds + p.img + buf * p.img_size, wave, lane, croptab);
+            return;
+        }
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
         async_copy_kib(group_frames(a, g), lds + p.img + buf * p.img_size, (n_img * d.CHW) >> 2, p.img_size >> 8, wave,
@@ -533,11 +611,13 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     auto fetch_out = [&](int64_t g) {
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
+        const TileAt at = tile_at(d, g);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             gy_n[q] = z2_n[q] = 0.f;
-            if (e_out[q] >= 0 && e_im[q] < n_img) {
-                const int64_t o = (first + e_im[q]) * (d.O2 * d.M2) + e_out[q];
+            if (e_out[q] >= 0 && e_im[q] < n_img && e_py[q] >= at.skip_y && e_px[q] >= at.skip_x) {
+                const int64_t o = (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] + (at.r0 + e_py[q]) * d.FW2 +
+                                  at.c0 + e_px[q];
                 gy_n[q] = a.gy[o];
                 z2_n[q] = a.z2[o];
             }
@@ -628,18 +708,20 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i)
-                        if (wave + 4 * i < NT2) da1[acc_base[r] + k2off[i]] += dp[i][r];
+                        if (wave + 4 * i < NT2 && acc_pos[r] >= 0) da1[acc_base[r] + k2off[i]] += dp[i][r];
                     lds_barrier();
                 }
             } else {
-                for (int pos = 0; pos < d.M2; ++pos) {
+                // positions whose patches cannot overlap — same (oy, ox) modulo ceil(k2 / s2) — go in one pass: 4 passes
+                // for the `simple` preset's 4 x 4 / 2 second layer instead of one per position (15 with 3 x 5 blocks)
+                for (int col = 0; col < n_col; ++col) {
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i) {
                         if (wave + 4 * i < NT2) {
                             const int ko = k2off[i];
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (acc_pos[r] == pos) da1[acc_base[r] + ko] += dp[i][r];
+                                if (acc_col[r] == col) da1[acc_base[r] + ko] += dp[i][r];
                         }
                     }
                     lds_barrier();
@@ -759,6 +841,7 @@ static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
     if (c.channels < 1 || c.height < 1 || c.width < 1 || c.out1 < 1 || c.out2 < 1 || c.kernel1 < 1 || c.kernel2 < 1 ||
         c.stride1 < 1 || c.stride2 < 1)
         return false;
+    d = ConvDims{};
     d.C = c.channels; d.H = c.height; d.W = c.width; d.CHW = d.C * d.H * d.W;
     d.O1 = c.out1; d.k1 = c.kernel1; d.s1 = c.stride1;
     d.O2 = c.out2; d.k2 = c.kernel2; d.s2 = c.stride2;
@@ -767,12 +850,48 @@ static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
     if (d.H1 < d.k2 || d.W1 < d.k2) return false;
     d.H2 = (d.H1 - d.k2) / d.s2 + 1; d.W2 = (d.W1 - d.k2) / d.s2 + 1; d.M2 = d.H2 * d.W2; d.K2 = d.O1 * d.k2 * d.k2;
     if (d.O1 > 16 || d.O2 > 32 || d.K1 > kConvMaxK || d.K2 > kConvMaxK || (d.K1 & 15) || (d.K2 & 15)) return false;
-    if (d.M2 > 16 || (16 % d.M2) != 0) return false;
-    d.G = 16 / d.M2;
-    d.rows1 = d.G * d.M1;
-    d.RT1 = (d.rows1 + 15) / 16;
-    return (size_t)conv_fwd_plan(d).total * sizeof(float) <= kConvLdsLimit &&
-           (size_t)conv_bwd_plan(d).total * sizeof(float) <= kConvLdsLimit;
+    d.tiles = 1, d.nbx = 1, d.bh = d.H2, d.bw = d.W2;
+    d.FH = d.H, d.FW = d.W, d.FHW = d.H * d.W, d.FCHW = d.CHW, d.FH2 = d.H2, d.FW2 = d.W2, d.FM2 = d.M2;
+    d.crop4 = 0, d.cw4 = 0;
+    auto fits = [&]() {
+        return (size_t)conv_fwd_plan(d).total * sizeof(float) <= kConvLdsLimit &&
+               (size_t)conv_bwd_plan(d).total * sizeof(float) <= kConvLdsLimit;
+    };
+    if (d.M2 <= 16 && (16 % d.M2) == 0) {
+        d.G = 16 / d.M2;
+        d.rows1 = d.G * d.M1;
+        d.RT1 = (d.rows1 + 15) / 16;
+        if (fits()) return true;
+    }
+    // tiled: blocks of bh x bw <= 16 second-layer positions; the block shape that recomputes the fewest layer-1 positions
+    // among those whose crops are 16-byte granular (LDS-DMA of crop rows) and fit the LDS
+    if (d.M2 <= 4 || (d.FW & 3) || (d.FHW & 3) || ((d.s1 * d.s2) & 3)) return false;
+    const ConvDims full = d;
+    int64_t best = -1;
+    ConvDims pick{};
+    for (int bh = 1; bh <= 16 && bh <= full.H2; ++bh)
+        for (int bw = 1; bh * bw <= 16 && bw <= full.W2; ++bw) {
+            if (bh * bw <= 4) continue;           // (the col2im pass of M2 <= 4 assumes whole groups of frames)
+            ConvDims t = full;
+            t.bh = bh, t.bw = bw;
+            t.H2 = bh, t.W2 = bw, t.M2 = bh * bw;
+            t.H1 = (bh - 1) * t.s2 + t.k2, t.W1 = (bw - 1) * t.s2 + t.k2, t.M1 = t.H1 * t.W1;
+            t.H = (t.H1 - 1) * t.s1 + t.k1, t.W = (t.W1 - 1) * t.s1 + t.k1, t.CHW = t.C * t.H * t.W;
+            if (t.W & 3) continue;
+            const int nby = (full.H2 + bh - 1) / bh;
+            t.nbx = (full.W2 + bw - 1) / bw;
+            t.tiles = nby * t.nbx;
+            t.crop4 = t.CHW / 4, t.cw4 = t.W / 4;
+            t.G = 1, t.rows1 = t.M1, t.RT1 = (t.rows1 + 15) / 16;
+            d = t;
+            if (!fits()) continue;
+            // cost: layer-1 positions computed per frame, a whole 16-row tile at a time, plus the layer-2 tiles
+            const int64_t cost = (int64_t)t.tiles * (t.RT1 * 16 * (int64_t)t.K1 * 16 + 16 * (int64_t)t.K2 * 32);
+            if (best < 0 || cost < best) best = cost, pick = t;
+        }
+    if (best < 0) return false;
+    d = pick;
+    return true;
 }
 
 static int conv_lds_limit(const void* fn, bool& done, const char* where) {
@@ -811,8 +930,19 @@ int64_t asac_conv2_param_count(const asac_conv2_desc_t* desc) {
 int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc, int64_t N) {
     ConvDims d;
     if (!desc || !conv_dims(*desc, d) || N <= 0) return -1;
-    const int64_t groups = (N + d.G - 1) / d.G;
+    const int64_t groups = (N * d.tiles + d.G - 1) / d.G;
     return (groups < kConvBwdGroupsCap ? groups : kConvBwdGroupsCap) * conv_param_count(d);
+}
+
+int64_t asac_conv2_z1_floats(const asac_conv2_desc_t* desc, int64_t N) {
+    ConvDims d;
+    if (!desc || !conv_dims(*desc, d) || N <= 0) return -1;
+    return N * d.tiles * d.M1 * d.O1;
+}
+
+int asac_conv2_tiles(const asac_conv2_desc_t* desc) {
+    ConvDims d;
+    return desc && conv_dims(*desc, d) ? d.tiles : -1;
 }
 
 int asac_conv2_forward(const asac_conv2_desc_t* desc, const float* x, int64_t N, const float* w1, const float* b1,
@@ -828,15 +958,17 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, in
         return bad_arg("asac_conv2_forward");
     if (frames_per_sample) {
         if (frames_per_sample < 0 || frames_per_sample % a.d.G != 0 || N % frames_per_sample != 0 ||
-            sample_stride < (int64_t)frames_per_sample * a.d.CHW)
+            sample_stride < (int64_t)frames_per_sample * a.d.FCHW)
             return bad_arg("asac_conv2_forward_windows");
         a.x_sample_groups = frames_per_sample / a.d.G;
         a.x_sample_stride = sample_stride;
     }
+    if (a.d.tiles > 1 && ((reinterpret_cast<uintptr_t>(x) & 15) || (sample_stride & 3) || (a.d.FCHW & 3)))
+        return bad_arg("asac_conv2_forward: tiled frames need 16-byte aligned rows");
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.y = y; a.z1 = z1_out; a.z2 = z2_out;
-    a.N = N;
-    a.n_groups = (N + a.d.G - 1) / a.d.G;
+    a.N = N * a.d.tiles;                                     // (tiled: virtual frames, one group each)
+    a.n_groups = (a.N + a.d.G - 1) / a.d.G;
     const size_t lds = (size_t)conv_fwd_plan(a.d).total * sizeof(float);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t cap = 256 * per_cu;
@@ -861,17 +993,20 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
         return bad_arg("asac_conv2_backward");
     if (frames_per_sample) {
         if (frames_per_sample < 0 || frames_per_sample % a.d.G != 0 || N % frames_per_sample != 0 ||
-            sample_stride < (int64_t)frames_per_sample * a.d.CHW)
+            sample_stride < (int64_t)frames_per_sample * a.d.FCHW)
             return bad_arg("asac_conv2_backward_windows");
         a.x_sample_groups = frames_per_sample / a.d.G;
         a.x_sample_stride = sample_stride;
     }
+    if (a.d.tiles > 1 && ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(z1) & 15) ||
+                          (sample_stride & 3) || (a.d.FCHW & 3) || ((a.d.M1 * a.d.O1) & 3)))
+        return bad_arg("asac_conv2_backward: tiled frames need 16-byte aligned rows");
     a.x = x; a.w2 = w2;
     a.z1 = const_cast<float*>(z1); a.z2 = const_cast<float*>(z2);
     a.gy = grad_y;
     a.partial = workspace;
-    a.N = N;
-    a.n_groups = (N + a.d.G - 1) / a.d.G;
+    a.N = N * a.d.tiles;
+    a.n_groups = (a.N + a.d.G - 1) / a.d.G;
     static bool attr = false;
     if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd), attr, "asac_conv2_backward")) return rc;
     const size_t lds = (size_t)conv_bwd_plan(a.d).total * sizeof(float);

@@ -304,6 +304,8 @@ _SIGNATURES = {
     'asac_xty_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     'asac_xty': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                            C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_conv2_tiles': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_z1_floats': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_group_frames': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_backward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -1357,6 +1359,16 @@ def conv2_forward(desc, x, w1, b1, w2, b2, y, z1_out=None, z2_out=None):
 
 def conv2_group_frames(desc) -> int:
     return int(load().asac_conv2_group_frames(C.byref(desc)))
+
+
+def conv2_tiles(desc) -> int:
+    """blocks per frame (1: the whole frame in one piece; > 1: frames whose second-layer map exceeds 16 positions)"""
+    return int(load().asac_conv2_tiles(C.byref(desc)))
+
+
+def conv2_z1_floats(desc, N) -> int:
+    """size of the `z1_out` buffer of a training forward over N frames"""
+    return int(load().asac_conv2_z1_floats(C.byref(desc), int(N)))
 
 
 @_profiled

@@ -83,6 +83,13 @@ CONFIGS['cfg5_without_prediction'] = dict(
     CONFIGS['cfg5'], use_prediction=False,
     desc='cfg5 without use_prediction: vector(10)+image(3,30,30) conv + attention rep, FORWARD curiosity, b=5 n=3, '
          'PER capacity 65536')
+# cfg4 on the frame size of the reference's environments (ConvLayers(84, 84, 3, 'simple'): 20 x 20 -> 9 x 9 positions, the
+# tiled form of the fused convolution stack); 84.7 KB per frame: capacity and batch sized so that ring and batch stay
+# within a few GB
+CONFIGS['cfg4_84'] = dict(
+    CONFIGS['cfg4'], obs_shapes=[(10,), (3, 84, 84)], plugin='nn_conv84', batch_size=256, capacity=16384, fill=2 ** 13,
+    desc='cfg4_84: vector(10)+image(3,84,84) conv rep (the reference environments\' frame size), ensemble 4 (2 sampled), '
+         'b=5 n=3, batch 256, PER capacity 16384')
 # cfg3 with the recurrent core of the reference's environments (one GRU layer of 64 units: envs/square/memory_corridor/nn.py:19)
 CONFIGS['cfg3_h64'] = dict(
     CONFIGS['cfg3'], plugin='nn_rnn_h64', hidden=(1, 64),
@@ -401,7 +408,7 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg5', 'cfg5_without_prediction', 'cfg_attn_h64'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84', 'cfg5', 'cfg5_without_prediction', 'cfg_attn_h64'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess

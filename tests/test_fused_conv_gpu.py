@@ -17,15 +17,22 @@ def _stack(C, o1, k1, s1, o2, k2, s2, seed=0):
     return ref, copy.deepcopy(ref).cuda()
 
 
-@pytest.mark.parametrize('N,C,H,W,o1,k1,s1,o2,k2,s2', [
-    (4608, 3, 30, 30, 16, 8, 4, 32, 4, 2),      # the cfg4 representation pass: 512 x 9 frames, `simple` preset
-    (37, 3, 30, 30, 16, 8, 4, 32, 4, 2),        # ragged last group
-    (3, 3, 30, 30, 16, 8, 4, 32, 4, 2),         # less than one group
-    (50, 4, 20, 24, 12, 4, 2, 20, 4, 3),        # other geometry: 9x11 -> 2x3... (unsupported -> generic path)
-    (41, 1, 28, 28, 16, 4, 4, 24, 4, 3),        # 7x7 -> 2x2, K1 = 16, out2 not a multiple of 16
-    (29, 4, 16, 16, 8, 4, 2, 32, 4, 1),         # 7x7 -> 4x4 = 16 positions: one frame per group, 8 channels (K2 = 128)
+@pytest.mark.parametrize('N,C,H,W,o1,k1,s1,o2,k2,s2,tiles', [
+    (4608, 3, 30, 30, 16, 8, 4, 32, 4, 2, 1),   # the cfg4 representation pass: 512 x 9 frames, `simple` preset
+    (37, 3, 30, 30, 16, 8, 4, 32, 4, 2, 1),     # ragged last group
+    (3, 3, 30, 30, 16, 8, 4, 32, 4, 2, 1),      # less than one group
+    (50, 4, 20, 24, 12, 4, 2, 20, 4, 3, 0),     # 9x11 -> 2x3 = 6 positions, strides 2 x 3: crops not 16-byte granular (generic path)
+    (41, 1, 28, 28, 16, 4, 4, 24, 4, 3, 1),     # 7x7 -> 2x2, K1 = 16, out2 not a multiple of 16
+    (29, 4, 16, 16, 8, 4, 2, 32, 4, 1, 1),      # 7x7 -> 4x4 = 16 positions: one frame per group, 8 channels (K2 = 128)
+    # TILED: the second-layer map has more than 16 positions
+    (37, 3, 84, 84, 16, 8, 4, 32, 4, 2, -1),    # the reference environments' frames (ConvLayers(84, 84, 3, 'simple')):
+                                                # 20x20 -> 9x9 in blocks of <= 16 positions (six of 3 x 5: the cheapest cover)
+    (300, 3, 84, 84, 16, 8, 4, 32, 4, 2, -1),   # ... more virtual frames than workgroups
+    (21, 1, 64, 64, 16, 8, 4, 32, 4, 2, -1),    # 15x15 -> 6x6: blocks that do not tile the map are moved inside, duplicates masked
+    (18, 2, 52, 68, 8, 4, 4, 16, 4, 2, -1),     # 13x17 -> 5x7, non-square frame, fewer channels
+    (10, 3, 48, 48, 16, 8, 4, 32, 4, 1, -1),    # 11x11 -> 8x8 with second stride 1 (s1 * s2 = 4)
 ])
-def test_fused_conv_stack_matches_modules(N, C, H, W, o1, k1, s1, o2, k2, s2):
+def test_fused_conv_stack_matches_modules(N, C, H, W, o1, k1, s1, o2, k2, s2, tiles):
     import asac_amd  # noqa: F401
     from asac_amd import native
     from algorithm.fused_conv import conv_stack_desc, fused_conv_stack
@@ -39,11 +46,10 @@ def test_fused_conv_stack_matches_modules(N, C, H, W, o1, k1, s1, o2, k2, s2):
     desc = conv_stack_desc(dev, xd)
     h1, w1 = (H - k1) // s1 + 1, (W - k1) // s1 + 1
     h2, w2 = (h1 - k2) // s2 + 1, (w1 - k2) // s2 + 1
-    fits = (o1 <= 16 and o2 <= 32 and (C * k1 * k1) % 16 == 0 and (o1 * k2 * k2) % 16 == 0
-            and C * k1 * k1 <= 256 and o1 * k2 * k2 <= 256 and 16 % (h2 * w2) == 0)
-    assert (desc is not None) == fits
+    assert (desc is not None) == (tiles != 0)
     if desc is None:
         return
+    assert h2 * w2 > 0 and (native.conv2_tiles(desc) == tiles if tiles > 0 else native.conv2_tiles(desc) > 1)
     with native.LaunchProfiler() as prof:
         got = fused_conv_stack(xd, desc, dev)
         (got * gy.cuda()).sum().backward()
