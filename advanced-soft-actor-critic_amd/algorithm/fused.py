@@ -8,6 +8,8 @@
   * noise sources     `DeviceNoise` (Philox, graph-capturable) and `RecordedNoise` (parity tests)
 """
 import numpy as np
+import contextlib
+
 import torch
 
 from asac_amd import native
@@ -285,6 +287,61 @@ class _ScaledMseFn(torch.autograd.Function):
         if _is_unit(g_loss):      # the root gradient of `autograd.grad(loss, ...)`: 1 / divisor is a host constant
             return grad / ctx.divisor, None, None
         return grad * (g_loss / ctx.divisor), None, None
+
+
+class _MseMeanFn(torch.autograd.Function):
+    """mse_loss(pred, target) over millions of elements, value and gradient from one launch (`asac_mse_mean_grad`)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, workspace):
+        from asac_amd import native
+        grad = torch.empty_like(pred)
+        loss = torch.empty((), dtype=pred.dtype, device=pred.device)
+        native.mse_mean_grad(pred.detach(), target, grad, loss, workspace)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad,) = ctx.saved_tensors
+        from .sac_aux import _is_unit
+        return (grad if _is_unit(g_loss) else grad * g_loss), None, None
+
+
+MSE_INTERCEPT_MIN = 1 << 20       # below this ATen's chain is a few launches of microseconds each
+
+
+@contextlib.contextmanager
+def fused_mse_loss(workspace: torch.Tensor):
+    """While active, `torch.nn.functional.mse_loss(input, target)` — the call a plugin's `ModelObservation.get_loss` makes
+    on decoded frames (reference envs/*/nn*.py under sac_base.py:1817) — with default arguments, a contiguous f32 device
+    `input` of >= 2^20 elements that requires grad and a same-shaped `target` that does not runs as ONE launch for value and
+    gradient (`asac_mse_mean_grad`; ATen: an elementwise pass writing the squared differences, a split reduction, and
+    backwards a fill and another elementwise pass).  Every other call goes to the original function.  `workspace`: the
+    caller's zeroed `native.mse_mean_grad_workspace()` floats."""
+    from asac_amd import native
+    F = torch.nn.functional
+    orig = F.mse_loss
+
+    def mse_loss(input, target, *args, **kwargs):
+        if (not args and not kwargs and isinstance(input, torch.Tensor) and isinstance(target, torch.Tensor)
+                and input.dim() >= 3 and input.shape == target.shape and input.numel() >= MSE_INTERCEPT_MIN
+                and input.requires_grad and not target.requires_grad and torch.is_grad_enabled() and input.is_contiguous()):
+            B, T = input.shape[:2]
+            pred3 = input.view(B, T, -1)
+            try:
+                target3 = target.view(B, T, -1)
+            except RuntimeError:
+                target3 = None
+            if target3 is not None and native.mse_mean_grad_ok(pred3, target3):
+                return _MseMeanFn.apply(pred3, target3, workspace)
+        return orig(input, target, *args, **kwargs)
+
+    F.mse_loss = mse_loss
+    try:
+        yield
+    finally:
+        F.mse_loss = orig
 
 
 def scaled_mse(pred: torch.Tensor, target: torch.Tensor, divisor: float) -> torch.Tensor:

@@ -381,7 +381,16 @@ class AuxHeadsMixin:
             loss_reward = scaled_mse(self.model_reward(time_slice(nx_states, 1)), n_rewards.unsqueeze(2), self.n_step)
         else:
             loss_reward = functional.mse_loss(self.model_reward(nx_states[:, 1:]), n_rewards.unsqueeze(2)) / self.n_step
-        loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
+        if self._fused_rpm_loss and nx_states.is_cuda:
+            from .fused import fused_mse_loss
+            ws = getattr(self, '_mse_big_ws', None)
+            if ws is None:       # (first eager step: zeroed exchange words of `asac_mse_mean_grad`, kept by the learner)
+                from asac_amd import native
+                ws = self._mse_big_ws = torch.zeros(native.mse_mean_grad_workspace(), dtype=torch.float32, device=self.device)
+            with fused_mse_loss(ws):
+                loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
+        else:
+            loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
         model_params = [list(mod.parameters()) for mod in (self.model_transition, self.model_reward, self.model_observation)]
         pred_params = list(chain(*model_params))
         losses = [loss_transition, loss_reward, loss_obs]

@@ -494,6 +494,8 @@ class SAC_Base(AuxHeadsMixin):
         self._loss_q_e = torch.zeros(E, **f32)             # per-ensemble Q losses of the last step
         self._stats['loss_q'] = self._loss_q_e[0]
         self._grad_q = torch.zeros(E, B, **f32)            # d loss / d q written by the loss kernels
+        # zeroed exchange words of `asac_mse_mean_grad` (the observation model's frame loss, sac_aux._train_rpm)
+        self._mse_big_ws = torch.zeros(native.mse_mean_grad_workspace(), **f32) if self.use_prediction else None
         self._grad_logp = torch.zeros(B, **f32)
         self._ls_y = None
         self._cq_buf, self._tq_buf, self._cq_td_buf = (torch.zeros(E, B, 1, **f32) for _ in range(3))

@@ -202,6 +202,99 @@ __global__ __launch_bounds__(kMseThreads) void k_masked_mse(const float* __restr
     }
 }
 
+// The same loss over MILLIONS of elements — a plugin's observation loss `mse_loss(decoded frames, frames)`, 11 M floats at
+// BASELINE configs[4] (sac_base.py:1817 through `ModelObservation.get_loss`) — for which ATen runs a 44 MB elementwise
+// pass, a split reduction and, backwards, a fill and another elementwise pass: one launch, loss and gradient (the scaled
+// difference) from ONE read of both operands.  Rows of K % 4 == 0 floats, 16-byte loads, a bounded grid of persistent
+// workgroups; the workgroups' sums are added in a fixed order by the last to arrive.  The exchange uses relaxed
+// agent-scope atomics only: an agent-scope release would write back every dirty line of the XCD's L2, i.e. the
+// gradient this very launch is streaming out (sumtree.hip, SampleSync).
+constexpr int kMseBigGrid = 2048;
+__global__ __launch_bounds__(kMseThreads) void k_mse_big(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         int64_t target_sb, int64_t target_st, int T, int K4,
+                                                         unsigned int n4, float inv_n, float* __restrict__ grad,
+                                                         float* __restrict__ loss, float* partial, unsigned int* counter) {
+    __shared__ float red[kMseThreads];
+    __shared__ bool last;
+    const float scale = 2.f * inv_n;
+    const float4* p4 = reinterpret_cast<const float4*>(pred);
+    float4* g4 = reinterpret_cast<float4*>(grad);
+    constexpr int U = 4;
+    float s = 0.f;
+    auto term = [&](const float4& a, const float4& b, float4* out) {
+        const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        s += ((d.x * d.x + d.y * d.y) + d.z * d.z) + d.w * d.w;
+        *out = make_float4(d.x * scale, d.y * scale, d.z * scale, d.w * scale);
+    };
+    if (target_st == (int64_t)4 * K4) {
+        // a sample's T rows are consecutive in the target too (a slice x[:, b:] of the window batch): a workgroup walks
+        // whole samples — no index arithmetic per element (two 32-bit divisions per float4 made the general form
+        // 40 us for 133 MB)
+        const unsigned int len4 = (unsigned)T * (unsigned)K4, B = n4 / len4;
+        for (unsigned int smp = blockIdx.x; smp < B; smp += gridDim.x) {
+            const float4* pc = p4 + (int64_t)smp * len4;
+            const float4* tc = reinterpret_cast<const float4*>(target + (int64_t)smp * target_sb);
+            float4* gc = g4 + (int64_t)smp * len4;
+            for (unsigned int base = threadIdx.x; base < len4; base += kMseThreads * U) {
+                float4 pv[U], qv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned int i = min(base + u * kMseThreads, len4 - 1);
+                    pv[u] = pc[i], qv[u] = tc[i];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (base + u * kMseThreads < len4) term(pv[u], qv[u], gc + base + u * kMseThreads);
+            }
+        }
+    } else {
+        for (unsigned int base = blockIdx.x * (kMseThreads * U); base < n4; base += gridDim.x * (kMseThreads * U)) {
+            float4 pv[U], qv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned int i = min(base + u * kMseThreads + threadIdx.x, n4 - 1);
+                const unsigned int row = i / (unsigned)K4, k4 = i - row * (unsigned)K4, b = row / (unsigned)T, t = row - b * (unsigned)T;
+                pv[u] = p4[i];
+                qv[u] = reinterpret_cast<const float4*>(target + (int64_t)b * target_sb + (int64_t)t * target_st)[k4];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned int i = base + u * kMseThreads + threadIdx.x;
+                if (i < n4) term(pv[u], qv[u], g4 + i);
+            }
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = kMseThreads / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    // fixed order: lane t adds partials [8 t, 8 t + 8) in turn, then the tree above
+    float v = 0.f;
+    for (int j = 0; j < kMseBigGrid / kMseThreads; ++j) {
+        const unsigned int w = threadIdx.x * (kMseBigGrid / kMseThreads) + j;
+        if (w < gridDim.x) v += __hip_atomic_load(partial + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = kMseThreads / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *loss = red[0] * inv_n;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+}
+
 // Transition model's loss (SAC_Base._train_rpm, reference sac_base.py:1798-1816): for the model's Normal(loc, scale)
 // over the next state and the target representation's state x,
 //   loss = -mean(log N(x; loc, scale)) + w * mean(KL(N(loc, scale) || N(0, 1))),  entropy = mean(H(N(loc, scale)))
@@ -418,6 +511,24 @@ int asac_masked_mse(const float* pred, const float* target, int64_t target_strid
                 target_stride_t, padding_mask, mask_stride_b, B, T, K, grad_out, loss_out, workspace,
                 reinterpret_cast<unsigned int*>(workspace + blocks));
     return finish_launch("asac_masked_mse");
+}
+
+int64_t asac_mse_mean_grad_workspace(void) { return kMseBigGrid + 1; }
+
+int asac_mse_mean_grad(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T,
+                       int K, float* grad_out, float* loss_out, float* workspace, void* stream) {
+    const int64_t n = (int64_t)B * T * K;
+    if (B <= 0 || T <= 0 || K <= 0 || (K & 3) || !pred || !target || !grad_out || !loss_out || !workspace ||
+        n / 4 >= 0x7fffffffll || (target_stride_b & 3) || (target_stride_t & 3) ||
+        ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad_out)) & 15))
+        return bad_arg("asac_mse_mean_grad");
+    const unsigned int n4 = (unsigned int)(n / 4);
+    const int64_t want = ((int64_t)n4 + kMseThreads * 4 - 1) / (kMseThreads * 4);
+    const unsigned blocks = (unsigned)(want < kMseBigGrid ? want : kMseBigGrid);
+    ASAC_LAUNCH(k_mse_big, dim3(blocks), dim3(kMseThreads), 0, as_stream(stream), pred, target, target_stride_b,
+                target_stride_t, T, K / 4, n4, 1.f / (float)n, grad_out, loss_out, workspace,
+                reinterpret_cast<unsigned int*>(workspace + kMseBigGrid));
+    return finish_launch("asac_mse_mean_grad");
 }
 
 int64_t asac_normal_nll_kl_workspace(int64_t n) {

@@ -292,6 +292,9 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'asac_masked_mse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_mse_mean_grad_workspace': (C.c_int64, []),
+    'asac_mse_mean_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_masked_mse_workspace': (C.c_int64, [C.c_int64]),
     'asac_normal_nll_kl_workspace': (C.c_int64, [C.c_int64]),
     'asac_normal_nll_kl': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -1237,6 +1240,27 @@ def masked_mse(pred, target, padding_mask, grad_out, loss_out):
         _MSE_WS[key] = torch.zeros(int(load().asac_masked_mse_workspace(pred.numel())), dtype=torch.float32, device=pred.device)
     _check(load().asac_masked_mse(_p(pred), pt, sb, st, pm, ms, B, T, K, _p(grad_out), _p(loss_out), _p(_MSE_WS[key]),
                                   _stream()), 'asac_masked_mse')
+
+
+@_profiled
+def mse_mean_grad(pred, target, grad_out, loss_out, workspace):
+    """loss_out <- mean((pred - target)^2), grad_out <- its gradient w.r.t. pred; pred [B, T, K] dense, target a [B, T, K]
+    view with a dense last dimension (see `mse_mean_grad_ok`); `workspace`: zeros(mse_mean_grad_workspace()), kept by the caller"""
+    B, T, K = pred.shape
+    pt, sb, st = _window3(target)
+    _check(load().asac_mse_mean_grad(_p(pred), pt, sb, st, B, T, K, _p(grad_out), _p(loss_out), _p(workspace), _stream()),
+           'asac_mse_mean_grad')
+
+
+def mse_mean_grad_workspace() -> int:
+    return int(load().asac_mse_mean_grad_workspace())
+
+
+def mse_mean_grad_ok(pred, target) -> bool:
+    return (pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32 and pred.dim() == 3
+            and pred.is_contiguous() and target.shape == pred.shape and target.stride(2) == 1 and pred.shape[2] % 4 == 0
+            and target.stride(0) % 4 == 0 and target.stride(1) % 4 == 0 and pred.data_ptr() % 16 == 0
+            and target.data_ptr() % 16 == 0 and 0 < pred.numel() < 2 ** 33)
 
 
 _NLL_WS = {}

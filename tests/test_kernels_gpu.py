@@ -906,3 +906,51 @@ def test_normal_nll_kl_against_torch_distributions(nat):
     torch.testing.assert_close(g_scale, want_scale, rtol=1e-5, atol=1e-9)
     nat.normal_nll_kl(loc.detach(), scale.detach(), target, w, g_loc, g_scale, out)      # the workspace is clean again
     torch.testing.assert_close(out[0], want.detach(), rtol=2e-6, atol=1e-6)
+
+
+def test_mse_mean_grad_and_the_intercepted_mse_loss(nat):
+    """`asac_mse_mean_grad` against torch's mse_loss (value 1e-6, gradient bit-level formula (a - b) * 2 / N), target a
+    strided slice of a window batch, run-to-run identical, replayable; `fused.fused_mse_loss` routes exactly the calls it
+    describes and leaves the function as it found it."""
+    from algorithm.fused import fused_mse_loss
+    g = torch.Generator().manual_seed(4)
+    B, L, b = 128, 9, 5
+    frames = torch.randn(B, L, 3, 30, 30, generator=g).cuda()
+    target = frames[:, b:]                                   # [B, 4, 3, 30, 30], batch stride L * 2700
+    pred = torch.randn(B, L - b, 3, 30, 30, generator=g).cuda().requires_grad_()
+    assert pred.numel() >= 1 << 20
+    ws = torch.zeros(nat.mse_mean_grad_workspace(), device='cuda')
+    orig = torch.nn.functional.mse_loss
+    with fused_mse_loss(ws):
+        with nat.LaunchProfiler(repeat=1) as prof:
+            loss = torch.nn.functional.mse_loss(pred, target)
+        assert prof.summary()['asac_mse_mean_grad']['calls'] == 1
+        small = torch.nn.functional.mse_loss(pred[:2], target[:2])                       # below the threshold: ATen
+        summed = torch.nn.functional.mse_loss(pred, target, reduction='sum')             # other arguments: ATen
+    assert torch.nn.functional.mse_loss is orig
+    (g_fused,) = torch.autograd.grad(loss * 3.0, pred)
+    want = orig(pred, target)
+    (g_want,) = torch.autograd.grad(want * 3.0, pred)
+    np.testing.assert_allclose(loss.item(), want.item(), rtol=2e-6)
+    np.testing.assert_allclose(g_fused.cpu().numpy(), g_want.cpu().numpy(), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(small.item(), orig(pred[:2], target[:2]).item(), rtol=1e-6)
+    np.testing.assert_allclose(summed.item(), orig(pred, target, reduction='sum').item(), rtol=1e-5)
+    assert not ws[-1:].view(torch.int32).any()
+    # the raw entry point: identical results launch after launch, also as hipGraph replays
+    p3, t3 = pred.detach().view(B, L - b, -1), target.view(B, L - b, -1)
+    grad, out = torch.empty_like(p3), torch.zeros((), device='cuda')
+    nat.mse_mean_grad(p3, t3, grad, out, ws)
+    first = (out.clone(), grad.clone())
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            nat.mse_mean_grad(p3, t3, grad, out, ws)
+        for _ in range(3):
+            grad.zero_()
+            out.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, first[0]) and torch.equal(grad, first[1])
+    assert float(first[0]) == float(loss)
