@@ -408,7 +408,7 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
-def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84', 'cfg5', 'cfg5_without_prediction', 'cfg_attn_h64'), steps=300, warmup=40) -> dict:
+def other_configs(names=('cfg2_lookahead', 'cfg2_force_dist', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84', 'cfg5', 'cfg5_without_prediction', 'cfg_attn_h64'), steps=300, warmup=40) -> dict:
     """train steps/s of the other BASELINE configurations, each in its own process (its own replay buffers and
     hipGraph), same timing contract, fewer steps"""
     import subprocess
@@ -419,6 +419,11 @@ def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84'
             cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name[:-len('_lookahead')], '--steps', '2000',
                    '--warmup', '100', '--no-cpu-baseline', '--profile-steps', '0', '--no-extras', '--run-length', '0', '--emit', 'full']
             env['ASAC_BENCH_HIP_CONFIG'] = json.dumps({**json.loads(env.get('ASAC_BENCH_HIP_CONFIG', '{}')), 'lookahead': 1})
+        elif name.endswith('_force_dist'):    # one rank with every collective of the data-parallel step issued (RCCL, captured)
+            cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name[:-len('_force_dist')], '--steps', '2000',
+                   '--warmup', '100', '--no-cpu-baseline', '--profile-steps', '0', '--no-extras', '--run-length', '0', '--emit', 'full',
+                   '--force-dist']
+            env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
         else:
             cmd = [sys.executable, str(Path(__file__).resolve()), '--config', name, '--steps', str(steps), '--warmup',
                    str(warmup), '--cpu-budget', '8', '--profile-steps', '12', '--no-extras', '--run-length', '0', '--emit', 'full']
@@ -428,6 +433,7 @@ def other_configs(names=('cfg2_lookahead', 'cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84'
             d = json.loads(line)
             out[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
                          'warmup': d['warmup'], 'workload': d['config']['workload'], 'hipgraph': d['config']['hipgraph'],
+                         'ranks': d['config'].get('ranks'), 'collectives': d['config'].get('collectives'),
                          'roofline': d.get('roofline'), 'roofline_hbm': d.get('roofline_hbm'),
                          'cpu_baseline': d.get('cpu_baseline')}
         except Exception as e:   # a failed side run must not lose the main line

@@ -175,6 +175,7 @@ def _parity_worker(rank, world, port, out_dir):
         sharded.update(td)
         new_mu = torch.full((len(gidx), 3, 2), float(100 + it)) + torch.from_numpy(gidx.astype(np.float32))[:, None, None]
         mask = torch.zeros((len(gidx), 3), dtype=torch.bool)
+        ring_before = mine.storage.columns['mu_prob'].copy()
         sharded.update_windows(-1, 3, mask, 'mu_prob', new_mu)
         # every rank replays ALL updates on its copy of the shards it does not own... through the union oracle instead:
         td_full = torch.zeros(B)
@@ -190,6 +191,20 @@ def _parity_worker(rank, world, port, out_dir):
             sid = mine.storage.ids_at(np.array([slot[i]]))[0]
             got = mine.storage.rows_at(np.array([sid]))['mu_prob'][0]
             assert got[0] >= 100, 'the write-back reached the owning shard'
+        # ... and the WHOLE ring of my shard is what a plain oracle shard holds after the same rows were written to it in
+        # ascending sample order (the exchange delivers them in that order: last writer wins on overlapping windows)
+        want_ring = PrioritizedReplayRef(batch_size=B, sample_prev_n=1, sample_post_n=2, capacity=Cs)
+        want_ring.storage = type(mine.storage).__new__(type(mine.storage))
+        want_ring.storage.__dict__.update({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in mine.storage.__dict__.items()})
+        want_ring.storage.columns = {k: v.copy() for k, v in mine.storage.columns.items()}
+        want_ring.storage.columns['mu_prob'] = ring_before
+        sids_own = mine.storage.ids_at(slot[own_rows])
+        tgt_own = (sids_own[:, None] - 1 + np.arange(3)[None, :]).reshape(-1)
+        vals_own = np.repeat((100 + it + own_rows).astype(np.float32), 3)[:, None] * np.ones((1, 2), np.float32)
+        if len(own_rows):
+            want_ring.update_transitions(tgt_own, 'mu_prob', vals_own)
+        assert np.array_equal(mine.storage.columns['mu_prob'].view(np.uint32), want_ring.storage.columns['mu_prob'].view(np.uint32)), \
+            'my shard\'s mu_prob ring after the write-backs == the oracle shard\'s'
         # keep this rank's copies of the OTHER shards (and the union tree) in step for the next round: the same
         # priorities and mu rows their owners just received (rows arrive in ascending sample order: last writer wins)
         for s_i, s in enumerate(shards):
