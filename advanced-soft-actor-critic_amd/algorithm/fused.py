@@ -293,32 +293,38 @@ class _MseMeanFn(torch.autograd.Function):
     """mse_loss(pred, target) over millions of elements, value and gradient from one launch (`asac_mse_mean_grad`)"""
 
     @staticmethod
-    def forward(ctx, pred, target, workspace):
+    def forward(ctx, pred, target, workspace, grad_scale):
         from asac_amd import native
         grad = torch.empty_like(pred)
         loss = torch.empty((), dtype=pred.dtype, device=pred.device)
-        native.mse_mean_grad(pred.detach(), target, grad, loss, workspace)
+        native.mse_mean_grad(pred.detach(), target, grad, loss, workspace, grad_scale)
         ctx.save_for_backward(grad)
+        ctx.grad_scale = float(grad_scale)
         return loss
 
     @staticmethod
     def backward(ctx, g_loss):
         (grad,) = ctx.saved_tensors
-        from .sac_aux import _is_unit
-        return (grad if _is_unit(g_loss) else grad * g_loss), None, None
+        from .sac_aux import _const_value
+        # the stored gradient already carries `grad_scale`: a root gradient that IS that factor (the cached constant the
+        # caller's division hands down) needs nothing more; anything else is one more pass
+        if _const_value(g_loss) == ctx.grad_scale:
+            return grad, None, None, None
+        return grad * (g_loss / ctx.grad_scale), None, None, None
 
 
 MSE_INTERCEPT_MIN = 1 << 20       # below this ATen's chain is a few launches of microseconds each
 
 
 @contextlib.contextmanager
-def fused_mse_loss(workspace: torch.Tensor):
+def fused_mse_loss(workspace: torch.Tensor, grad_scale: float = 1.0):
     """While active, `torch.nn.functional.mse_loss(input, target)` — the call a plugin's `ModelObservation.get_loss` makes
     on decoded frames (reference envs/*/nn*.py under sac_base.py:1817) — with default arguments, a contiguous f32 device
     `input` of >= 2^20 elements that requires grad and a same-shaped `target` that does not runs as ONE launch for value and
     gradient (`asac_mse_mean_grad`; ATen: an elementwise pass writing the squared differences, a split reduction, and
     backwards a fill and another elementwise pass).  Every other call goes to the original function.  `workspace`: the
-    caller's zeroed `native.mse_mean_grad_workspace()` floats."""
+    caller's zeroed `native.mse_mean_grad_workspace()` floats; `grad_scale`: the constant the caller will multiply the
+    loss with (`sac_aux._DivConstFn`), folded into the stored gradient."""
     from asac_amd import native
     F = torch.nn.functional
     orig = F.mse_loss
@@ -334,7 +340,7 @@ def fused_mse_loss(workspace: torch.Tensor):
             except RuntimeError:
                 target3 = None
             if target3 is not None and native.mse_mean_grad_ok(pred3, target3):
-                return _MseMeanFn.apply(pred3, target3, workspace)
+                return _MseMeanFn.apply(pred3, target3, workspace, grad_scale)
         return orig(input, target, *args, **kwargs)
 
     F.mse_loss = mse_loss

@@ -81,6 +81,48 @@ def unit_gradient(like: torch.Tensor) -> torch.Tensor:
     return one
 
 
+_CONST = {}
+
+
+def const_gradient(like: torch.Tensor, value: float) -> torch.Tensor:
+    """a cached scalar `value` on `like`'s device — what `_DivConstFn` hands down for a unit root gradient, recognisable by
+    `_const_value` (so that a consumer that prepared for exactly this factor needs no launch at all)"""
+    key = (like.device, like.dtype, float(value))
+    c = _CONST.get(key)
+    if c is None:
+        c = torch.full((), float(value), dtype=like.dtype, device=like.device)
+        if not (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _CONST[key] = c
+    return c
+
+
+def _const_value(g: torch.Tensor):
+    """the host value of `g` if it is one of the cached constant gradients (or the unit), else None"""
+    if g.dim() != 0:
+        return None
+    if _is_unit(g):
+        return 1.0
+    for (dev, dt, value), c in _CONST.items():
+        if dev == g.device and dt == g.dtype and c.data_ptr() == g.data_ptr():
+            return value
+    return None
+
+
+class _DivConstFn(torch.autograd.Function):
+    """loss / n for a host constant n; a unit root gradient comes out as the cached constant 1 / n (no launch)"""
+
+    @staticmethod
+    def forward(ctx, loss, n):
+        ctx.n = float(n)
+        return loss / n
+
+    @staticmethod
+    def backward(ctx, g):
+        if _is_unit(g):
+            return const_gradient(g, 1.0 / ctx.n), None
+        return g / ctx.n, None
+
+
 def _is_unit(g: torch.Tensor) -> bool:
     one = _UNIT.get((g.device, g.dtype))
     return one is not None and g.data_ptr() == one.data_ptr() and g.dim() == 0
@@ -387,8 +429,9 @@ class AuxHeadsMixin:
             if ws is None:       # (first eager step: zeroed exchange words of `asac_mse_mean_grad`, kept by the learner)
                 from asac_amd import native
                 ws = self._mse_big_ws = torch.zeros(native.mse_mean_grad_workspace(), dtype=torch.float32, device=self.device)
-            with fused_mse_loss(ws):
-                loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
+            # (the frame loss prepares its gradient for the division below: no second pass over the frames' gradient)
+            with fused_mse_loss(ws, grad_scale=1.0 / self.n_step):
+                loss_obs = _DivConstFn.apply(self.model_observation.get_loss(nx_states, list(nx_obses_list)), self.n_step)
         else:
             loss_obs = self.model_observation.get_loss(nx_states, list(nx_obses_list)) / self.n_step
         model_params = [list(mod.parameters()) for mod in (self.model_transition, self.model_reward, self.model_observation)]

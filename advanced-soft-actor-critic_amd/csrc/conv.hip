@@ -88,9 +88,10 @@ struct TileAt {
     int64_t frame;
     int r0, c0, skip_y, skip_x;
 };
+template <bool TILED>
 __device__ __forceinline__ TileAt tile_at(const ConvDims& d, int64_t g) {
     TileAt t;
-    if (d.tiles == 1) {
+    if (!TILED) {
         t.frame = g * d.G, t.r0 = t.c0 = t.skip_y = t.skip_x = 0;
         return t;
     }
@@ -182,12 +183,13 @@ __device__ __forceinline__ void build_croptab(const ConvDims& d, int* croptab) {
 
 // frames of group g -> LDS through the DMA path; frames beyond the batch re-read the last real one (their results
 // are never stored and their gradients are zero)
+template <bool TILED = false>
 __device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float* img, int wave, int lane,
                                              const int* croptab = nullptr) {
     const ConvDims& d = a.d;
-    if (d.tiles > 1) {
+    if (TILED) {
         // the crop of frame g / tiles that block g % tiles needs: a lane's 16 bytes come from wherever the table says
-        const TileAt t = tile_at(d, g);
+        const TileAt t = tile_at<true>(d, g);
         const float* src = group_frames(a, t.frame) + (int64_t)(t.r0 * d.s2 * d.s1) * d.FW + t.c0 * d.s2 * d.s1;
         const int chunks = (d.CHW + 255) >> 8;
         for (int c = wave; c < chunks; c += kConvThreads / 64) {
@@ -293,6 +295,9 @@ __device__ __forceinline__ void conv1_finish(const ConvArgs& a, int64_t g, int r
     conv1_store(a, g, row, abase, z_rows, oc, z, gelu_f(z), a1);
 }
 
+// (TILED: a second instantiation — the whole-frame form keeps the code it had before the tiled mode existed: with the
+// block addressing compiled in, its launches were 0.5-2.8 us longer at cfg4's sizes)
+template <bool TILED>
 __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvDims& d = a.d;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
-    if (d.tiles > 1) build_croptab(d, croptab);
+    if (TILED) build_croptab(d, croptab);
     // parameters pass through the (still free) work area: W1 | W2
     coop_copy2(a.w1, d.O1 * d.K1, a.w2, d.O2 * d.K2, img);
     __syncthreads();
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // layer 2: this lane's A row (position lr of the 16) and the two output elements this thread finishes
     int base2;
     {
-        const int lrc = min(lr, d.G * d.M2 - 1);      // (rows beyond the group's positions — a 3 x 3 block — repeat the last)
+        const int lrc = TILED ? min(lr, d.G * d.M2 - 1) : lr;      // (rows beyond a block's positions repeat the last)
         const int im = lrc / d.M2, pos = lrc - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
         base2 = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
     }
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         e_im[q] = row / d.M2;
         const int pos = row - e_im[q] * d.M2;
         e_py[q] = pos / d.W2, e_px[q] = pos - e_py[q] * d.W2;
-        e_out[q] = oc < d.O2 ? oc * d.FM2 : -1;
+        e_out[q] = oc < d.O2 ? (TILED ? oc * d.FM2 : oc * d.M2 + pos) : -1;
     }
     float b1s = b1v;
     const int qa = (Q1 * wave) / 4, qb = (Q1 * (wave + 1)) / 4;    // this wave's share of a split tail tile
@@ -388,12 +393,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
     // (tiled mode: the host has checked the 16-byte granularity the crops need)
-    const bool dma = d.tiles > 1 ||
+    const bool dma = TILED ||
                      ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0);
-    if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames(a, blockIdx.x, img, wave, lane, croptab);
+    if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         const int n_img = (int)min((int64_t)d.G, a.N - g * d.G);
-        const TileAt at = tile_at(d, g);
+        const TileAt at = tile_at<TILED>(d, g);
         const int z_rows = n_img * d.M1;
         if (dma) {
             dma_barrier();
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
                 for (int r = 0; r < 4; ++r) red[(u * 4 + wave) * 256 + (4 * lk + r) * 16 + lr] = tail[u][r];
             }
         lds_barrier();             // the frames are consumed
-        if (dma && g + gridDim.x < a.n_groups) async_frames(a, g + gridDim.x, img, wave, lane, croptab);
+        if (dma && g + gridDim.x < a.n_groups) async_frames<TILED>(a, g + gridDim.x, img, wave, lane, croptab);
         for (int u = 0; u < rem; ++u) {
             const float* ru = red + u * 4 * 256;
             const int e = threadIdx.x;                 // element (row e/16, channel e%16) of the tile
@@ -454,11 +459,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
             const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
-            if (e_out[q] >= 0 && e_im[q] < n_img && e_py[q] >= at.skip_y && e_px[q] >= at.skip_x) {
+            if (e_out[q] >= 0 && e_im[q] < n_img && (!TILED || (e_py[q] >= at.skip_y && e_px[q] >= at.skip_x))) {
                 const int i = row * 16 + (oc & 15);
                 const float z = (red[(2 * c2) * 256 + i] + red[(2 * c2 + 1) * 256 + i]) + e_bias[q];
-                const int64_t o = (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] + (at.r0 + e_py[q]) * d.FW2 +
-                                  at.c0 + e_px[q];
+                const int64_t o = TILED ? (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] +
+                                              (at.r0 + e_py[q]) * d.FW2 + at.c0 + e_px[q]
+                                        : (g * d.G + e_im[q]) * (d.O2 * d.M2) + e_out[q];
                 a.y[o] = gelu_f(z);
                 if (a.z2) a.z2[o] = z;
             }
@@ -501,6 +507,7 @@ __host__ __device__ inline int conv_param_count(const ConvDims& d) { return d.O1
 constexpr int kNT1 = kConvMaxK / 16 / 4;        // layer-1 weight-gradient column tiles per wave (k1 index / 16)
 constexpr int kNT2 = kConvMaxK / 16 / 4;        // layer-2 weight-gradient column tiles per wave, per row tile
 
+template <bool TILED>
 __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvDims& d = a.d;
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows_pad = d.RT1 * 16;
     const int NT1 = d.K1 / 16, NT2 = d.K2 / 16;
-    if (d.tiles > 1) build_croptab(d, croptab);
+    if (TILED) build_croptab(d, croptab);
 
     // index tables, one entry per thread (see the note on integer division above)
     for (int row = threadIdx.x; row < rows_pad; row += kConvThreads) {
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     // rows (4 lk + r), and the two dz2 elements (e / 32, e % 32) this thread forms
     // (rows beyond the group's G * M2 positions — 7 of the 16 with a 3 x 3 block — carry dz2 = 0: their operand
     // addresses repeat the last real row's, their col2im contributions are dropped)
-    const int last_row = d.G * d.M2 - 1;
+    const int last_row = TILED ? d.G * d.M2 - 1 : 15;
     const int reach = (d.k2 + d.s2 - 1) / d.s2, n_col = reach * reach;
     int rowbase[4], acc_pos[4], acc_base[4], acc_col[4], e_im[2], e_out[2], e_py[2], e_px[2];
 #pragma unroll
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         acc_pos[r] = 4 * lk + r <= last_row ? pos : -1;
         acc_base[r] = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
         // colour class of the position (frames of a group never overlap, but one pass per colour serves them all)
-        acc_col[r] = acc_pos[r] < 0 ? -1 : (oy % reach) * reach + (ox % reach);
+        acc_col[r] = !TILED || acc_pos[r] < 0 ? -1 : (oy % reach) * reach + (ox % reach);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -584,16 +591,16 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         e_im[q] = row / d.M2;
         const int pos = row - e_im[q] * d.M2;
         e_py[q] = pos / d.W2, e_px[q] = pos - e_py[q] * d.W2;
-        e_out[q] = oc < d.O2 ? oc * d.FM2 : -1;
+        e_out[q] = oc < d.O2 ? (TILED ? oc * d.FM2 : oc * d.M2 + pos) : -1;
     }
     // frames and saved z1 rows travel by LDS-DMA when 16-byte granular; the output-side operands (two elements of gy
     // and z2 per thread) are fetched into registers one group ahead
-    const bool dma = d.tiles > 1 ||
+    const bool dma = TILED ||
                      ((d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 && (a.x_sample_stride & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0);
     auto request = [&](int64_t g, int buf) {
-        if (d.tiles > 1) {
-            async_frames(a, g, lds + p.img + buf * p.img_size, wave, lane, croptab);
+        if (TILED) {
+            async_frames<true>(a, g, lds + p.img + buf * p.img_size, wave, lane, croptab);
             return;
         }
         const int64_t first = g * d.G;
@@ -611,13 +618,14 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     auto fetch_out = [&](int64_t g) {
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
-        const TileAt at = tile_at(d, g);
+        const TileAt at = tile_at<TILED>(d, g);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             gy_n[q] = z2_n[q] = 0.f;
-            if (e_out[q] >= 0 && e_im[q] < n_img && e_py[q] >= at.skip_y && e_px[q] >= at.skip_x) {
-                const int64_t o = (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] + (at.r0 + e_py[q]) * d.FW2 +
-                                  at.c0 + e_px[q];
+            if (e_out[q] >= 0 && e_im[q] < n_img && (!TILED || (e_py[q] >= at.skip_y && e_px[q] >= at.skip_x))) {
+                const int64_t o = TILED ? (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] +
+                                              (at.r0 + e_py[q]) * d.FW2 + at.c0 + e_px[q]
+                                        : (first + e_im[q]) * (d.O2 * d.M2) + e_out[q];
                 gy_n[q] = a.gy[o];
                 z2_n[q] = a.z2[o];
             }
@@ -708,20 +716,23 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i)
-                        if (wave + 4 * i < NT2 && acc_pos[r] >= 0) da1[acc_base[r] + k2off[i]] += dp[i][r];
+                        if (wave + 4 * i < NT2 && (!TILED || acc_pos[r] >= 0)) da1[acc_base[r] + k2off[i]] += dp[i][r];
                     lds_barrier();
                 }
             } else {
                 // positions whose patches cannot overlap — same (oy, ox) modulo ceil(k2 / s2) — go in one pass: 4 passes
                 // for the `simple` preset's 4 x 4 / 2 second layer instead of one per position (15 with 3 x 5 blocks)
-                for (int col = 0; col < n_col; ++col) {
+                // (the whole-frame form keeps one pass per position: its maps of 8 / 16 positions are not on a BASELINE path,
+                // and the colour bookkeeping cost its other branch registers — 34 more SGPR spills, +1.8 us a launch)
+                const int passes = TILED ? n_col : d.M2;
+                for (int col = 0; col < passes; ++col) {
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i) {
                         if (wave + 4 * i < NT2) {
                             const int ko = k2off[i];
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (acc_col[r] == col) da1[acc_base[r] + ko] += dp[i][r];
+                                if ((TILED ? acc_col[r] : acc_pos[r]) == col) da1[acc_base[r] + ko] += dp[i][r];
                         }
                     }
                     lds_barrier();
@@ -973,9 +984,14 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, in
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t cap = 256 * per_cu;
     const unsigned blocks = (unsigned)(a.n_groups < cap ? a.n_groups : cap);
-    static bool attr = false;
-    if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_fwd), attr, "asac_conv2_forward")) return rc;
-    ASAC_LAUNCH(k_conv2_fwd, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
+    static bool attr = false, attr_t = false;
+    if (a.d.tiles > 1) {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_fwd<true>), attr_t, "asac_conv2_forward")) return rc;
+        ASAC_LAUNCH(k_conv2_fwd<true>, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
+    } else {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_fwd<false>), attr, "asac_conv2_forward")) return rc;
+        ASAC_LAUNCH(k_conv2_fwd<false>, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
+    }
     return finish_launch("asac_conv2_forward");
 }
 
@@ -1007,12 +1023,17 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
     a.partial = workspace;
     a.N = N * a.d.tiles;
     a.n_groups = (a.N + a.d.G - 1) / a.d.G;
-    static bool attr = false;
-    if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd), attr, "asac_conv2_backward")) return rc;
+    static bool attr = false, attr_t = false;
     const size_t lds = (size_t)conv_bwd_plan(a.d).total * sizeof(float);
     const unsigned blocks = (unsigned)(a.n_groups < kConvBwdGroupsCap ? a.n_groups : kConvBwdGroupsCap);
     hipStream_t s = as_stream(stream);
-    ASAC_LAUNCH(k_conv2_bwd, dim3(blocks), dim3(kConvThreads), lds, s, a);
+    if (a.d.tiles > 1) {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd<true>), attr_t, "asac_conv2_backward")) return rc;
+        ASAC_LAUNCH(k_conv2_bwd<true>, dim3(blocks), dim3(kConvThreads), lds, s, a);
+    } else {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd<false>), attr, "asac_conv2_backward")) return rc;
+        ASAC_LAUNCH(k_conv2_bwd<false>, dim3(blocks), dim3(kConvThreads), lds, s, a);
+    }
     const int n = conv_param_count(a.d);
     // launched once (not under the repeat knob: it may accumulate)
     hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,

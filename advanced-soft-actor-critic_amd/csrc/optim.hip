@@ -212,11 +212,12 @@ __global__ __launch_bounds__(kMseThreads) void k_masked_mse(const float* __restr
 constexpr int kMseBigGrid = 2048;
 __global__ __launch_bounds__(kMseThreads) void k_mse_big(const float* __restrict__ pred, const float* __restrict__ target,
                                                          int64_t target_sb, int64_t target_st, int T, int K4,
-                                                         unsigned int n4, float inv_n, float* __restrict__ grad,
-                                                         float* __restrict__ loss, float* partial, unsigned int* counter) {
+                                                         unsigned int n4, float inv_n, float grad_scale,
+                                                         float* __restrict__ grad, float* __restrict__ loss, float* partial,
+                                                         unsigned int* counter) {
     __shared__ float red[kMseThreads];
     __shared__ bool last;
-    const float scale = 2.f * inv_n;
+    const float scale = 2.f * inv_n * grad_scale;
     const float4* p4 = reinterpret_cast<const float4*>(pred);
     float4* g4 = reinterpret_cast<float4*>(grad);
     constexpr int U = 4;
@@ -516,7 +517,7 @@ int asac_masked_mse(const float* pred, const float* target, int64_t target_strid
 int64_t asac_mse_mean_grad_workspace(void) { return kMseBigGrid + 1; }
 
 int asac_mse_mean_grad(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T,
-                       int K, float* grad_out, float* loss_out, float* workspace, void* stream) {
+                       int K, float grad_scale, float* grad_out, float* loss_out, float* workspace, void* stream) {
     const int64_t n = (int64_t)B * T * K;
     if (B <= 0 || T <= 0 || K <= 0 || (K & 3) || !pred || !target || !grad_out || !loss_out || !workspace ||
         n / 4 >= 0x7fffffffll || (target_stride_b & 3) || (target_stride_t & 3) ||
@@ -526,7 +527,7 @@ int asac_mse_mean_grad(const float* pred, const float* target, int64_t target_st
     const int64_t want = ((int64_t)n4 + kMseThreads * 4 - 1) / (kMseThreads * 4);
     const unsigned blocks = (unsigned)(want < kMseBigGrid ? want : kMseBigGrid);
     ASAC_LAUNCH(k_mse_big, dim3(blocks), dim3(kMseThreads), 0, as_stream(stream), pred, target, target_stride_b,
-                target_stride_t, T, K / 4, n4, 1.f / (float)n, grad_out, loss_out, workspace,
+                target_stride_t, T, K / 4, n4, 1.f / (float)n, grad_scale, grad_out, loss_out, workspace,
                 reinterpret_cast<unsigned int*>(workspace + kMseBigGrid));
     return finish_launch("asac_mse_mean_grad");
 }

@@ -293,8 +293,8 @@ _SIGNATURES = {
     'asac_masked_mse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_mse_mean_grad_workspace': (C.c_int64, []),
-    'asac_mse_mean_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_mse_mean_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_masked_mse_workspace': (C.c_int64, [C.c_int64]),
     'asac_normal_nll_kl_workspace': (C.c_int64, [C.c_int64]),
     'asac_normal_nll_kl': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -1243,13 +1243,13 @@ def masked_mse(pred, target, padding_mask, grad_out, loss_out):
 
 
 @_profiled
-def mse_mean_grad(pred, target, grad_out, loss_out, workspace):
+def mse_mean_grad(pred, target, grad_out, loss_out, workspace, grad_scale: float = 1.0):
     """loss_out <- mean((pred - target)^2), grad_out <- its gradient w.r.t. pred; pred [B, T, K] dense, target a [B, T, K]
     view with a dense last dimension (see `mse_mean_grad_ok`); `workspace`: zeros(mse_mean_grad_workspace()), kept by the caller"""
     B, T, K = pred.shape
     pt, sb, st = _window3(target)
-    _check(load().asac_mse_mean_grad(_p(pred), pt, sb, st, B, T, K, _p(grad_out), _p(loss_out), _p(workspace), _stream()),
-           'asac_mse_mean_grad')
+    _check(load().asac_mse_mean_grad(_p(pred), pt, sb, st, B, T, K, float(grad_scale), _p(grad_out), _p(loss_out),
+                                     _p(workspace), _stream()), 'asac_mse_mean_grad')
 
 
 def mse_mean_grad_workspace() -> int:

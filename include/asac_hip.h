@@ -1083,13 +1083,15 @@ int asac_masked_mse(const float* pred, const float* target, int64_t target_strid
 
 /* The plain mean squared error over millions of elements and its gradient, one launch, one read of both operands (a
  * plugin's observation loss `mse_loss(decoded frames, frames)` under sac_base.py:1817 / 1798-1839:
- * *loss_out = sum (pred - target)^2 / N, grad_out = (pred - target) * 2 / N, N = B T K).  pred / grad_out [B][T][K]
+ * *loss_out = sum (pred - target)^2 / N, grad_out = grad_scale * (pred - target) * 2 / N, N = B T K; grad_scale: the factor
+ * the caller is going to multiply the loss with — 1 / n_step in `_train_rpm` — so that the gradient needs no second pass
+ * over its 44 MB).  pred / grad_out [B][T][K]
  * dense, target strided (floats) like asac_masked_mse's; K and the strides multiples of 4, 16-byte aligned pointers;
  * N < 2^33.  Fixed summation order.  workspace: f32[asac_mse_mean_grad_workspace()], ZERO before its first use (left
  * zero by every launch). */
 int64_t asac_mse_mean_grad_workspace(void);
 int asac_mse_mean_grad(const float* pred, const float* target, int64_t target_stride_b, int64_t target_stride_t, int B, int T,
-                       int K, float* grad_out, float* loss_out, float* workspace, void* stream);
+                       int K, float grad_scale, float* grad_out, float* loss_out, float* workspace, void* stream);
 
 /* Loss of the recurrent prediction model's transition head and its gradient (SAC_Base._train_rpm,
  * sac_base.py:1798-1816; torch/distributions/normal.py log_prob / entropy, kl.py _kl_normal_normal):
