@@ -5,15 +5,19 @@ import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r04'
+R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r05'
 
-for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
-    shutil.copy(R / f'{c}_bench.json', P / f'{TAG}_{c}_bench.json')
+CFGS = ('cfg2', 'cfg3', 'cfg4', 'cfg4_84', 'cfg5')
+for c in CFGS:
+    # (one JSON document per file: cfg2's is bench_details.json, indented; the others the `--emit full` line)
+    d = json.loads((R / f'{c}_bench.json').read_text().strip().splitlines()[-1] if c != 'cfg2' else (R / f'{c}_bench.json').read_text())
+    (P / f'{TAG}_{c}_bench.json').write_text(json.dumps(d) + '\n')
+shutil.copy(R / 'cfg2_bench_line.json', P / f'{TAG}_cfg2_bench_line.json')
 for name in ('cfg2_kernel_stats.csv', 'cfg2_kernel_stats_summary.txt', 'kernel_sweep.txt', 'cfg2_step_sequence.txt',
              'cfg3_step_sequence.txt', 'cfg4_step_sequence.txt', 'cfg5_step_sequence.txt', 'cfg3_kernel_stats_summary.txt',
              'cfg4_kernel_stats_summary.txt', 'cfg5_kernel_stats_summary.txt', 'cfg5_without_prediction_step_sequence.txt',
              'cfg5_without_prediction_kernel_stats_summary.txt', 'cfg2_kernel_stats.json', 'cfg3_kernel_stats.json',
-             'cfg4_kernel_stats.json', 'cfg5_kernel_stats.json', 'cfg5_without_prediction_kernel_stats.json',
+             'cfg4_kernel_stats.json', 'cfg5_kernel_stats.json', 'cfg4_84_kernel_stats.json', 'cfg4_84_kernel_stats_summary.txt', 'cfg4_84_step_sequence.txt', 'cfg5_without_prediction_kernel_stats.json',
              'cfg3_h64_kernel_stats.json', 'cfg3_h64_kernel_stats_summary.txt', 'cfg3_h64_step_sequence.txt',
              'cfg_attn_h64_kernel_stats.json', 'cfg_attn_h64_kernel_stats_summary.txt', 'cfg_attn_h64_step_sequence.txt',
              'cfg2_lookahead_step_sequence.txt', 'cfg2_lookahead_kernel_stats.json', 'cfg2_lookahead_kernel_stats_summary.txt'):
@@ -25,7 +29,7 @@ for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',
                          'bench.py cfg2 (--steps 100 --warmup 10 --fill 20000, hipgraph replay) under rocprofv3 --pmc (two passes); per-launch averages'),
                         *[(f'{c}_pmc_traffic.json', f'{TAG}_{c}_pmc_traffic',
                            f'bench.py --config {c} (--steps 60 --warmup 10 --fill 20000, hipgraph replay) under rocprofv3 --pmc (two passes); per-launch averages')
-                          for c in ('cfg3', 'cfg4', 'cfg5') if (R / f'{c}_pmc_traffic.json').exists()]):
+                          for c in ('cfg3', 'cfg4', 'cfg4_84', 'cfg5') if (R / f'{c}_pmc_traffic.json').exists()]):
     d = {k: v for k, v in json.load(open(R / src)).items() if k.startswith('asac::')}
     json.dump(d, open(P / f'{dst}.json', 'w'), indent=1, sort_keys=True)
     lines = [f'# {title}', '# fetch x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md "HBM"); write is raw',
@@ -34,7 +38,7 @@ for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',
     for k, v in sorted(d.items(), key=lambda kv: -(kv[1]['fetch_bytes_raw'] or 0)):
         lines.append(f'{k:52s} {v["launches"]:8d} {fmt(v["fetch_bytes_raw"])} {fmt(v["fetch_bytes_corrected"])} {fmt(v["write_bytes_raw"])}')
     (P / f'{dst}.txt').write_text('\n'.join(lines) + '\n')
-for c in ('cfg2', 'cfg3', 'cfg4', 'cfg5'):
+for c in CFGS:
     d = json.load(open(P / f'{TAG}_{c}_bench.json'))
     r, h = d['roofline'] or {}, d['roofline_hbm'] or {}
     print(c, d['value'], d['ms_per_step'], 'cpu', d['cpu_baseline'] and d['cpu_baseline']['value'], '| roofline',
