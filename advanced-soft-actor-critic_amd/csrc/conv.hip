@@ -335,12 +335,18 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
+    const int Q1 = d.K1 / 16;
+    // layer-2 weights of this wave's (column tile, k half): B operand element (k = 4 step + lk, column lr)
+    const int ct = wave >> 1, kh = wave & 1;
+    constexpr int S2H = kConvMaxK / 8;           // steps per k half
+    float w2r[S2H];
+    const int oc2 = ct * 16 + lr;
+    {
     if (TILED) build_croptab(d, croptab);
     // parameters pass through the (still free) work area: W1 | W2
     coop_copy2(a.w1, d.O1 * d.K1, a.w2, d.O2 * d.K2, img);
     __syncthreads();
     // layer-1 operand tables (see conv1_tile): element (quad, lane, u) <-> reduction index k = 16 quad + 4 u + lk
-    const int Q1 = d.K1 / 16;
     for (int i = threadIdx.x; i < Q1 * 256; i += kConvThreads) {
         const int u = i & 3, ln = (i >> 2) & 63, q = i >> 8;
         const int k = 16 * q + 4 * u + (ln >> 4), oc = ln & 15;
@@ -350,11 +356,6 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         const int u = i & 3, lkk = (i >> 2) & 3, q = i >> 4;
         ktq[i] = ktab[16 * q + 4 * u + lkk];
     }
-    // layer-2 weights of this wave's (column tile, k half): B operand element (k = 4 step + lk, column lr)
-    const int ct = wave >> 1, kh = wave & 1;
-    constexpr int S2H = kConvMaxK / 8;           // steps per k half
-    float w2r[S2H];
-    const int oc2 = ct * 16 + lr;
     {
         const float* w2l = img + d.O1 * d.K1 + min(oc2, d.O2 - 1) * d.K2;
 #pragma unroll
@@ -363,6 +364,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             const float v = w2l[min(k, d.K2 - 1)];
             w2r[s] = (k < d.K2 && oc2 < d.O2) ? v : 0.f;
         }
+    }
     }
     __syncthreads();               // the work area is free again
     const int full = d.RT1 & ~3, rem = d.RT1 & 3;
