@@ -15,16 +15,25 @@ plainly with --gpus N.  Every rank owns a replay shard (capacity 524288/N); grad
 `value` is always the rate of plain `SAC_Base.train()` calls (one call, one hipGraph launch, one step — the reference's
 loop); `value_runs_of_4` beside it is the same work issued as `SAC_Base.train_steps(4)` (one graph launch per four steps).
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline      the dominant KERNEL of the step (launches grouped by kernel name, mean launch time from HIP events on
-                the launch stream): algorithmic flops or bytes / time vs the gfx950 peak, PMC traffic
+Output (rank 0).  The LAST line of stdout is ONE compact JSON line under 4 KB — what the driver parses: the contract fields,
+`config`, ONE `roofline` (the dominant kernel), ONE `roofline_hbm` (K1-K4), `cpu_baseline`, the side configurations as bare
+rates (`compact_line`, tests/test_bench_line.py).  The full record goes to bench_details.json (repo root and gpurun_out/):
+  roofline      the dominant KERNEL of the step (launches grouped by kernel name): algorithmic flops or bytes / time vs the
+                gfx950 peak, PMC traffic.  `frac` / `achieved` / `avg_launch_us` are the IN-SITU figures — the kernel's mean
+                duration inside the replayed hipGraph step, from the committed rocprofv3 --kernel-trace --stats summary of this
+                command (profiles/r05_<config>_kernel_stats.json, named in `frac_source`); the live HIP-event figures (each
+                launch re-issued 20x back to back on the launch stream: warm caches, optimistic) sit beside them as
+                `*_hip_events`
   roofline_hbm  the north-star's "sample + return" kernels K1-K4 (sample + IS weights, window gather, return / min / V)
-                as one group: algorithmic bytes / time vs the HBM peak at this batch size, PMC traffic and its ratio
+                as one group, same convention
   sweep         the same kernels at saturating sizes (tools/kernel_sweep.py), where the HBM fraction is meaningful
-  configs       train steps/s of the other BASELINE configurations (cfg3 / cfg4 / cfg5), each in its own process
+  configs       the other BASELINE configurations and the side configurations (cfg3 / cfg4 / cfg4_84 / cfg5 / ..., the
+                headline with one batch in flight, the headline on one rank with every collective forced), each in its own
+                process with ITS rooflines and CPU baseline
   kernels       the per-entry-point accounting for every libasac_hip launch of the step
   cpu_baseline  the CPU oracle (`oracle/sac_ref.py`, a port of the reference's step) timed on this
                 host's cores on the same workload (bounded sample)
+`--emit full` prints the full record as the one line instead (what the side runs and tools/ read).
 """
 import argparse
 import json
