@@ -7,11 +7,17 @@
 namespace asac {
 
 constexpr int kGatherBlock = 256;
-// units per thread (template parameter UNROLL): 4 keeps >= 4 x 16 B loads in flight per lane — what a gather of
-// megabytes wants (70-75 % of the HBM peak); a gather of a few thousand units (the headline batch: 8 keys x 1 280 rows)
-// is a handful of workgroups that way, each thread walking four dependent id -> index ring -> row chains: with ONE
-// unit per thread and four times the workgroups the same launch is 4 us shorter (cfg2: +4 % steps/s, A/B on one box)
-constexpr int kUnrollLarge = 4;
+// units per thread (template parameter UNROLL): a gather of a few thousand units (the headline batch: 8 keys x 1 280 rows)
+// wants ONE unit per thread — with more, each thread walks several dependent id -> index ring -> row chains and the launch
+// is a handful of workgroups (cfg2: +4 % steps/s, A/B on one box).  A gather of megabytes wants a few 16-byte loads in
+// flight per lane: TWO (round 5; it had been four since round 1).  `tools/k14_probe.py`, fresh ids every launch, 100 / 200
+// MB on a 711 MB ring: one unit 21.2 / 36.7 us, two 20.7 / 35.2, three 21.4 / 36.5, four 21.4 / 37.3, six 24.6 / 38.2;
+// in the step (A/B on one box): cfg4 2 895 vs 2 874 steps/s, cfg5 438.9 vs 437.8; the kernel in situ 22.8 / 40.1 us
+// against 23.7-24.8 / 41.6-45.
+#ifndef ASAC_GATHER_UNROLL
+#define ASAC_GATHER_UNROLL 2
+#endif
+constexpr int kUnrollLarge = ASAC_GATHER_UNROLL;
 constexpr int64_t kSmallGatherBlocks = 8192;      // up to this many one-unit workgroups: UNROLL = 1 (cfg3: 1 100, +0.9 %)
 
 struct GatherKeyDev {
