@@ -388,19 +388,27 @@ class DeviceNoise:
                            for t in (u, flat, subsets) if t is not None]
 
     def begin_step_with_sample(self, step_counter, rb, flat, subsets=None, ensemble: int = 0, polyak=None,
-                               zero=None, gather: bool = False) -> int:
+                               zero=None, gather: bool = False, defer_weights: bool = False) -> int:
         """`begin_step` and the replay buffer's stratified sample (`rb.sample_into_static`'s tree walk) as ONE launch
         when that form applies (this source feeds the sampler, batch <= 1024); with a sharded replay
         (`rb.min_ratio_reducer`) the launch leaves the IS weights to `rb.sample_into_static`, which needs the MIN over
         ranks first;  -> 0 (not applicable), 1 (sampled: the caller runs only the buffer's weights / gather) or, with
         `gather`, 2: the window gather of the drawn batch was part of the same launch too
-        (`asac_step_prologue_sample_gather`)."""
+        (`asac_step_prologue_sample_gather`); with `defer_weights` and a batch of 257 .. 1 024 on one GPU, 3: sampled, and
+        the IS weights are left to the gather's launch (`rb.sample_into_static(sampled=3)`: `asac_window_gather_pad_w`)."""
         if (rb.uniform_source is not self or rb.sharded is not None
                 or rb.batch_size > native.PROLOGUE_SAMPLE_MAX_BATCH):
             return 0
         if subsets is not None and subsets.shape[1] == ensemble:
             subsets = None
         gather = gather and rb._gather_keys is not None
+        if (defer_weights and not gather and rb.min_ratio_reducer is None and rb.batch_size > 256
+                and rb._gather_keys is not None):
+            native.step_prologue_sample_partial(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
+                                                rb.capacity, rb.batch_size, rb._slot_ids, rb._leaf, rb._p, rb._ids, rb._min_p)
+            self._prefilled = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
+                               for t in (rb._u, flat, subsets) if t is not None]
+            return 3
         if gather:
             native.step_prologue_sample_gather(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
                                                rb.capacity, rb.batch_size, rb._slot_ids, rb._beta,

@@ -453,7 +453,8 @@ class PrioritizedReplayBuffer:
     def sample_into_static(self, sampled: int = 0) -> None:
         """The device part of `sample()` (no host logic; safe inside graph capture).  `sampled`: 1 — the tree walk
         (leaf, p, ids, IS weights) has already been done by the caller's fused prologue launch; 2 — and the window gather
-        too (`NoiseSource.begin_step_with_sample(..., gather=True)`)."""
+        too (`NoiseSource.begin_step_with_sample(..., gather=True)`); 3 — the tree walk has been done, the IS weights have
+        not: the gather's launch forms them (`asac_window_gather_pad_w`)."""
         B, C = self.batch_size, self.capacity
         if self.sharded is not None:       # "parity" mode: the batch is drawn over every rank's shard (host logic)
             self.sharded.sample_into(self)
@@ -472,7 +473,10 @@ class PrioritizedReplayBuffer:
             reducer(self._min_p[1:2])
             native.per_is_weights(self._p, B, self._tree, self._min_p[1:2], self._beta,
                                   self.beta_increment_per_sampling, self._w)
-        if sampled != 2:
+        if sampled == 3:
+            native.window_gather_pad_w(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, self._index_ring(),
+                                       self._p, self._tree, self._beta, self.beta_increment_per_sampling, self._w, self._min_p)
+        elif sampled != 2:
             native.window_gather_pad(self._gather_keys, self._ids, B, self.prev_n, self.post_n, C, self._index_ring())
 
     # ------------------------------------------------------------------------------------------

@@ -241,6 +241,9 @@ class SAC_Base(AuxHeadsMixin):
         # steps each) 11 567 steps/s with it against 11 664 without, although the merged launch is 1.8 us shorter than the two
         # under rocprofv3 — the gather's workgroups sleep and poll for the ids ~2.5 us, about what a launch boundary costs
         self._prologue_gather = bool(hip_config.get('prologue_gather', False))
+        # batches of 257 .. 1 024: the IS weights in an extra workgroup of the gather's launch instead of behind an exchange
+        # between the sampler's workgroups (asac_step_prologue_sample_partial + asac_window_gather_pad_w)
+        self._defer_is_weights = bool(hip_config.get('defer_is_weights', True))
         self._fused_policy_step = bool(hip_config.get('fused_policy_step', True))
         self._fused_forward_chain = bool(hip_config.get('fused_forward_chain', True))
         self._fused_td_chain = bool(hip_config.get('fused_td_chain', True))
@@ -1791,7 +1794,7 @@ class SAC_Base(AuxHeadsMixin):
             # ... and the sampler and the window gather of the batch it draws (`prologue_gather`): one launch for K1-K3 + K5
             sampled = self._use_sidecars and self.noise.begin_step_with_sample(
                 self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero,
-                gather=self._prologue_gather)
+                gather=self._prologue_gather, defer_weights=self._defer_is_weights)
             if not sampled:
                 self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
                                       self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)

@@ -123,6 +123,13 @@ __device__ __forceinline__ const ASAC_KARG void* kernarg_base() {
 #endif
 }
 
+// IS weight of one sampled row (reference replay_buffer.py:352-354 under NumPy 2 promotion rules)
+__device__ __forceinline__ float is_weight(float p, float total, float min_ratio, double beta) {
+    const float ratio = p / total;                   // float32, like NumPy
+    const float rel = ratio / min_ratio;
+    return (float)pow((double)rel, -beta);           // float64 power, then astype(float32)
+}
+
 // a by-value copy of (a part of) the kernel arguments, fetched where the copy is made
 template <typename T>
 __device__ __forceinline__ T karg_copy(const ASAC_KARG T* p) {

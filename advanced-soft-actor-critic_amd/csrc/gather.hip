@@ -19,6 +19,44 @@ __global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad(const Gather
     gather_block<NK, kUnroll>(m, blockIdx.x);
 }
 
+// ... with the batch's IS weights (K2) formed by ONE extra workgroup beside the gather's: the sampler of the launch in
+// front (asac_step_prologue_sample_partial: a workgroup per 256 samples) left its workgroups' minima in min_p_out[2..]; here
+// they are combined, beta advances, and the weights of all <= 1 024 rows are written — under a gather of tens of
+// microseconds instead of behind a cross-workgroup exchange inside the sampler (~1.5 us of the step's first launch).
+struct WeightsJob {
+    const float* p;            // [batch] leaf priorities of the sampled rows
+    const float* tree;         // tree[0] = total
+    double* beta_state;
+    double beta_increment;
+    float* w_out;              // [batch]
+    float* min_p_out;          // [0] <- min p; [2 .. 2 + parts) the sampler workgroups' minima
+    int32_t batch, parts;
+};
+
+__device__ __forceinline__ void weights_job(const WeightsJob& j) {
+    float bm = j.min_p_out[2];
+    for (int k = 1; k < j.parts; ++k) bm = fminf(bm, j.min_p_out[2 + k]);
+    const float root = j.tree[0];
+    const double b = fmin(1.0, *j.beta_state + j.beta_increment);
+    const float min_ratio = bm / root;
+    __syncthreads();               // every lane has read the old beta
+    for (int i = threadIdx.x; i < j.batch; i += kGatherBlock) j.w_out[i] = is_weight(j.p[i], root, min_ratio, b);
+    if (threadIdx.x == 0) {
+        *j.beta_state = b;
+        j.min_p_out[0] = bm;
+    }
+}
+
+template <int NK, int kUnroll>
+__global__ __launch_bounds__(kGatherBlock) void k_window_gather_pad_w(const GatherLaunch<NK> m, unsigned gather_blocks,
+                                                                      const WeightsJob j) {
+    if (blockIdx.x == 0) {         // (first in the grid: dispatched at once — as the LAST workgroup it started when the
+        weights_job(j);            //  gather was nearly through and its f64 powers stuck out of the launch by ~1.2 us)
+        return;
+    }
+    gather_block<NK, kUnroll>(m, blockIdx.x - 1);
+}
+
 // K7 (asac_sidecar.h: ScatterArgs, scatter_elect_row, scatter_write_row)
 __global__ __launch_bounds__(256) void k_scatter_elect(const ScatterArgs a) {
     scatter_elect_row(a, blockIdx.x * blockDim.x + threadIdx.x);
@@ -170,6 +208,43 @@ int asac_window_gather_pad(const asac_gather_key_t* keys_host, int n_keys, const
                     as_stream(stream), m);
     }
     return finish_launch("asac_window_gather_pad");
+}
+
+int asac_window_gather_pad_w(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int batch, int prev_n,
+                             int post_n, int capacity, const int32_t* index_ring, const float* p, const float* tree,
+                             double* beta_state, double beta_increment, float* is_weights_out, float* min_p_out,
+                             void* stream) {
+    if (!p || !tree || !beta_state || !is_weights_out || !min_p_out || batch <= 256 || batch > 1024)
+        return bad_arg("asac_window_gather_pad_w");
+    GatherLaunch<ASAC_MAX_GATHER_KEYS> m{};
+    uint64_t blocks = 0;
+    int unroll = 0;
+    if (const int rc = gather_fill(keys_host, n_keys, ids, batch, prev_n, post_n, capacity, index_ring, 0, m, &blocks, &unroll))
+        return rc;
+    const dim3 grid((unsigned)blocks + 1u);
+    // (under the measurement repeat knob beta advances in the first repetition only)
+    for (int rep = 0; rep < g_launch_repeat; ++rep) {
+        const WeightsJob j{p, tree, beta_state, rep == 0 ? beta_increment : 0.0, is_weights_out, min_p_out, batch,
+                           (batch + 255) / 256};
+        if (n_keys <= 8) {
+            GatherLaunch<8> m8{};
+            for (int q = 0; q < n_keys; ++q) m8.key[q] = m.key[q];
+            m8.c = m.c;
+            if (unroll == 1)
+                hipLaunchKernelGGL((k_window_gather_pad_w<8, 1>), grid, dim3(kGatherBlock), 0, as_stream(stream), m8,
+                                   (unsigned)blocks, j);
+            else
+                hipLaunchKernelGGL((k_window_gather_pad_w<8, kUnrollLarge>), grid, dim3(kGatherBlock), 0, as_stream(stream),
+                                   m8, (unsigned)blocks, j);
+        } else if (unroll == 1) {
+            hipLaunchKernelGGL((k_window_gather_pad_w<ASAC_MAX_GATHER_KEYS, 1>), grid, dim3(kGatherBlock), 0,
+                               as_stream(stream), m, (unsigned)blocks, j);
+        } else {
+            hipLaunchKernelGGL((k_window_gather_pad_w<ASAC_MAX_GATHER_KEYS, kUnrollLarge>), grid, dim3(kGatherBlock), 0,
+                               as_stream(stream), m, (unsigned)blocks, j);
+        }
+    }
+    return finish_launch("asac_window_gather_pad_w");
 }
 
 int64_t asac_window_gather_plan_bytes(void) { return (int64_t)sizeof(GatherLaunch<ASAC_MAX_GATHER_KEYS>); }

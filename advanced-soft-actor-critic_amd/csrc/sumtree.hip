@@ -35,12 +35,6 @@ constexpr int kSampleBlock = 256;
 constexpr int kLdsLevels = 12;                       // nodes of levels 0..11 -> 4095 floats
 constexpr int kLdsNodes = (1 << kLdsLevels) - 1;
 
-__device__ __forceinline__ float is_weight(float p, float total, float min_ratio, double beta) {
-    const float ratio = p / total;                   // float32, like NumPy
-    const float rel = ratio / min_ratio;
-    return (float)pow((double)rel, -beta);           // float64 power, then astype(float32)
-}
-
 // STAGE_TOP: the top kLdsNodes nodes of the heap are staged into LDS first (one coalesced round trip,
 // then ~12 of the 19 levels cost an LDS read).  That pays for the BASELINE batch (1 workgroup); with
 // thousands of workgroups the 16 KB per workgroup would dwarf the useful traffic, and because the
@@ -83,7 +77,7 @@ __device__ __forceinline__ void sync_store(float* p, float v) { __hip_atomic_sto
 __device__ __forceinline__ float sync_load(float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false, bool EXPLICIT = false, int TRIPS = kFusedSampleMax / kSampleBlock,
-          bool MULTI = false, bool PUBLISH = false, int LDS_LEVELS = kLdsLevels>
+          bool MULTI = false, bool PUBLISH = false, int LDS_LEVELS = kLdsLevels, bool PARTIAL = false>
 __device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
     double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
@@ -284,6 +278,21 @@ __device__ __forceinline__ void sumtree_sample_body(
     }
     SampleSync* const sync = MULTI ? reinterpret_cast<SampleSync*>(min_p_out + 2) : nullptr;
     const unsigned n_wg = MULTI ? (unsigned)((batch + kSampleBlock - 1) / kSampleBlock) : 1u;
+    if (PARTIAL) {
+        // the weights are formed by a workgroup of the NEXT launch (asac_window_gather_pad_w, beside the gather): this
+        // workgroup's minimum is all that is left to hand over — no exchange, no power, no beta here
+        if (threadIdx.x == 0) {
+            float bm = red[0];
+            for (int w = 1; w < kSampleBlock / kWave; ++w) bm = fminf(bm, red[w]);
+            sync->part[blockIdx.x] = bm;
+        }
+#pragma unroll
+        for (int trip = 0; trip < kTrips; ++trip) {
+            const int i = first + trip * kSampleBlock;
+            if (live_[trip]) ids_out[i] = id_reg[trip];
+        }
+        return;
+    }
     if (MULTI) {
         if (threadIdx.x == 0) {
             float bm = red[0];
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(kSampleBlock) void k_sumtree_sample(
 // The first launch of a captured train step: workgroup 0 is the fused single-workgroup sampler (drawing its own
 // stratified uniforms), the others are the step prologue's workers (Polyak, gradient memset, Gaussian draws, ensemble
 // subsets): nothing the sampler reads is written by them.
+template <bool PARTIAL>
 __global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
     const PrologueArgs pa, const float* __restrict__ tree, int capacity, int levels, int batch,
     const int64_t* __restrict__ slot_ids, double* beta_state, double beta_increment, int32_t* __restrict__ leaf_out,
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
                 tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment, leaf_out, p_out, ids_out, w_out,
                 min_p_out, dr);
         else
-            sumtree_sample_body<true, true, true, false, 1, true, false, 13>(
+            sumtree_sample_body<true, true, true, false, 1, true, false, 13, PARTIAL>(
                 tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment, leaf_out, p_out, ids_out, w_out,
                 min_p_out, dr);
     } else {
@@ -819,12 +829,12 @@ int asac_per_is_weights_slice(const float* p_all, int n_all, int first, int coun
     return finish_launch("asac_per_is_weights_slice");
 }
 
-int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
-                              int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
-                              float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
-                              int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
-                              double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
-                              int64_t* ids_out, float* is_weights_out, float* min_p_out, void* stream) {
+static int prologue_sample_launch(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                                  int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                                  float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                                  int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                                  double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
+                                  int64_t* ids_out, float* is_weights_out, float* min_p_out, bool partial, void* stream) {
     if (!step_counter || n_normal < 0 || n_subsets < 0 || n_polyak < 0 || n_zero < 0 || !uniform_out ||
         (n_polyak > 0 && (!target || !source)) || (n_zero > 0 && !zero_out) || (n_normal > 0 && !normal_out))
         return bad_arg("asac_step_prologue_sample");
@@ -841,11 +851,40 @@ int asac_step_prologue_sample(float* target, const float* source, int64_t n_poly
         const int blocks_p = rep == 0 ? (int)pb : 0;
         const PrologueArgs a{seed, step_counter, uniform_out, batch, normal_out, n_normal, subsets_out, n_subsets, E_sample,
                              E, blocks_p, target, source, n_polyak, one_m_tau, tau, (int)zb, zero_out, n_zero};
-        hipLaunchKernelGGL(k_prologue_sample, dim3((unsigned)((batch + kSampleBlock - 1) / kSampleBlock + blocks_p + zb + (lanes + 255) / 256)),
-                           dim3(kSampleBlock), 0, as_stream(stream), a, tree, capacity, ilog2(capacity), batch, slot_ids,
-                           beta_state, rep == 0 ? beta_increment : 0.0, leaf_out, p_out, ids_out, is_weights_out, min_p_out);
+        const dim3 grid((unsigned)((batch + kSampleBlock - 1) / kSampleBlock + blocks_p + zb + (lanes + 255) / 256));
+        if (partial)
+            hipLaunchKernelGGL(k_prologue_sample<true>, grid, dim3(kSampleBlock), 0, as_stream(stream), a, tree, capacity,
+                               ilog2(capacity), batch, slot_ids, beta_state, 0.0, leaf_out, p_out, ids_out, is_weights_out,
+                               min_p_out);
+        else
+            hipLaunchKernelGGL(k_prologue_sample<false>, grid, dim3(kSampleBlock), 0, as_stream(stream), a, tree, capacity,
+                               ilog2(capacity), batch, slot_ids, beta_state, rep == 0 ? beta_increment : 0.0, leaf_out, p_out,
+                               ids_out, is_weights_out, min_p_out);
     }
     return finish_launch("asac_step_prologue_sample");
+}
+
+int asac_step_prologue_sample(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                              int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                              float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                              int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                              double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
+                              int64_t* ids_out, float* is_weights_out, float* min_p_out, void* stream) {
+    return prologue_sample_launch(target, source, n_polyak, tau, zero_out, n_zero, seed, step_counter, uniform_out, normal_out,
+                                  n_normal, subsets_out, n_subsets, E_sample, E, tree, capacity, batch, slot_ids, beta_state,
+                                  beta_increment, leaf_out, p_out, ids_out, is_weights_out, min_p_out, false, stream);
+}
+
+int asac_step_prologue_sample_partial(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                                      int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                                      float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                                      int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                                      int32_t* leaf_out, float* p_out, int64_t* ids_out, float* min_p_out, void* stream) {
+    if (batch <= kSampleBlock) return bad_arg("asac_step_prologue_sample_partial: one workgroup samples such a batch whole");
+    static double unused_beta = 0.0;      // (never dereferenced in the partial form)
+    return prologue_sample_launch(target, source, n_polyak, tau, zero_out, n_zero, seed, step_counter, uniform_out, normal_out,
+                                  n_normal, subsets_out, n_subsets, E_sample, E, tree, capacity, batch, slot_ids, &unused_beta,
+                                  0.0, leaf_out, p_out, ids_out, nullptr, min_p_out, true, stream);
 }
 
 int asac_step_prologue_sample_gather(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 65
+ABI_VERSION = 66
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -353,6 +353,13 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_step_prologue_sample_partial': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_uint64,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_window_gather_pad_w': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     'asac_step_prologue_sample_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_uint64,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
@@ -1656,6 +1663,36 @@ def step_prologue_sample(polyak, zero, seed, step_counter, uniform_out, normal_o
         _p(normal_out), nn_, _p(subsets_out), ns, es, int(ensemble), _p(tree), capacity, batch, _p(slot_ids),
         _p(beta_state), float(beta_increment), _p(leaf_out), _p(p_out), _p(ids_out), _p(is_weights_out), _p(min_p_out),
         _stream()), 'asac_step_prologue_sample')
+
+
+@_profiled
+def step_prologue_sample_partial(polyak, zero, seed, step_counter, uniform_out, normal_out, subsets_out, ensemble, tree,
+                                 capacity, batch, slot_ids, leaf_out, p_out, ids_out, min_p_out):
+    """`step_prologue_sample` for 256 < batch <= 1024 without the weights: the sampler workgroups leave their minima in
+    `min_p_out[2:]`; `window_gather_pad_w` (the next launch) forms the weights and advances beta"""
+    target_flat, source_flat, tau = polyak if polyak is not None else (None, None, 0.0)
+    assert uniform_out.numel() == batch and uniform_out.dtype == torch.float64 and 256 < batch <= PROLOGUE_SAMPLE_MAX_BATCH
+    assert min_p_out.numel() >= 528 and min_p_out.dtype == torch.float32
+    assert zero is None or (zero.is_contiguous() and zero.dtype == torch.float32)
+    nn_ = 0 if normal_out is None else normal_out.numel()
+    ns = es = 0
+    if subsets_out is not None:
+        assert subsets_out.dtype == torch.int32 and subsets_out.is_contiguous() and subsets_out.dim() == 2
+        ns, es = subsets_out.shape
+    _check(load().asac_step_prologue_sample_partial(
+        _p(target_flat), _p(source_flat), 0 if polyak is None else target_flat.numel(), float(tau), _p(zero),
+        0 if zero is None else zero.numel(), C.c_uint64(int(seed) & (2 ** 64 - 1)), _p(step_counter), _p(uniform_out),
+        _p(normal_out), nn_, _p(subsets_out), ns, es, int(ensemble), _p(tree), capacity, batch, _p(slot_ids),
+        _p(leaf_out), _p(p_out), _p(ids_out), _p(min_p_out), _stream()), 'asac_step_prologue_sample_partial')
+
+
+@_profiled
+def window_gather_pad_w(keys, ids, batch, prev_n, post_n, capacity, index_ring, p, tree, beta_state, beta_increment,
+                        is_weights_out, min_p_out):
+    """`window_gather_pad` + the IS weights of the batch `step_prologue_sample_partial` drew, one launch"""
+    _check(load().asac_window_gather_pad_w(keys, len(keys), _p(ids), batch, prev_n, post_n, capacity, _p(index_ring), _p(p),
+                                           _p(tree), _p(beta_state), float(beta_increment), _p(is_weights_out),
+                                           _p(min_p_out), _stream()), 'asac_window_gather_pad_w')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 65
+#define ASAC_ABI_VERSION 66
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -1028,6 +1028,21 @@ int asac_step_prologue_sample(float* target, const float* source, int64_t n_poly
                               int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
                               double* beta_state, double beta_increment, int32_t* leaf_out, float* p_out,
                               int64_t* ids_out, float* is_weights_out, float* min_p_out, void* stream);
+
+/* The pair for batches of 257 .. 1 024 rows on one GPU (hip_config['defer_is_weights']): the sampler's workgroups (256
+ * samples each) only leave their minima in min_p_out[2 ..] — no exchange between them, no weights, beta untouched —, and
+ * asac_window_gather_pad_w, the NEXT launch, forms the weights in one extra workgroup beside the gather's (minimum over the
+ * workgroups' minima, beta advanced first, f64 power: replay_buffer.py:352-354), min_p_out[0] = min p.  Same numbers as
+ * asac_step_prologue_sample followed by asac_window_gather_pad, bit for bit. */
+int asac_step_prologue_sample_partial(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
+                                      int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
+                                      float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets, int E_sample,
+                                      int E, const float* tree, int capacity, int batch, const int64_t* slot_ids,
+                                      int32_t* leaf_out, float* p_out, int64_t* ids_out, float* min_p_out, void* stream);
+int asac_window_gather_pad_w(const asac_gather_key_t* keys_host, int n_keys, const int64_t* ids, int batch, int prev_n,
+                             int post_n, int capacity, const int32_t* index_ring, const float* p, const float* tree,
+                             double* beta_state, double beta_increment, float* is_weights_out, float* min_p_out,
+                             void* stream);
 
 /* asac_step_prologue_sample and asac_window_gather_pad of the batch it draws (ids = ids_out, same batch / capacity) as
  * ONE launch: the gather's workgroups wait inside the launch until the sampler workgroups — first in the grid — have
