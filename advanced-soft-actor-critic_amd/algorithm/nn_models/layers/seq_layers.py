@@ -222,7 +222,9 @@ class _AttnMhFn(torch.autograd.Function):
     heads concatenated, mean-over-heads weights * keep, keep)"""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, heads):
+    def forward(ctx, q, k, v, mask, heads, row_zero=None):
+        """`row_zero` bool [B, Lq]: the caller's padded positions — the fourth result is then keep * ~row_zero, the one
+        factor the caller's output needs (else it is `keep` again)"""
         from asac_amd import native
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, Lq, E = q.shape
@@ -230,27 +232,30 @@ class _AttnMhFn(torch.autograd.Function):
         out = torch.empty(B, Lq, E, dtype=q.dtype, device=q.device)
         weights = torch.empty(B, Lq, Lk, dtype=q.dtype, device=q.device)
         keep = torch.empty(B, Lq, dtype=q.dtype, device=q.device)
+        keep_rows = torch.empty(B, Lq, dtype=q.dtype, device=q.device) if row_zero is not None else keep
         p_heads = torch.empty(B, heads, Lq, Lk, dtype=q.dtype, device=q.device) if any(ctx.needs_input_grad[:3]) else None
-        native.attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads)
+        native.attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads,
+                                    None if row_zero is None else row_zero.contiguous(),
+                                    keep_rows if row_zero is not None else None)
         if p_heads is not None:
             ctx.save_for_backward(q, k, v, p_heads, *([mask] if mask is not None else []))
         ctx.heads, ctx.has_mask = heads, mask is not None
-        ctx.mark_non_differentiable(keep)
+        ctx.mark_non_differentiable(keep, keep_rows)
         ctx.set_materialize_grads(False)
-        return out, weights, keep
+        return out, weights, keep, keep_rows
 
     @staticmethod
-    def backward(ctx, g_out, g_w, _g_keep):
+    def backward(ctx, g_out, g_w, _g_keep, _g_keep_rows=None):
         from asac_amd import native
         q, k, v, p_heads, *rest = ctx.saved_tensors
         if g_out is None and g_w is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if g_out is None:
             g_out = torch.zeros(q.shape, dtype=q.dtype, device=q.device)
         g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         native.attention_mh_backward(q, k, v, rest[0] if ctx.has_mask else None, ctx.heads, p_heads, g_out.contiguous(),
                                      None if g_w is None else g_w.contiguous(), g_q, g_k, g_v)
-        return g_q, g_k, g_v, None, None
+        return g_q, g_k, g_v, None, None, None
 
 
 class _AttnProjFn(torch.autograd.Function):
@@ -467,12 +472,18 @@ class MultiheadAttention(nn.Module):
                 if m is not None:
                     m = m.unsqueeze(0) if m.dim() == 2 else m
                     m = m if m.dtype in (torch.bool, torch.uint8) else m != 0
-                out, weights, keep = _AttnMhFn.apply(q, k, v, m, self.num_heads)
+                # the dead-row rule and the caller's padded rows as ONE factor formed by the launch itself (keep * ~row mask:
+                # a product with `keep`, a `bitwise_not`, a cast and a second product were four launches per block and pass)
+                rz = out_row_mask
+                if rz is not None:
+                    rz = rz.reshape(-1, rz.shape[-1])
+                    rz = rz if rz.dtype in (torch.bool, torch.uint8) else rz != 0
+                out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
                 out = self.out_proj(out)
-                if m is not None:
+                if rz is not None:
+                    out = out * keep_rows.unsqueeze(-1)
+                elif m is not None:
                     out = out * keep.unsqueeze(-1)
-                if out_row_mask is not None:
-                    out = out * (~out_row_mask.reshape(-1, out_row_mask.shape[-1])).to(out.dtype).unsqueeze(-1)
                 return out.reshape(*lead, *out.shape[1:]), weights.reshape(*lead, *weights.shape[1:])
         q, k, v = self._split_heads(q), self._split_heads(k), self._split_heads(v)
 

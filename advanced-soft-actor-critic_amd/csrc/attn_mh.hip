@@ -57,6 +57,8 @@ struct Args {
     float* out;            // [B][Lq][E]
     float* w_avg;          // [B][Lq][Lk]  mean over heads of softmax, * keep
     float* keep;           // [B][Lq]
+    const uint8_t* row_zero;   // [B][Lq] or NULL: the caller's padded positions (rows whose OUTPUT it zeroes)
+    float* keep_rows;      // [B][Lq] or NULL: keep * !row_zero — the one factor the caller multiplies the output with
     float* p_heads;        // [B][H][Lq][Lk] per-head softmax (saved for the backward) or NULL
     // backward
     const float* g_out;    // [B][Lq][E]
@@ -355,7 +357,11 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             const int qi = 16 * qn + x;
             if (qi >= Lq) continue;
             const float kp = dead[qn] ? 0.f : 1.f;
-            if (qq == 0) a.keep[(int64_t)b * Lq + qi] = kp;
+            if (qq == 0) {
+                a.keep[(int64_t)b * Lq + qi] = kp;
+                if (a.keep_rows)
+                    a.keep_rows[(int64_t)b * Lq + qi] = (a.row_zero && a.row_zero[(int64_t)b * Lq + qi]) ? 0.f : kp;
+            }
 #pragma unroll
             for (int km = 0; km < 2; ++km) {
                 f32x4 t = wsum[km][qn];
@@ -385,12 +391,14 @@ int asac_attention_mh_supported(int Lq, int Lk, int heads, int head_dim) {
 
 int asac_attention_mh_forward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
                               int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
-                              float* out, float* weights, float* keep, float* p_heads, void* stream) {
+                              float* out, float* weights, float* keep, float* p_heads, const uint8_t* row_zero,
+                              float* keep_rows, void* stream) {
     if (!q || !k || !v || !out || !weights || !keep || B <= 0 || !asac_attention_mh_supported(Lq, Lk, heads, head_dim))
         return bad_arg("asac_attention_mh_forward");
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = weights, a.keep = keep, a.p_heads = p_heads;
+    a.row_zero = row_zero, a.keep_rows = keep_rows;
     ASAC_LAUNCH(k_attn_mh<false>, dim3((unsigned)B), dim3(kThreads), 0, as_stream(stream), a);
     return finish_launch("asac_attention_mh_forward");
 }

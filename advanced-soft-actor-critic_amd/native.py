@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 66
+ABI_VERSION = 67
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -376,7 +376,7 @@ _SIGNATURES = {
     'asac_attention_mh_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'asac_attention_mh_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_attention_mh_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -1905,15 +1905,18 @@ def _mask3(mask, B):
 
 
 @_profiled
-def attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads):
+def attention_mh_forward(q, k, v, mask, heads, out, weights, keep, p_heads, row_zero=None, keep_rows=None):
     global _last_work
     B, Lq, E = q.shape
     Lk = k.shape[1]
     _last_work = 4.0 * B * Lq * Lk * E
     _dense_f32(q, k, v, out, weights, keep, p_heads)
     pm, sb, si, sj = _mask3(mask, B)
+    if row_zero is not None:
+        assert row_zero.shape == (B, Lq) and row_zero.is_contiguous() and row_zero.element_size() == 1 and keep_rows is not None
     _check(load().asac_attention_mh_forward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(out),
-                                            _p(weights), _p(keep), _p(p_heads), _stream()), 'asac_attention_mh_forward')
+                                            _p(weights), _p(keep), _p(p_heads), _p(row_zero), _p(keep_rows), _stream()),
+           'asac_attention_mh_forward')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 66
+#define ASAC_ABI_VERSION 67
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -899,14 +899,16 @@ int asac_obs_decoder_backward(const float* state, int64_t state_stride, int64_t 
  *   q [B][Lq][E], k / v [B][Lk][E], E = heads * head_dim, head h = channels [h * head_dim, (h + 1) * head_dim);
  *   mask as asac_attention_forward (shared by the heads).  out [B][Lq][E] (heads concatenated);  weights [B][Lq][Lk] = the
  *   mean over the heads of softmax(s) * keep;  keep [B][Lq] = 1 - dead;  p_heads [B][heads][Lq][Lk] (or NULL): every head's
- *   softmax, saved for the backward.
+ *   softmax, saved for the backward.  row_zero u8 [B][Lq] (or NULL) = the caller's padded positions and keep_rows [B][Lq]
+ *   (or NULL) <- keep * !row_zero: the ONE factor the caller multiplies the projected output with (`out * keep` and
+ *   `out * ~out_row_mask` of seq_layers.py:320-333 as one product).
  * Backward: grad_out [B][Lq][E], grad_weights [B][Lq][Lk] (w.r.t. the returned weights) or NULL -> grad_q / grad_k / grad_v.
  * One workgroup per batch entry, its heads dealt over four waves; sums in a fixed order: deterministic.
  * ------------------------------------------------------------------------------------------- */
 int asac_attention_mh_supported(int Lq, int Lk, int heads, int head_dim);
 int asac_attention_mh_forward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
                               int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
-                              float* out, float* weights, float* keep, float* p_heads, void* stream);
+                              float* out, float* weights, float* keep, float* p_heads, const uint8_t* row_zero, float* keep_rows, void* stream);
 int asac_attention_mh_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
                                int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
                                const float* p_heads, const float* grad_out, const float* grad_weights, float* grad_q,

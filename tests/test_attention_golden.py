@@ -18,7 +18,7 @@ CASES = {
     'abscat_cat': dict(embed_dim=4, num_layers=2, pe=POSITIONAL_ENCODING.ABSOLUTE_CAT, gate=GATE.CAT),
     'single': dict(embed_dim=8, num_layers=1, num_heads=2, pe=POSITIONAL_ENCODING.ROPE),
 }
-TOL = dict(rtol=1e-5, atol=1e-6)
+TOL = dict(rtol=1e-5, atol=5e-6)      # (host BLAS differs by a few 1e-6 between CPUs; SURVEY 8c: ATTN 2e-5)
 
 
 def _load(mod, g, prefix):
