@@ -132,6 +132,8 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_mlp_backward_policy_q': 'asac::k_mlp_bwd', 'asac_mlp_backward_policy_sample': 'asac::k_mlp_bwd',
               'asac_window_gather_pad': 'asac::k_window_gather_pad', 'asac_vtrace_return_min': 'asac::k_vtrace_return_min',
               'asac_sumtree_sample': 'asac::k_sumtree_sample', 'asac_step_prologue_sample': 'asac::k_prologue_sample',
+              'asac_step_prologue_sample_partial': 'asac::k_prologue_sample', 'asac_window_gather_pad_w': 'asac::k_window_gather_pad_w',
+              'asac_step_prologue_sample_gather': 'asac::k_prologue_sample_gather',
               'asac_sumtree_update': 'asac::k_sumtree_update', 'asac_squash_multi': 'asac::k_squash_multi',
               'asac_squash_sample_fwd': 'asac::k_squash_sample_fwd', 'asac_gru_forward': 'asac::k_gru_fwd',
               'asac_gru_backward': 'asac::k_gru_bwd', 'asac_scatter_rows_if_id_match': 'asac::k_scatter_write',
@@ -152,7 +154,8 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_gru_wide_forward': 'asac::gruw::k_gruw_fwd', 'asac_gru_wide_backward': 'asac::gruw::k_gruw_bwd',
               'asac_normal_nll_kl': 'asac::k_normal_nll_kl', 'asac_normal_nll_kl_logstd': 'asac::k_normal_nll_kl',
               'asac_masked_mse': 'asac::k_masked_mse'}
-SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_vtrace_return_min',
+SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_step_prologue_sample_partial', 'asac_step_prologue_sample_gather',
+                 'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_window_gather_pad_w', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
 ROUND = 'r05'
 _ROUNDS = ('r05', 'r04')      # newest committed summary wins; the source file is named in the line
@@ -586,6 +589,10 @@ def main():
         B = CFG['batch_size']
         # the fused first launch: sampler (K1 + K2) + Polyak (K5) + the step's draws
         alg['asac_step_prologue_sample'] = alg['asac_sumtree_sample'] + alg['asac_polyak'] + 8 * B + 4 * agent._eps_all.numel()
+        # batches of 257 .. 1 024: K2 (IS weights, 8 B bytes) is formed by an extra workgroup of the gather's launch
+        alg['asac_step_prologue_sample_partial'] = alg['asac_step_prologue_sample'] - 8 * B
+        alg['asac_window_gather_pad_w'] = alg['asac_window_gather_pad'] + 8 * B
+        alg['asac_step_prologue_sample_gather'] = alg['asac_step_prologue_sample'] + alg['asac_window_gather_pad']
         for name, st in sorted(summ.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['calls']):
             by = alg.get(name)
             calls_per_step = st['calls'] / args.profile_steps

@@ -55,3 +55,16 @@ def test_compact_line_without_optional_sections():
         full[k] = None
     d = json.loads(bench.compact_line(full))
     assert d['roofline'] is None and d['cpu_baseline'] is None and 'side_configs' not in d
+
+
+def test_every_sample_return_entry_point_has_its_kernel_and_bytes():
+    """a new entry point of the K1-K4 group that bench.py does not know silently drops out of `roofline_hbm` (round 5: the
+    gather launch with the IS weights was missing for one refresh, K1-K4 read 0.15 % instead of 33 %)"""
+    import bench
+    assert all(n in bench._KERNEL_OF for n in bench.SAMPLE_RETURN)
+    import re
+    from pathlib import Path
+    header = (Path(bench.__file__).parent / 'include' / 'asac_hip.h').read_text()
+    declared = set(re.findall(r'\bint (asac_(?:step_prologue_sample\w*|window_gather_pad\w*|sumtree_sample|vtrace_return_min|td_update))\(', header))
+    declared -= {'asac_vtrace_return_min_sc', 'asac_window_gather_plan'}       # (bound through their base names / not a launch)
+    assert declared <= set(bench.SAMPLE_RETURN), declared - set(bench.SAMPLE_RETURN)
