@@ -278,6 +278,22 @@ __device__ __forceinline__ f32x4 conv1_tile(const float* base, const int* ktq, c
     return acc0 + acc1;
 }
 
+// ... with the operand constants of ALL quads in registers (Q1C compile-time quads: 8 VGPRs each): per quad the LDS then
+// serves the four patch reads only — the two 16-byte table reads were two thirds of the layer's LDS bytes
+template <int Q1C>
+__device__ __forceinline__ f32x4 conv1_tile_reg(const float* base, const int4 (&ko)[Q1C], const float4 (&w)[Q1C]) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < Q1C; ++q) {
+        const float a0 = base[ko[q].x], a1v = base[ko[q].y], a2 = base[ko[q].z], a3 = base[ko[q].w];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, w[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, w[q].w, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
 // bias + GELU of one layer-1 element; keeps the activation in LDS (channel-major, what layer 2's patches index)
 // and, when training, the pre-activation in HBM (position-major: frame*M1 + pos == group row).  `abase` = the
 // row's a1 offset frame*O1*M1 + pos (negative beyond the group's positions), `z_rows` = rows backed by real frames
@@ -297,7 +313,7 @@ __device__ __forceinline__ void conv1_finish(const ConvArgs& a, int64_t g, int r
 
 // (TILED: a second instantiation — the whole-frame form keeps the code it had before the tiled mode existed: with the
 // block addressing compiled in, its launches were 0.5-2.8 us longer at cfg4's sizes)
-template <bool TILED>
+template <bool TILED, int Q1C = 0>
 __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvDims& d = a.d;
@@ -391,6 +407,17 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < S2H; ++s) settle(w2r[s]);
     settle(e_bias[0]); settle(e_bias[1]); settle(b1e); settle(b1s);
+    // (Q1C > 0: the full tiles' operand constants, read from the tables once)
+    constexpr int QR = Q1C > 0 ? Q1C : 1;
+    int4 ko_r[QR];
+    float4 w_r[QR];
+    if (Q1C > 0) {
+#pragma unroll
+        for (int q = 0; q < QR; ++q) {
+            ko_r[q] = (reinterpret_cast<const int4*>(ktq) + lk)[q * 4];
+            w_r[q] = (reinterpret_cast<const float4*>(w1q) + lane)[q * 64];
+        }
+    }
 
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
@@ -414,7 +441,8 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         for (int u = 0; u < 3; ++u)     // the last tiles: every wave takes a quarter of the reduction of each
             if (u < rem) tail[u] = conv1_tile(img + rowx[(full + u) * 16 + lr], ktq, w1q, qa, qb);
         for (int t = wave; t < full; t += 4) {
-            const f32x4 acc = conv1_tile(img + rowx[t * 16 + lr], ktq, w1q, 0, Q1);
+            const f32x4 acc = Q1C > 0 ? conv1_tile_reg<QR>(img + rowx[t * 16 + lr], ko_r, w_r)
+                                      : conv1_tile(img + rowx[t * 16 + lr], ktq, w1q, 0, Q1);
             f32x2_g ya, yb, unused;       // the fragment's four elements as two packed pairs
             gelu_parts2((f32x2_g){acc[0] + b1s, acc[1] + b1s}, ya, unused);
             gelu_parts2((f32x2_g){acc[2] + b1s, acc[3] + b1s}, yb, unused);
@@ -986,14 +1014,23 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, in
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int64_t cap = 256 * per_cu;
     const unsigned blocks = (unsigned)(a.n_groups < cap ? a.n_groups : cap);
-    static bool attr = false, attr_t = false;
-    if (a.d.tiles > 1) {
-        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_fwd<true>), attr_t, "asac_conv2_forward")) return rc;
-        ASAC_LAUNCH(k_conv2_fwd<true>, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
-    } else {
-        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_fwd<false>), attr, "asac_conv2_forward")) return rc;
-        ASAC_LAUNCH(k_conv2_fwd<false>, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
+    // the layer-1 operand constants of the full tiles in registers where the quad count is one of the usual ones (8 x 8
+    // filters over 1 / 3 / 4 input channels; cfg4 +0.9 %, cfg4_84 +2 % A/B); any other count: the LDS tables
+    static bool attr[2][4] = {};
+    auto launch = [&](auto kernel, bool& done) -> int {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(kernel), done, "asac_conv2_forward")) return rc;
+        ASAC_LAUNCH(kernel, dim3(blocks), dim3(kConvThreads), lds, as_stream(stream), a);
+        return 0;
+    };
+    const bool tiled = a.d.tiles > 1;
+    int rc = 0;
+    switch (a.d.K1 / 16) {
+    case 4: rc = tiled ? launch(k_conv2_fwd<true, 4>, attr[1][1]) : launch(k_conv2_fwd<false, 4>, attr[0][1]); break;
+    case 12: rc = tiled ? launch(k_conv2_fwd<true, 12>, attr[1][2]) : launch(k_conv2_fwd<false, 12>, attr[0][2]); break;
+    case 16: rc = tiled ? launch(k_conv2_fwd<true, 16>, attr[1][3]) : launch(k_conv2_fwd<false, 16>, attr[0][3]); break;
+    default: rc = tiled ? launch(k_conv2_fwd<true, 0>, attr[1][0]) : launch(k_conv2_fwd<false, 0>, attr[0][0]); break;
     }
+    if (rc) return rc;
     return finish_launch("asac_conv2_forward");
 }
 

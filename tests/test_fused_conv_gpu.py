@@ -31,6 +31,9 @@ def _stack(C, o1, k1, s1, o2, k2, s2, seed=0):
     (21, 1, 64, 64, 16, 8, 4, 32, 4, 2, -1),    # 15x15 -> 6x6: blocks that do not tile the map are moved inside, duplicates masked
     (18, 2, 52, 68, 8, 4, 4, 16, 4, 2, -1),     # 13x17 -> 5x7, non-square frame, fewer channels
     (10, 3, 48, 48, 16, 8, 4, 32, 4, 1, -1),    # 11x11 -> 8x8 with second stride 1 (s1 * s2 = 4)
+    (23, 4, 30, 30, 16, 8, 4, 32, 4, 2, 1),     # four input channels: K1 = 256, sixteen quads of operand constants in registers
+    (9, 4, 44, 44, 16, 8, 4, 32, 4, 2, 1),      # ... 10x10 -> 4x4 = 16 positions: one frame per group
+    (9, 4, 52, 52, 16, 8, 4, 32, 4, 2, -1),     # ... 12x12 -> 5x5: tiled
 ])
 def test_fused_conv_stack_matches_modules(N, C, H, W, o1, k1, s1, o2, k2, s2, tiles):
     import asac_amd  # noqa: F401
