@@ -574,6 +574,17 @@ def conv_cases():
             dict(seq_encoder=SEQ_ENCODER.ATTN, curiosity=CURIOSITY.FORWARD, **tiny), [40, 30, 50, 9], 2, **IMG_OBS)
 
 
+def conv84_case():
+    """The frame size of the reference's environments (`ConvLayers(84, 84, C, 'simple')`: every 84 x 84 plugin under
+    `envs/uav`, `envs/ugv`, `envs/roller`) in a recorded train step sequence: the reference's Conv2d stack against the
+    product's tiled convolution kernels.  The plugin is this repository's tests/plugins/nn_conv84_small.py (plugin API only,
+    so it loads under the reference; a small head keeps the fixture at a few MB — `envs/uav/uav_search/nn.py` itself records
+    10 MB of weights)."""
+    tiny = dict(batch_size=8, replay_config={'capacity': 128}, burn_in_step=2, n_step=3)
+    f6_step('conv84', str(HERE.parent / 'plugins' / 'nn_conv84_small.py'), tiny, [24, 20], 2,
+            obs_names=('vector', 'image'), obs_shapes=((10,), (3, 84, 84)), c_action_size=4)
+
+
 # ------------------------------------------------------------------------------------------------
 def f8_interop():
     """Files the reference writes (`<step>.pth`, `<step>-rb_tree.npy`, `<step>-rb_storage.npz`;
@@ -863,6 +874,7 @@ def main():
             [60, 45, 70], 3, d_action_sizes=(3, 2), c_action_size=2)
     aux_cases()
     conv_cases()
+    conv84_case()
     f8_interop()
     f9_acting()
     f10_agent()

@@ -90,6 +90,7 @@ def snapshot_tree(agent):
 # ------------------------------------------------------------------------------------------------
 VEC = dict(obs_names=['vector'], obs_shapes=[(6,)], c_action_size=2, batch_size=32, capacity=512)
 IMG = dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 30, 30)], c_action_size=4, batch_size=16, capacity=256)
+IMG84 = dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 84, 84)], c_action_size=4, batch_size=8, capacity=128)
 # case -> (plugin module name under tests.plugins, learner keywords, discrete action sizes, observation / size set)
 STEP_CASES = {
     'cfg1': ('nn_vec', dict(n_step=1, use_priority=False), (), VEC),
@@ -101,6 +102,8 @@ STEP_CASES = {
     # BASELINE configs[3] / configs[4] compositions (reference tests/nn_conv_vanilla.py, tests/nn_conv_attn.py)
     'conv': ('nn_conv', dict(n_step=3, burn_in_step=5, ensemble_q_num=4, ensemble_q_sample=2), (), IMG),
     'conv_attn_cur': ('nn_conv_attn', dict(n_step=3, burn_in_step=5, seq_encoder='ATTN', curiosity='FORWARD'), (), IMG),
+    # the frame size of the reference's environments (ConvLayers(84, 84, 3, 'simple')): the tiled convolution kernels
+    'conv84': ('nn_conv84_small', dict(n_step=3, burn_in_step=2), (), IMG84),
 }
 
 
