@@ -585,6 +585,19 @@ def conv84_case():
             obs_names=('vector', 'image'), obs_shapes=((10,), (3, 84, 84)), c_action_size=4)
 
 
+def wide_cases():
+    """The recurrent and attention widths of the reference's environments (`m.GRU(.., 64, 1)`:
+    envs/square/memory_corridor/nn.py:19; `EpisodeMultiheadAttention(64, 2 layers, 8 heads)`:
+    envs/gym/toy_queue/nn_attn.py:28-45) in recorded train steps: the product's wide-GRU and multi-head attention
+    kernels against the reference's own modules.  Plugins: this repository's tests/plugins/nn_rnn_h64.py /
+    nn_attn_h64.py (plugin API only: they load under the reference)."""
+    small = dict(batch_size=16, replay_config={'capacity': 256})
+    f6_step('rnn_h64', str(HERE.parent / 'plugins' / 'nn_rnn_h64.py'),
+            dict(n_step=3, burn_in_step=3, seq_encoder=SEQ_ENCODER.RNN, **small), [40, 30, 50, 12], 2)
+    f6_step('attn_h64', str(HERE.parent / 'plugins' / 'nn_attn_h64.py'),
+            dict(n_step=3, burn_in_step=4, seq_encoder=SEQ_ENCODER.ATTN, **small), [40, 30, 50, 12], 2)
+
+
 # ------------------------------------------------------------------------------------------------
 def f8_interop():
     """Files the reference writes (`<step>.pth`, `<step>-rb_tree.npy`, `<step>-rb_storage.npz`;
@@ -875,6 +888,7 @@ def main():
     aux_cases()
     conv_cases()
     conv84_case()
+    wide_cases()
     f8_interop()
     f9_acting()
     f10_agent()

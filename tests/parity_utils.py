@@ -90,6 +90,7 @@ def snapshot_tree(agent):
 # ------------------------------------------------------------------------------------------------
 VEC = dict(obs_names=['vector'], obs_shapes=[(6,)], c_action_size=2, batch_size=32, capacity=512)
 IMG = dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 30, 30)], c_action_size=4, batch_size=16, capacity=256)
+VEC16 = dict(obs_names=['vector'], obs_shapes=[(6,)], c_action_size=2, batch_size=16, capacity=256)
 IMG84 = dict(obs_names=['vector', 'image'], obs_shapes=[(10,), (3, 84, 84)], c_action_size=4, batch_size=8, capacity=128)
 # case -> (plugin module name under tests.plugins, learner keywords, discrete action sizes, observation / size set)
 STEP_CASES = {
@@ -104,6 +105,9 @@ STEP_CASES = {
     'conv_attn_cur': ('nn_conv_attn', dict(n_step=3, burn_in_step=5, seq_encoder='ATTN', curiosity='FORWARD'), (), IMG),
     # the frame size of the reference's environments (ConvLayers(84, 84, 3, 'simple')): the tiled convolution kernels
     'conv84': ('nn_conv84_small', dict(n_step=3, burn_in_step=2), (), IMG84),
+    # ... their recurrent width (GRU(64): the wide-GRU MFMA recurrence) and their attention core (64 channels, 8 heads, 2 layers)
+    'rnn_h64': ('nn_rnn_h64', dict(n_step=3, burn_in_step=3, seq_encoder='RNN'), (), VEC16),
+    'attn_h64': ('nn_attn_h64', dict(n_step=3, burn_in_step=4, seq_encoder='ATTN'), (), VEC16),
 }
 
 

@@ -92,7 +92,7 @@ def _load_weights(agent, g, prefix):
 
 # same eager ops on the same host give identical bits; these cases run other kernels for the same math: the GRU
 # un-packed (nn_models/layers/seq_layers.py), attention heads as batched GEMMs instead of chunk / cat
-INEXACT = ('cfg3', 'attn', 'attn_tanh', 'conv_attn_cur')
+INEXACT = ('cfg3', 'attn', 'attn_tanh', 'conv_attn_cur', 'rnn_h64', 'attn_h64')
 
 
 @pytest.mark.parametrize('case', list(pu.STEP_CASES))

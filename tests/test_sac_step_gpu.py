@@ -38,7 +38,7 @@ def make_agent(case, use_graph=False, hip=None):
 # right after the reference's own update) under the sign-aware bound of `parity_utils.assert_weights_close`, then
 # (2) aligns them with the reference's (`SAC_Base.after_rep_q_update`), so the rest of the step is compared from
 # identical weights at the same tolerances as every other case.
-TRAINED_REP = ('cfg3', 'attn', 'attn_tanh', 'conv', 'conv_attn_cur', 'conv84')
+TRAINED_REP = ('cfg3', 'attn', 'attn_tanh', 'conv', 'conv_attn_cur', 'conv84', 'rnn_h64', 'attn_h64')
 
 
 # `attn`: the attention output IS the state (no tanh head), |state| reaches 18, the stock policy saturates and its
