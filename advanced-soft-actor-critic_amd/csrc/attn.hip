@@ -268,6 +268,16 @@ __device__ __forceinline__ void project_t(const float* w, const float (&g)[EM], 
     }
 }
 
+// one element of W^T g at a time (the sixteen-channel backward: with all sixteen outputs of two such products unrolled the
+// compiler hoisted 2 x 256 weight reads — 256 VGPRs + 256 AGPRs + 228 bytes of scratch per lane)
+template <int EM>
+__device__ __forceinline__ float project_t_at(const float* w, const float (&g)[EM], int c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < EM; ++o) acc = fmaf(w[o * EM + c], g[o], acc);
+    return acc;
+}
+
 template <int EM>
 __device__ __forceinline__ void load_row(const float* src, int E, float (&x)[EM]) {
 #pragma unroll
@@ -426,6 +436,36 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         for (int c = 0; c < EM; ++c) y[c] = y[c] / rsd;
         put_row<EM>(qL + (bl * a.Lq + r) * EM, y);
         put_row<EM>(xqL + (bl * a.Lq + r) * EM, xq);
+        if constexpr (EM > 8) {
+            // (the same products and sums, one output at a time through the row's LDS stages: see project_t_at)
+            float* gor = goL + (bl * a.Lq + r) * EM;
+            if (a.wo) {
+                float* gzr = gzL + (bl * a.Lq + r) * EM;
+                const float* wo = wL + 3 * blk;
+#pragma unroll
+                for (int d = 0; d < EM; ++d) go[d] *= kp;
+                put_row<EM>(gor, go);
+                put_row<EM>(ovL + (bl * a.Lq + r) * EM, o);
+#pragma unroll 1
+                for (int d = 0; d < EM; ++d) {
+                    float z = wo[EM * EM + d];
+#pragma unroll
+                    for (int c = 0; c < EM; ++c) z = fmaf(wo[d * EM + c], o[c], z);
+                    gzr[d] = gor[d] * gelu_grad(z);
+                }
+#pragma unroll 1
+                for (int c = 0; c < EM; ++c) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int d = 0; d < EM; ++d) acc = fmaf(wo[d * EM + c], gzr[d], acc);
+                    gor[c] += acc;
+                }
+#pragma unroll
+                for (int d = 0; d < EM; ++d) go[d] = gor[d];
+            } else {
+                put_row<EM>(gor, go);
+            }
+        } else {
         if (a.wo) {                // back through y = (GELU(z) + o) * keep, z = Wo o + bo
             float z[EM], gz[EM], back[EM];
             project<EM>(wL + 3 * blk, o, z);
@@ -441,6 +481,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
             for (int d = 0; d < EM; ++d) go[d] += back[d];
         }
         put_row<EM>(goL + (bl * a.Lq + r) * EM, go);
+        }
     }
     __syncthreads();
     const float* kb = kL + bl * a.Lk * EM;
@@ -469,6 +510,14 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
 #pragma unroll
         for (int d = 0; d < EM; ++d) gq[d] = gq[d] / rsd;      // gradient of the unscaled projection output
         put_row<EM>(gqL + (bl * a.Lq + r) * EM, gq);
+        if constexpr (EM > 8) {                                   // (same sums, one output at a time: see project_t_at)
+#pragma unroll 1
+            for (int c = 0; c < EM; ++c) {
+                const float v = project_t_at<EM>(wL, gq, c);
+                if (tail) gxqL[(bl * a.Lq + r) * EM + c] = v;
+                else if (c < E) a.g_xq[row * E + c] = v;
+            }
+        } else {
         project_t<EM>(wL, gq, gx);                                // gradient of x_q: Wq^T g_q
         if (tail) {
             put_row<EM>(gxqL + (bl * a.Lq + r) * EM, gx);
@@ -476,6 +525,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
 #pragma unroll
             for (int c = 0; c < EM; ++c)
                 if (c < E) a.g_xq[row * E + c] = gx[c];
+        }
         }
     }
     __syncthreads();
@@ -495,10 +545,18 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         }
         put_row<EM>(gkL + (bl * a.Lk + r) * EM, gk);
         put_row<EM>(gvL + (bl * a.Lk + r) * EM, gv);
-        project_t<EM>(wL + blk, gk, gx);
-        project_t<EM>(wL + 2 * blk, gv, gx2);
         const int64_t kr = ((int64_t)b * a.Lk + r) * E;
         const int qi = r - (a.Lk - a.Lq);                         // tail form: this key row is query row qi
+        if constexpr (EM > 8) {
+#pragma unroll 1
+            for (int c = 0; c < E; ++c) {
+                float v = project_t_at<EM>(wL + blk, gk, c) + project_t_at<EM>(wL + 2 * blk, gv, c);
+                if (tail && qi >= 0) v += gxqL[(bl * a.Lq + qi) * EM + c];
+                a.g_xk[kr + c] = v;
+            }
+        } else {
+        project_t<EM>(wL + blk, gk, gx);
+        project_t<EM>(wL + 2 * blk, gv, gx2);
 #pragma unroll
         for (int c = 0; c < EM; ++c)
             if (c < E) {
@@ -506,6 +564,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
                 if (tail && qi >= 0) v += gxqL[(bl * a.Lq + qi) * EM + c];     // (as `g_xk[:, -Lq:] += g_xq`)
                 a.g_xk[kr + c] = v;
             }
+        }
     }
     __syncthreads();
     // phase 3: this workgroup's partial parameter gradients (fixed order over its rows), packed for width E
