@@ -121,15 +121,20 @@ class _GruWideFn(torch.autograd.Function):
             h_prev = torch.cat([h_first, h_raw[:, :-1]], dim=1).reshape(B * L, H)
             inp2 = inp.reshape(B * L, -1)
             if native.xty_supported(B * L, 3 * H, max(inp2.shape[1], H)):
-                # weight and bias gradients as products over the B * L rows, one MFMA launch each (`asac_xty`)
+                # weight and bias gradients as products over the B * L rows on MFMA, both in one launch pair (`asac_xty_multi`)
+                jobs = []
                 if ctx.needs_input_grad[5 + 4 * l]:
                     g_w[4 * l] = torch.empty(3 * H, inp2.shape[1], dtype=dt, device=dev)
                     g_w[4 * l + 2] = torch.empty(3 * H, dtype=dt, device=dev)
-                    native.xty(dgi2, inp2 if inp2.stride(1) == 1 else inp2.contiguous(), g_w[4 * l], g_w[4 * l + 2])
+                    jobs.append((dgi2, inp2 if inp2.stride(1) == 1 else inp2.contiguous(), g_w[4 * l], g_w[4 * l + 2]))
                 if ctx.needs_input_grad[5 + 4 * l + 1]:
                     g_w[4 * l + 1] = torch.empty(3 * H, H, dtype=dt, device=dev)
                     g_w[4 * l + 3] = torch.empty(3 * H, dtype=dt, device=dev)
-                    native.xty(dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3])
+                    jobs.append((dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3]))
+                if len(jobs) == 2:
+                    native.xty_multi(jobs)
+                elif jobs:
+                    native.xty(*jobs[0])
             else:
                 ones = torch.ones(1, B * L, dtype=dt, device=dev)      # column sums as library products (fixed order)
                 if ctx.needs_input_grad[5 + 4 * l]:

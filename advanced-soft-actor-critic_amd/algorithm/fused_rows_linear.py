@@ -14,6 +14,48 @@ import torch
 
 ENABLED = os.environ.get('ASAC_ROWS_LINEAR', '1') != '0'      # (0: plain nn.Linear — A/B runs)
 MIN_ROWS = 2048
+QUEUE = os.environ.get('ASAC_XTY_QUEUE', '1') != '0'      # (0: one launch pair per product — A/B runs)
+
+
+# Direct mode (the learner's `loss.backward()`: gradients are ADDED into the `.grad` views of the flat buffer, nobody reads them
+# before the optimizer): the products are not launched one by one but queued and issued four at a time as one launch pair
+# (`asac_xty_multi` — the four Linears of an attention block make exactly one), the rest when the backward pass ends.
+_pending = []
+_armed = False
+
+
+def flush_param_grads():
+    from asac_amd import native
+    jobs = list(_pending)
+    del _pending[:]
+    if len(jobs) == 1:
+        native.xty(*jobs[0], accumulate=True)
+    elif jobs:
+        native.xty_multi(jobs, accumulate=True)
+
+
+def _end_of_backward():
+    global _armed
+    _armed = False
+    flush_param_grads()
+
+
+def queue_param_grads(g2, x2, w_grad, b_grad):
+    """w_grad += g2^T x2, b_grad += column sums of g2 — some time before this backward pass returns"""
+    global _armed
+    if not QUEUE:
+        from asac_amd import native
+        native.xty(g2, x2, w_grad, b_grad, accumulate=True)
+        return
+    if any(j[2].data_ptr() == w_grad.data_ptr() or (b_grad is not None and j[3] is not None and j[3].data_ptr() == b_grad.data_ptr())
+           for j in _pending):
+        flush_param_grads()      # (a layer applied twice: its two products add to one gradient, one after the other)
+    _pending.append((g2, x2, w_grad, b_grad))
+    if len(_pending) == 4:
+        flush_param_grads()
+    elif not _armed:
+        _armed = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
 
 
 class _RowsLinearFn(torch.autograd.Function):
@@ -41,7 +83,7 @@ class _RowsLinearFn(torch.autograd.Function):
                     and b_grad.is_contiguous()):
                 # `loss.backward()` of the learner's step: added straight into the `.grad` views of the flat buffer (no
                 # gradient tensors handed to autograd, no accumulation launches)
-                native.xty(g2, x2, w_grad, b_grad, accumulate=True)
+                queue_param_grads(g2, x2, w_grad, b_grad)
             else:
                 gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
                 native.xty(g2, x2, gw, gb)

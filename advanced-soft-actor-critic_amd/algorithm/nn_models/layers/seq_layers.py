@@ -182,6 +182,8 @@ class RotaryPositionalEncoding2(nn.Module):
 FUSED_PROJECTIONS = True      # q / k / v Linear projections inside the attention launch when they are plain Linears
 # several heads: the core of all heads as one MFMA launch (csrc/attn_mh.hip); ASAC_ATTN_MH=0 keeps the module path (A/B runs)
 FUSED_MULTIHEAD = os.environ.get('ASAC_ATTN_MH', '1') != '0'
+# the Linear layers around the multi-head core as one launch each (csrc/rows_proj.hip)   (0: library GEMMs — A/B runs)
+FUSED_ROWS_PROJ = os.environ.get('ASAC_ROWS_PROJ', '1') != '0'
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -327,6 +329,111 @@ class _AttnProjFn(torch.autograd.Function):
         return (g_xq, g_xk, None, None, *grads)
 
 
+def _rows_param_grads(ctx_needs, params, g2, x2):
+    """weight / bias gradient of one Linear from its output gradient rows g2 and input rows x2 (`asac_xty`): added straight
+    into the `.grad` views under the learner's direct mode, else returned"""
+    from asac_amd import native
+    from algorithm.fused_mlp import direct_enabled, direct_skips
+    weight, bias = params
+    if not any(ctx_needs) or direct_skips(weight, bias):
+        return None, None
+    w_grad, b_grad = weight.grad, bias.grad
+    if direct_enabled() and w_grad is not None and b_grad is not None and w_grad.is_contiguous() and b_grad.is_contiguous():
+        from algorithm.fused_rows_linear import queue_param_grads
+        queue_param_grads(g2, x2, w_grad, b_grad)
+        return None, None
+    gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+    native.xty(g2, x2, gw, gb)
+    return gw, gb
+
+
+class _QkvRowsFn(torch.autograd.Function):
+    """`q_proj(x[:, -tail:]), k_proj(x), v_proj(x)` — three nn.Linear(E, E) over the rows of a window batch — as ONE MFMA
+    launch; backward: the input gradient of the three as one launch, the parameter gradients as products over the rows
+    (`asac_rows_proj_*`, csrc/rows_proj.hip; `asac_xty`)"""
+
+    @staticmethod
+    def forward(ctx, x, tail, wq, bq, wk, bk, wv, bv):
+        from asac_amd import native
+        if x.stride(2) != 1 or (x.stride(0) | x.stride(1) | (x.data_ptr() >> 2)) & 3:
+            x = x.contiguous()
+        B, L, E = x.shape
+        q = torch.empty(B, tail, E, dtype=x.dtype, device=x.device)
+        k, v = torch.empty(B, L, E, dtype=x.dtype, device=x.device), torch.empty(B, L, E, dtype=x.dtype, device=x.device)
+        native.rows_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
+                                 [tail, L, L], [q, k, v])
+        ctx.save_for_backward(x)
+        ctx.tail, ctx.params = tail, (wq, bq, wk, bk, wv, bv)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        from asac_amd import native
+        x, = ctx.saved_tensors
+        B, L, E = x.shape
+        wq, bq, wk, bk, wv, bv = ctx.params
+        grads = [g.contiguous() for g in (gq, gk, gv)]
+        tails = [ctx.tail, L, L]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, L, E, dtype=x.dtype, device=x.device)
+            native.rows_proj_backward(grads, tails, [wq.detach(), wk.detach(), wv.detach()], gx)
+        x2 = x.reshape(-1, E)
+        xq2 = x2 if ctx.tail == L else x[:, -ctx.tail:].reshape(-1, E)
+        out = [gx, None]
+        for j, (g, xin) in enumerate(zip(grads, (xq2, x2, x2))):
+            out.extend(_rows_param_grads(ctx.needs_input_grad[2 + 2 * j:4 + 2 * j], ctx.params[2 * j:2 * j + 2],
+                                         g.view(-1, E), xin))
+        return tuple(out)
+
+
+class _OutResRowsFn(torch.autograd.Function):
+    """`(x + gelu(linear(x))) * row_scale[..., None]` — the output ResBlock of an attention layer and its dead-row / padded-row
+    factor — as one MFMA launch per pass (`asac_rows_resblock_*`, csrc/rows_proj.hip); the parameter gradients from `asac_xty`"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, row_scale):
+        from asac_amd import native
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1 or (x2.stride(0) | (x2.data_ptr() >> 2)) & 3:
+            x2 = x2.contiguous()
+        y, pre = torch.empty(x2.shape, dtype=x.dtype, device=x.device), torch.empty(x2.shape, dtype=x.dtype, device=x.device)
+        sc = None if row_scale is None else row_scale.reshape(-1).contiguous()
+        native.rows_resblock_forward(x2, weight.detach(), bias.detach(), sc, y, pre)
+        ctx.save_for_backward(x2, pre, *([sc] if sc is not None else []))
+        ctx.params, ctx.lead = (weight, bias), x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from asac_amd import native
+        x2, pre, *rest = ctx.saved_tensors
+        weight, bias = ctx.params
+        gy2 = gy.reshape(x2.shape).contiguous()
+        gx, gpre = torch.empty_like(pre), torch.empty_like(pre)
+        native.rows_resblock_backward(gy2, pre, weight.detach(), rest[0] if rest else None, gx, gpre)
+        gw, gb = _rows_param_grads(ctx.needs_input_grad[1:3], ctx.params, gpre, x2)
+        return gx.view(ctx.lead), gw, gb, None
+
+
+def _rows_proj_ok(module, query, key) -> bool:
+    """the q / k / v projections of `module` as one `_QkvRowsFn` launch: plain Linears E -> E over a device window batch whose
+    query is the key tensor or its newest positions"""
+    if not (FUSED_ROWS_PROJ and key.is_cuda and key.dtype == torch.float32 and key.dim() == 3 and key.stride(2) == 1):
+        return False
+    if not (query is key or _is_tail_view(query, key)):
+        return False
+    E = module.embed_dim
+    from asac_amd import native
+    if not native.rows_proj_supported(E):
+        return False
+    for ll in (module.q_proj, module.k_proj, module.v_proj):
+        lin = _plain_linear(ll)
+        if lin is None or lin.in_features != E or lin.out_features != E:
+            return False
+    return True
+
+
 def _is_tail_view(query, key):
     """query is `key[:, -q:]` (the episode blocks' cut query): same memory, so one gradient serves both"""
     q = query.shape[1]
@@ -457,7 +564,11 @@ class MultiheadAttention(nn.Module):
                         out = out * (~rz).to(out.dtype).unsqueeze(-1)
                 return out.reshape(*lead, *out.shape[1:]), weights.reshape(*lead, *weights.shape[1:])
 
-        q, k, v = self.q_proj(query), self.k_proj(key), self.v_proj(value)
+        if (self.pe is None or self.pe is False) and same_kv and _rows_proj_ok(self, query, key):
+            q, k, v = _QkvRowsFn.apply(key, q_len, *(t for ll in (self.q_proj, self.k_proj, self.v_proj)
+                                                     for t in (_plain_linear(ll).weight, _plain_linear(ll).bias)))
+        else:
+            q, k, v = self.q_proj(query), self.k_proj(key), self.v_proj(value)
         if self.pe in (POSITIONAL_ENCODING.ROPE, POSITIONAL_ENCODING.ROPE2):
             q, k = self.rope(query_index, key_index, q, k)
         if (FUSED_MULTIHEAD and (self.num_heads > 1 or self.head_dim > 16) and q.is_cuda and q.dtype == torch.float32
@@ -479,11 +590,15 @@ class MultiheadAttention(nn.Module):
                     rz = rz.reshape(-1, rz.shape[-1])
                     rz = rz if rz.dtype in (torch.bool, torch.uint8) else rz != 0
                 out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
-                out = self.out_proj(out)
-                if rz is not None:
-                    out = out * keep_rows.unsqueeze(-1)
-                elif m is not None:
-                    out = out * keep.unsqueeze(-1)
+                scale = keep_rows if rz is not None else (keep if m is not None else None)
+                lo = _plain_resblock(self.out_proj, self.embed_dim) if FUSED_ROWS_PROJ else None
+                if lo is not None and native.rows_proj_supported(self.embed_dim):
+                    # the output ResBlock and the dead-row / padded-row factor: one launch
+                    out = _OutResRowsFn.apply(out, lo.weight, lo.bias, scale)
+                else:
+                    out = self.out_proj(out)
+                    if scale is not None:
+                        out = out * scale.unsqueeze(-1)
                 return out.reshape(*lead, *out.shape[1:]), weights.reshape(*lead, *weights.shape[1:])
         q, k, v = self._split_heads(q), self._split_heads(k), self._split_heads(v)
 

@@ -21,7 +21,7 @@ namespace asac {
 namespace amh {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int kThreads = 256;      // 4 waves = the heads of one batch entry, dealt round robin
+constexpr int kWaves = 4, kThreads = 64 * kWaves;      // the waves of a workgroup = the heads of one batch entry, dealt round robin
 constexpr int kMaxL = 32;
 constexpr int kTP = 20;             // LDS pitch of a turned tile's rows
 
@@ -76,11 +76,11 @@ __device__ __forceinline__ f32x4 row4(const float* base, bool live, int c0, int 
     return v;
 }
 
-template <bool BWD>
+template <bool BWD, int NT>
 __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     // per wave: P and dS tiles turned for the products over the queries; rows of 16 at a pitch of kTP = 20 floats: the four
     // lane quarters of a store then fall into four different 16-bank groups, rows stay 16-byte aligned for the b128 reads
-    __shared__ float s_t[4][8][16 * kTP];
+    __shared__ float s_t[kWaves][2 * NT * NT][16 * kTP];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, qq = l >> 4, x = l & 15;
     const int b = blockIdx.x;
     const int Lq = a.Lq, Lk = a.Lk, H = a.H, d = a.d, E = H * d;
@@ -90,14 +90,14 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     const float* kb = a.k + (int64_t)b * Lk * E;
     const float* vb = a.v + (int64_t)b * Lk * E;
     // mask of this entry: lane (qq, x) of tile (km, qn) holds keys 16 km + 4 qq + r of query 16 qn + x
-    bool blocked[2][2][4];
-    bool dead[2];
+    bool blocked[NT][NT][4];
+    bool dead[NT];
 #pragma unroll
-    for (int qn = 0; qn < 2; ++qn) {
+    for (int qn = 0; qn < NT; ++qn) {
         const int qi = 16 * qn + x;
         bool all_blocked = true;
 #pragma unroll
-        for (int km = 0; km < 2; ++km)
+        for (int km = 0; km < NT; ++km)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kj = 16 * km + 4 * qq + r;
@@ -110,43 +110,43 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         const int votes = (int)sum_over_q(all_blocked ? 1.f : 0.f);
         dead[qn] = a.mask != nullptr && votes == 4;
     }
-    f32x4 wsum[2][2];
+    f32x4 wsum[NT][NT];
 #pragma unroll
-    for (int km = 0; km < 2; ++km)
+    for (int km = 0; km < NT; ++km)
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn) wsum[km][qn] = zero4();
+        for (int qn = 0; qn < NT; ++qn) wsum[km][qn] = zero4();
     float* tbuf = &s_t[wv][0][0];
 
-    for (int h = wv; h < H; h += 4) {
+    for (int h = wv; h < H; h += kWaves) {
         const int hc = h * d;
-        f32x4 P[2][2];
+        f32x4 P[NT][NT];
         if (!BWD) {
             // ---- scores ---------------------------------------------------------------------------------------------
-            f32x4 S[2][2];
+            f32x4 S[NT][NT];
 #pragma unroll
-            for (int km = 0; km < 2; ++km)
+            for (int km = 0; km < NT; ++km)
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn) S[km][qn] = zero4();
+                for (int qn = 0; qn < NT; ++qn) S[km][qn] = zero4();
             for (int ct = 0; ct < CT; ++ct) {
-                f32x4 ka[2], qv[2];
+                f32x4 ka[NT], qv[NT];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     const int kj = 16 * t + x, qi = 16 * t + x;
                     ka[t] = row4(kb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
                     qv[t] = row4(qb + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d) * scale;
                 }
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
-                    for (int qn = 0; qn < 2; ++qn)
+                    for (int qn = 0; qn < NT; ++qn)
                         if (km < KT && qn < QT) S[km][qn] = mfma4(ka[km], qv[qn], S[km][qn]);
             }
             // ---- mask + softmax over the keys of each query ---------------------------------------------------------
 #pragma unroll
-            for (int qn = 0; qn < 2; ++qn) {
+            for (int qn = 0; qn < NT; ++qn) {
                 float mx = -INFINITY;
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                 mx = max_over_q(mx);
                 float sum = 0.f;
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float e = S[km][qn][r] == -INFINITY ? 0.f : expf(S[km][qn][r] - mx);
@@ -167,14 +167,14 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                 sum = sum_over_q(sum);
                 const float inv = 1.f / sum;
 #pragma unroll
-                for (int km = 0; km < 2; ++km) {
+                for (int km = 0; km < NT; ++km) {
                     P[km][qn] *= inv;
                     wsum[km][qn] += P[km][qn];
                 }
                 if (a.p_heads) {
                     const int qi = 16 * qn + x;
 #pragma unroll
-                    for (int km = 0; km < 2; ++km)
+                    for (int km = 0; km < NT; ++km)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int kj = 16 * km + 4 * qq + r;
@@ -185,20 +185,20 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             // ---- weighted sum of the values: O[c][query] = sum_keys V[key][c] P[key][query] ----------------------------
             for (int ct = 0; ct < CT; ++ct) {
                 const int c = 16 * ct + x;
-                f32x4 va[2];
+                f32x4 va[NT];
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
                         va[km][r] = (c < d && kj < Lk) ? vb[(int64_t)kj * E + hc + c] : 0.f;
                     }
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn) {
+                for (int qn = 0; qn < NT; ++qn) {
                     if (qn >= QT) continue;
                     f32x4 o = zero4();
 #pragma unroll
-                    for (int km = 0; km < 2; ++km)
+                    for (int km = 0; km < NT; ++km)
                         if (km < KT) o = mfma4(va[km], P[km][qn], o);
                     const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
                     if (qi < Lq) {
@@ -214,10 +214,10 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         } else {
             // ---- backward of head h ---------------------------------------------------------------------------------
 #pragma unroll
-            for (int qn = 0; qn < 2; ++qn) {
+            for (int qn = 0; qn < NT; ++qn) {
                 const int qi = 16 * qn + x;
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
@@ -226,33 +226,33 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             }
             const float* gob = a.g_out + (int64_t)b * Lq * E;
             // dP[key][query] = sum_c V[key][c] dO[query][c]  (+ the head's share of the averaged weights' gradient)
-            f32x4 dP[2][2];
+            f32x4 dP[NT][NT];
 #pragma unroll
-            for (int km = 0; km < 2; ++km)
+            for (int km = 0; km < NT; ++km)
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn) dP[km][qn] = zero4();
+                for (int qn = 0; qn < NT; ++qn) dP[km][qn] = zero4();
             for (int ct = 0; ct < CT; ++ct) {
-                f32x4 va[2], go[2];
+                f32x4 va[NT], go[NT];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     const int kj = 16 * t + x, qi = 16 * t + x;
                     va[t] = row4(vb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
                     go[t] = row4(gob + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d);
                 }
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
-                    for (int qn = 0; qn < 2; ++qn)
+                    for (int qn = 0; qn < NT; ++qn)
                         if (km < KT && qn < QT) dP[km][qn] = mfma4(va[km], go[qn], dP[km][qn]);
             }
-            f32x4 dS[2][2];
+            f32x4 dS[NT][NT];
 #pragma unroll
-            for (int qn = 0; qn < 2; ++qn) {
+            for (int qn = 0; qn < NT; ++qn) {
                 const int qi = 16 * qn + x;
                 const float kp = dead[qn] ? 0.f : 1.f / (float)H;       // weights returned = mean_h(P) * keep
                 float dot = 0.f;
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
@@ -261,27 +261,27 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                     }
                 dot = sum_over_q(dot);
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dS[km][qn][r] = P[km][qn][r] * (dP[km][qn][r] - dot);
             }
             // dQ[query][c] = scale * sum_keys K[key][c] dS[key][query]
             for (int ct = 0; ct < CT; ++ct) {
                 const int c = 16 * ct + x;
-                f32x4 ka[2];
+                f32x4 ka[NT];
 #pragma unroll
-                for (int km = 0; km < 2; ++km)
+                for (int km = 0; km < NT; ++km)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
                         ka[km][r] = (c < d && kj < Lk) ? kb[(int64_t)kj * E + hc + c] : 0.f;
                     }
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn) {
+                for (int qn = 0; qn < NT; ++qn) {
                     if (qn >= QT) continue;
                     f32x4 o = zero4();
 #pragma unroll
-                    for (int km = 0; km < 2; ++km)
+                    for (int km = 0; km < NT; ++km)
                         if (km < KT) o = mfma4(ka[km], dS[km][qn], o);
                     const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
                     if (qi < Lq) {
@@ -295,21 +295,21 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             // the products over the QUERIES: P and dS tiles turned (lane (qq, x = key) then holds queries 4 s + qq)
             wave_sync();
 #pragma unroll
-            for (int km = 0; km < 2; ++km)
+            for (int km = 0; km < NT; ++km)
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn)
+                for (int qn = 0; qn < NT; ++qn)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        tbuf[((km * 2 + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = P[km][qn][r];
-                        tbuf[((4 + km * 2 + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = dS[km][qn][r];
+                        tbuf[((km * NT + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = P[km][qn][r];
+                        tbuf[((NT * NT + km * NT + qn) * 16 * kTP) + (4 * qq + r) * kTP + tpos(x)] = dS[km][qn][r];
                     }
             wave_sync();
             // dV[key][c] = sum_queries P[key][query] dO[query][c];  dK[key][c] = scale * sum_queries dS[key][query] Q[query][c]
             for (int ct = 0; ct < CT; ++ct) {
                 const int c = 16 * ct + x;
-                f32x4 ga[2], qa[2];       // A[i = c][k-slot (qq, s) <-> query 16 qn + 4 s + qq]
+                f32x4 ga[NT], qa[NT];       // A[i = c][k-slot (qq, s) <-> query 16 qn + 4 s + qq]
 #pragma unroll
-                for (int qn = 0; qn < 2; ++qn)
+                for (int qn = 0; qn < NT; ++qn)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int qi = 16 * qn + 4 * s + qq;
@@ -318,14 +318,14 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                         qa[qn][s] = ok ? qb[(int64_t)qi * E + hc + c] : 0.f;
                     }
 #pragma unroll
-                for (int km = 0; km < 2; ++km) {
+                for (int km = 0; km < NT; ++km) {
                     if (km >= KT) continue;
                     f32x4 dv = zero4(), dk = zero4();
 #pragma unroll
-                    for (int qn = 0; qn < 2; ++qn) {
+                    for (int qn = 0; qn < NT; ++qn) {
                         if (qn >= QT) continue;
-                        const f32x4 pt = *reinterpret_cast<const f32x4*>(tbuf + (km * 2 + qn) * 16 * kTP + x * kTP + 4 * qq);
-                        const f32x4 st = *reinterpret_cast<const f32x4*>(tbuf + (4 + km * 2 + qn) * 16 * kTP + x * kTP + 4 * qq);
+                        const f32x4 pt = *reinterpret_cast<const f32x4*>(tbuf + (km * NT + qn) * 16 * kTP + x * kTP + 4 * qq);
+                        const f32x4 st = *reinterpret_cast<const f32x4*>(tbuf + (NT * NT + km * NT + qn) * 16 * kTP + x * kTP + 4 * qq);
                         dv = mfma4(ga[qn], pt, dv);
                         dk = mfma4(qa[qn], st, dk);
                     }
@@ -346,14 +346,14 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         // the waves' sums over their heads, added in wave order by wave 0 (s_t is free in the forward)
         f32x4* ws = reinterpret_cast<f32x4*>(&s_t[0][0][0]);
 #pragma unroll
-        for (int km = 0; km < 2; ++km)
+        for (int km = 0; km < NT; ++km)
 #pragma unroll
-            for (int qn = 0; qn < 2; ++qn) ws[(wv * 4 + km * 2 + qn) * 64 + l] = wsum[km][qn];
+            for (int qn = 0; qn < NT; ++qn) ws[(wv * NT * NT + km * NT + qn) * 64 + l] = wsum[km][qn];
         __syncthreads();
         if (wv != 0) return;
         const float invH = 1.f / (float)H;
 #pragma unroll
-        for (int qn = 0; qn < 2; ++qn) {
+        for (int qn = 0; qn < NT; ++qn) {
             const int qi = 16 * qn + x;
             if (qi >= Lq) continue;
             const float kp = dead[qn] ? 0.f : 1.f;
@@ -363,10 +363,10 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                     a.keep_rows[(int64_t)b * Lq + qi] = (a.row_zero && a.row_zero[(int64_t)b * Lq + qi]) ? 0.f : kp;
             }
 #pragma unroll
-            for (int km = 0; km < 2; ++km) {
+            for (int km = 0; km < NT; ++km) {
                 f32x4 t = wsum[km][qn];
 #pragma unroll
-                for (int w2 = 1; w2 < 4; ++w2) t += ws[(w2 * 4 + km * 2 + qn) * 64 + l];
+                for (int w2 = 1; w2 < kWaves; ++w2) t += ws[(w2 * NT * NT + km * NT + qn) * 64 + l];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kj = 16 * km + 4 * qq + r;
@@ -382,6 +382,15 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 
 using namespace asac;
 using namespace asac::amh;
+
+// windows of <= 16 positions are one tile a side: a quarter of the tile registers and of the LDS of the 2 x 2 form, so every
+// entry of a batch of 1024 is resident at once (56 / 92 VGPRs against 121 / 164; 9.8 / 14.0 us against 20 / 27 at window 9)
+template <bool BWD>
+static void launch(const Args& a, hipStream_t stream) {
+    const dim3 grid((unsigned)a.B);
+    if (a.Lq <= 16 && a.Lk <= 16) ASAC_LAUNCH((k_attn_mh<BWD, 1>), grid, dim3(kThreads), 0, stream, a);
+    else ASAC_LAUNCH((k_attn_mh<BWD, 2>), grid, dim3(kThreads), 0, stream, a);
+}
 
 extern "C" {
 
@@ -399,7 +408,7 @@ int asac_attention_mh_forward(const float* q, const float* k, const float* v, co
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = weights, a.keep = keep, a.p_heads = p_heads;
     a.row_zero = row_zero, a.keep_rows = keep_rows;
-    ASAC_LAUNCH(k_attn_mh<false>, dim3((unsigned)B), dim3(kThreads), 0, as_stream(stream), a);
+    launch<false>(a, as_stream(stream));
     return finish_launch("asac_attention_mh_forward");
 }
 
@@ -414,7 +423,7 @@ int asac_attention_mh_backward(const float* q, const float* k, const float* v, c
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim;
     a.p_heads = const_cast<float*>(p_heads), a.g_out = grad_out, a.g_w = grad_weights, a.g_q = grad_q, a.g_k = grad_k, a.g_v = grad_v;
-    ASAC_LAUNCH(k_attn_mh<true>, dim3((unsigned)B), dim3(kThreads), 0, as_stream(stream), a);
+    launch<true>(a, as_stream(stream));
     return finish_launch("asac_attention_mh_backward");
 }
 

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 67
+ABI_VERSION = 68
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -307,6 +307,9 @@ _SIGNATURES = {
     'asac_xty_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     'asac_xty': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                            C.c_int, C.c_void_p, C.c_void_p]),
+    'asac_xty_multi_workspace': (C.c_int64, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_xty_multi': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_conv2_tiles': (C.c_int, [C.POINTER(Conv2Desc)]),
     'asac_conv2_z1_floats': (C.c_int64, [C.POINTER(Conv2Desc), C.c_int64]),
     'asac_conv2_supported': (C.c_int, [C.POINTER(Conv2Desc)]),
@@ -380,6 +383,15 @@ _SIGNATURES = {
     'asac_attention_mh_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_rows_proj_supported': (C.c_int, [C.c_int]),
+    'asac_rows_proj_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_rows_proj_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
+    'asac_rows_resblock_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_rows_resblock_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     'asac_gru_wide_supported': (C.c_int, [C.c_int]),
     'asac_gru_wide_forward_twin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -1933,6 +1945,68 @@ def attention_mh_backward(q, k, v, mask, heads, p_heads, grad_out, grad_weights,
 
 
 # ------------------------------------------------------------------------------------------------
+# the Linear layers around the multi-head attention core (csrc/rows_proj.hip)
+# ------------------------------------------------------------------------------------------------
+def rows_proj_supported(width) -> bool:
+    return bool(load().asac_rows_proj_supported(int(width)))
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+@_profiled
+def rows_proj_forward(x, weights, biases, tails, outs):
+    """outs[j] [B][tails[j]][E] = x[:, L - tails[j]:] weights[j]^T + biases[j] for the <= 3 jobs, one launch; x [B][L][E] with
+    feature stride 1"""
+    global _last_work
+    B, L, E = x.shape
+    assert x.stride(2) == 1 and len(weights) == len(biases) == len(tails) == len(outs) <= 3
+    _dense_f32(*weights, *biases, *outs)
+    for o, n in zip(outs, tails):
+        assert o.shape == (B, n, E)
+    _last_work = 2.0 * B * sum(tails) * E * E
+    _check(load().asac_rows_proj_forward(_p(x), x.stride(0), x.stride(1), B, L, E, len(outs), _ptr_array(weights),
+                                         _ptr_array(biases), (C.c_int * len(tails))(*tails), _ptr_array(outs), _stream()),
+           'asac_rows_proj_forward')
+
+
+@_profiled
+def rows_proj_backward(grads, tails, weights, grad_x):
+    """grad_x [B][L][E] = sum_j grads[j] weights[j] (job j reaching the newest tails[j] positions), one launch"""
+    global _last_work
+    B, L, E = grad_x.shape
+    _dense_f32(*grads, *weights, grad_x)
+    for g, n in zip(grads, tails):
+        assert g.shape == (B, n, E)
+    _last_work = 2.0 * B * sum(tails) * E * E
+    _check(load().asac_rows_proj_backward(_ptr_array(grads), (C.c_int * len(tails))(*tails), len(grads), _ptr_array(weights), B,
+                                          L, E, _p(grad_x), _stream()), 'asac_rows_proj_backward')
+
+
+@_profiled
+def rows_resblock_forward(x, weight, bias, row_scale, y, pre):
+    """y = (x + gelu(x W^T + b)) * row_scale[:, None], pre = x W^T + b; x [rows][E] with feature stride 1"""
+    global _last_work
+    rows, E = x.shape
+    assert x.stride(1) == 1
+    _dense_f32(weight, bias, y, pre, *([] if row_scale is None else [row_scale]))
+    _last_work = 2.0 * rows * E * E
+    _check(load().asac_rows_resblock_forward(_p(x), x.stride(0), _p(weight), _p(bias), _p(row_scale), rows, E, _p(y), _p(pre),
+                                             _stream()), 'asac_rows_resblock_forward')
+
+
+@_profiled
+def rows_resblock_backward(grad_y, pre, weight, row_scale, grad_x, grad_pre):
+    global _last_work
+    rows, E = grad_y.shape
+    _dense_f32(grad_y, pre, weight, grad_x, grad_pre, *([] if row_scale is None else [row_scale]))
+    _last_work = 2.0 * rows * E * E
+    _check(load().asac_rows_resblock_backward(_p(grad_y), _p(pre), _p(weight), _p(row_scale), rows, E, _p(grad_x), _p(grad_pre),
+                                              _stream()), 'asac_rows_resblock_backward')
+
+
+# ------------------------------------------------------------------------------------------------
 # products over the rows of two tall matrices (csrc/xty.hip)
 # ------------------------------------------------------------------------------------------------
 def xty_supported(rows, M, N) -> bool:
@@ -1954,3 +2028,29 @@ def xty(x, y, out, colsum_x=None, accumulate=False):
         assert colsum_x.numel() == M and colsum_x.is_contiguous()
     _check(load().asac_xty(_p(x), x.stride(0), M, _p(y), y.stride(0), N, R, _p(out), _p(colsum_x), int(bool(accumulate)), _p(ws),
                            _stream()), 'asac_xty')
+
+
+@_profiled
+def xty_multi(jobs, accumulate=False):
+    """`xty(x, y, out, colsum_x)` for up to 4 jobs [(x, y, out, colsum_x | None), ...] as one launch pair (same values)"""
+    global _last_work
+    n = len(jobs)
+    assert 1 <= n <= 4
+    work = 0.0
+    for x, y, out, cs in jobs:
+        R, M = x.shape
+        N = y.shape[1]
+        assert y.shape[0] == R and x.stride(1) == 1 and y.stride(1) == 1 and out.shape == (M, N) and out.is_contiguous()
+        assert x.dtype == y.dtype == out.dtype == torch.float32 and x.is_cuda
+        assert cs is None or (cs.numel() == M and cs.is_contiguous())
+        work += 2.0 * R * M * N
+    _last_work = work
+    i64, i32, ptr = C.c_int64 * n, C.c_int * n, C.c_void_p * n
+    rows = i64(*[j[0].shape[0] for j in jobs])
+    Ms, Ns = i32(*[j[0].shape[1] for j in jobs]), i32(*[j[1].shape[1] for j in jobs])
+    ws = torch.empty(int(load().asac_xty_multi_workspace(n, rows, Ms, Ns)), dtype=torch.float32, device=jobs[0][0].device)
+    _check(load().asac_xty_multi(n, ptr(*[j[0].data_ptr() for j in jobs]), i64(*[j[0].stride(0) for j in jobs]), Ms,
+                                 ptr(*[j[1].data_ptr() for j in jobs]), i64(*[j[1].stride(0) for j in jobs]), Ns, rows,
+                                 ptr(*[j[2].data_ptr() for j in jobs]),
+                                 ptr(*[None if j[3] is None else j[3].data_ptr() for j in jobs]), int(bool(accumulate)),
+                                 _p(ws), _stream()), 'asac_xty_multi')

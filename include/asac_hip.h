@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 67
+#define ASAC_ABI_VERSION 68
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -914,6 +914,33 @@ int asac_attention_mh_backward(const float* q, const float* k, const float* v, c
                                const float* p_heads, const float* grad_out, const float* grad_weights, float* grad_q,
                                float* grad_k, float* grad_v, void* stream);
 
+/* The Linear layers around that core over the rows of a batch of windows, one launch each (csrc/rows_proj.hip) — replaces, in
+ * `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333): `self.q_proj(query), self.k_proj(key),
+ * self.v_proj(value)` (three nn.Linear(E, E) = three library GEMMs at the launch floor; backward three GEMMs and two
+ * accumulations) and `self.out_proj` when it is ONE residual GELU ResBlock (LinearLayers(E, E, dense_depth 1),
+ * linear_layers.py:24-119) followed by the dead-row / padded-row factor (a GEMM and three elementwise launches).
+ * width = E in {32, 64, 128}; all pointers 16-byte aligned; weights [E][E] (out x in), biases [E].
+ *
+ * asac_rows_proj_forward: x [batch][window][E] with strides in floats (feature stride 1; multiples of 4); job j (n_jobs <= 3)
+ * writes outs[j] [batch][tails[j]][E] = x[:, window - tails[j]:] weights[j]^T + biases[j]  (tails[j] in 1..window: the cut
+ * query of the episode blocks projects the newest positions only).  The pointer arrays are HOST arrays read at the call.
+ * asac_rows_proj_backward: grad_x [batch][window][E] (dense, overwritten) = sum_j grads[j] weights[j], job j reaching the
+ * newest tails[j] positions only; summation order: jobs in order, features in order.
+ * asac_rows_resblock_forward: y = (x + gelu(x W^T + b)) * row_scale[row] (row_scale NULL: 1), pre = x W^T + b (saved for the
+ * backward); x [rows][E] with row stride x_row_stride (multiple of 4), y / pre dense.
+ * asac_rows_resblock_backward: g = grad_y * row_scale; grad_pre = g * gelu'(pre) (dense: its products over the rows with x
+ * are the parameter gradients, asac_xty); grad_x = g + grad_pre W. */
+int asac_rows_proj_supported(int width);
+int asac_rows_proj_forward(const float* x, int64_t x_stride_b, int64_t x_stride_t, int batch, int window, int width, int n_jobs,
+                           const float* const* weights, const float* const* biases, const int* tails, float* const* outs,
+                           void* stream);
+int asac_rows_proj_backward(const float* const* grads, const int* tails, int n_jobs, const float* const* weights, int batch,
+                            int window, int width, float* grad_x, void* stream);
+int asac_rows_resblock_forward(const float* x, int64_t x_row_stride, const float* weight, const float* bias,
+                               const float* row_scale, int64_t rows, int width, float* y, float* pre, void* stream);
+int asac_rows_resblock_backward(const float* grad_y, const float* pre, const float* weight, const float* row_scale,
+                                int64_t rows, int width, float* grad_x, float* grad_pre, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Attention core for short windows: the scores / mask / softmax / weighted-sum part of
  * `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333) under the episode attention of
@@ -1143,6 +1170,14 @@ int asac_xty_supported(int64_t rows, int M, int N);
 int64_t asac_xty_workspace(int64_t rows, int M, int N);
 int asac_xty(const float* x, int64_t x_row_stride, int M, const float* y, int64_t y_row_stride, int N, int64_t rows, float* out,
              float* colsum_x, int accumulate, float* workspace, void* stream);
+/* n_jobs <= 4 such products as ONE launch pair (the parameter gradients of the Linear layers of one attention block: q / k / v
+ * projections and the output block).  Arrays of n_jobs entries (HOST arrays, read at the call); colsums NULL or with NULL
+ * entries: no column sums; no output may appear twice; workspace: asac_xty_multi_workspace floats.  Same values as n_jobs
+ * calls of asac_xty (same partition of the rows, same summation order). */
+int64_t asac_xty_multi_workspace(int n_jobs, const int64_t* rows, const int* M, const int* N);
+int asac_xty_multi(int n_jobs, const float* const* x, const int64_t* x_row_strides, const int* M, const float* const* y,
+                   const int64_t* y_row_strides, const int* N, const int64_t* rows, float* const* outs, float* const* colsums,
+                   int accumulate, float* workspace, void* stream);
 
 /* State head of a representation plugin: y = tanh(x W^T + b) over the N = batch * window rows of an encoder
  * output, one launch per pass (the reference's test plugins end their representations with

@@ -152,3 +152,120 @@ def test_episode_attention_of_the_reference_environments_and_its_speed():
         seq_layers.FUSED_MULTIHEAD = True
     print(f'\nEpisodeMultiheadAttention(64, 2 layers, 8 heads), 1024 x 9, forward + backward (eager, wall): MFMA core '
           f'{fused:.3f} ms, module path {generic:.3f} ms')
+
+
+@pytest.mark.parametrize('B,L,E,tail', [(1024, 9, 64, 9), (37, 9, 64, 3), (5, 18, 32, 1), (3, 7, 128, 7), (1, 1, 64, 1)])
+def test_rows_proj_kernels_against_f64(B, L, E, tail):
+    """`asac_rows_proj_forward/backward` (csrc/rows_proj.hip): q / k / v = three Linears of one input (the query on the newest
+    `tail` positions), read through a strided view, and the summed input gradient — against float64"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    gen = torch.Generator().manual_seed(B + L)
+    big = torch.randn(B, L + 2, E + 8, generator=gen)
+    x = big[:, 1:L + 1, 4:E + 4]                      # strides (L + 2)(E + 8), E + 8, 1: multiples of 4, 16-byte aligned start
+    ws = [torch.randn(E, E, generator=gen) / E ** 0.5 for _ in range(3)]
+    bs = [torch.randn(E, generator=gen) for _ in range(3)]
+    tails = [tail, L, L]
+    xd = big.cuda()[:, 1:L + 1, 4:E + 4]
+    outs = [torch.full((B, n, E), float('nan'), device='cuda') for n in tails]
+    native.rows_proj_forward(xd, [w.cuda() for w in ws], [b.cuda() for b in bs], tails, outs)
+    for o, w, b, n in zip(outs, ws, bs, tails):
+        want = x[:, L - n:].double() @ w.double().t() + b.double()
+        np.testing.assert_allclose(o.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    gs = [torch.randn(B, n, E, generator=gen) for n in tails]
+    gx = torch.full((B, L, E), float('nan'), device='cuda')
+    native.rows_proj_backward([g.cuda() for g in gs], tails, [w.cuda() for w in ws], gx)
+    want = torch.zeros(B, L, E, dtype=torch.float64)
+    for g, w, n in zip(gs, ws, tails):
+        want[:, L - n:] += g.double() @ w.double()
+    np.testing.assert_allclose(gx.cpu().numpy(), want.numpy(), rtol=2e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize('rows,E,scaled', [(9216, 64, True), (50, 64, False), (17, 32, True), (33, 128, True)])
+def test_rows_resblock_kernels_against_f64(rows, E, scaled):
+    """`asac_rows_resblock_forward/backward`: y = (x + gelu(x W^T + b)) * row_scale and its backward against float64 autograd"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, E, generator=gen)
+    w, b = torch.randn(E, E, generator=gen) / E ** 0.5, torch.randn(E, generator=gen)
+    sc = (torch.rand(rows, generator=gen) < 0.8).float() if scaled else None
+    gy = torch.randn(rows, E, generator=gen)
+    xr = x.double().requires_grad_(True)
+    pre_r = xr @ w.double().t() + b.double()
+    pre_r.retain_grad()
+    yr = (xr + torch.nn.functional.gelu(pre_r)) * (1.0 if sc is None else sc.double().unsqueeze(-1))
+    yr.backward(gy.double())
+    y, pre = torch.empty(rows, E, device='cuda'), torch.empty(rows, E, device='cuda')
+    scd = None if sc is None else sc.cuda()
+    native.rows_resblock_forward(x.cuda(), w.cuda(), b.cuda(), scd, y, pre)
+    np.testing.assert_allclose(pre.cpu().numpy(), pre_r.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-5)
+    gx, gpre = torch.empty(rows, E, device='cuda'), torch.empty(rows, E, device='cuda')
+    native.rows_resblock_backward(gy.cuda(), pre, w.cuda(), scd, gx, gpre)
+    np.testing.assert_allclose(gpre.cpu().numpy(), pre_r.grad.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(gx.cpu().numpy(), xr.grad.numpy(), rtol=2e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize('tail', [9, 4])
+def test_projections_and_output_block_around_the_core_are_one_launch_each(tail):
+    """self-attention of a window batch (value is key, query = its newest positions): the three projections as one launch,
+    the output ResBlock with the padded-row factor as one launch, per pass — values and every gradient as the CPU module"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    import algorithm.nn_models as m
+    torch.manual_seed(0)
+    ref = m.MultiheadAttention(64, 8, out_dense_depth=1)
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(1)
+    B, L = 300, 9
+    x = torch.randn(B, L, 64, generator=gen)
+    mask, kpm = _mask('batch', B, tail, L, gen)
+    rowm = torch.rand(B, tail, generator=gen) < 0.2
+    g_out, g_w = torch.randn(B, tail, 64, generator=gen), torch.randn(B, tail, L, generator=gen) * 0.2
+
+    def run(layer, device):
+        xd = x.clone().to(device).requires_grad_(True)
+        key = xd * 1.0
+        out, w = layer(key[:, -tail:] if tail != L else key, key, key, key_padding_mask=kpm.to(device), attn_mask=mask.to(device),
+                       out_row_mask=rowm.to(device))
+        ((out * g_out.to(device)).sum() + (w * g_w.to(device)).sum()).backward()
+        return [t.detach().cpu().numpy() for t in (out, w, xd.grad, *(p.grad for p in layer.parameters()))]
+
+    want = run(ref, 'cpu')
+    with native.LaunchProfiler() as prof:
+        got = run(dev, 'cuda')
+    seen = prof.summary()
+    for name in ('asac_rows_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_forward', 'asac_rows_resblock_backward',
+                 'asac_attention_mh_forward', 'asac_attention_mh_backward'):
+        assert seen[name]['calls'] == 1, (name, seen.keys())
+    for n_, (a, b) in enumerate(zip(got, want)):
+        assert np.isfinite(a).all()
+        atol = 3e-5 if n_ < 3 else 2e-7 * B * L * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
+        np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')
+
+
+def test_xty_multi_is_the_single_products():
+    """`asac_xty_multi`: up to four products over rows in one launch pair — bit-identical to the single launches (same
+    partition of the rows, same summation order), overwriting and accumulating, with ragged shapes side by side"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(9216, 64, 64), (3072, 64, 64), (9216, 192, 40), (777, 8, 64)]
+    jobs, single = [], []
+    for R, M, N in shapes:
+        x, y = torch.randn(R, M, device='cuda', generator=gen), torch.randn(R, N + 3, device='cuda', generator=gen)[:, :N]
+        jobs.append((x, y, torch.randn(M, N, device='cuda', generator=gen), torch.randn(M, device='cuda', generator=gen)))
+        single.append((jobs[-1][2].clone(), jobs[-1][3].clone()))
+    for acc in (False, True):
+        for (x, y, _, _), (o, c) in zip(jobs, single):
+            native.xty(x, y, o, c, accumulate=acc)
+        native.xty_multi(jobs[:3] + [(jobs[3][0], jobs[3][1], jobs[3][2], None)], accumulate=acc)
+        native.xty(jobs[3][0], jobs[3][1], torch.empty_like(jobs[3][2]), jobs[3][3], accumulate=acc)      # (its column sums)
+        for (x, y, o, c), (so, sc) in zip(jobs, single):
+            assert torch.equal(o, so) and torch.equal(c, sc)
+    want = jobs[0][0].double().t() @ jobs[0][1].double()
+    native.xty_multi(jobs[:2])
+    np.testing.assert_allclose(jobs[0][2].cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    with pytest.raises(RuntimeError):
+        native.xty_multi([jobs[0], jobs[0]])         # one output twice

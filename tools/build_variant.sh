@@ -7,6 +7,7 @@ tag=$1; src=$2; shift 2
 L=$R/advanced-soft-actor-critic_amd/lib
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -I$R/include -I$R/advanced-soft-actor-critic_amd/csrc "$@" \
   -c $R/advanced-soft-actor-critic_amd/csrc/$src -o /tmp/variant_$tag.o
-objs=$(ls $L/obj/*.o | grep -v "/${src%.hip}.o")
+base=${src%.hip}; base=${base%_old}       # <x>_old.hip stands in for x.hip
+objs=$(ls $L/obj/*.o | grep -v "/${base}.o")
 hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/variant_$tag.o -o $L/libasac_hip_$tag.so
 echo $L/libasac_hip_$tag.so
