@@ -32,6 +32,9 @@ inline int bad_arg(const char* where) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// out (+)= the sum over `blocks` partials [m * n | m] in a fixed order (csrc/xty.hip)
+void xty_reduce_launch(const float* part, int blocks, int mn, int m, float* out, float* colsum, int accumulate, hipStream_t stream);
+
 inline int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

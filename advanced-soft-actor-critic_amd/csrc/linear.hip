@@ -4,9 +4,12 @@
 // library GEMMs are pure latency (the weight-gradient GEMM reduces 4 608 rows into 8 x 18 numbers: 18 us, plus a
 // bias reduction, the tanh launches and two gradient accumulations); here a pass is one launch.
 //
-// HBM-bound by construction (a row is read once, <= 2 K flop per row): one lane per row, the weights broadcast
-// from LDS.  Backward: per-workgroup partial parameter gradients, summed in workgroup order by the last
-// workgroup to finish (deterministic; no float atomics).
+// A workgroup (4 waves) owns 64 rows: staged in LDS as they lie in memory (coalesced, whatever the row strides and the
+// two-part input), then every product on 16x16x4 f32 MFMA with the rows as the N dimension — forward x W^T, backward g W
+// (input gradient) and G^T (X | 1) (per-workgroup partial parameter gradients).  The partials are summed in workgroup order
+// (deterministic; no float atomics): by the last workgroup to finish when they are few, else by csrc/xty.hip's slice reduction
+// as a second launch.  (Rounds 1-4 ran one lane per row with the weights broadcast from LDS: at K = 64 the 64-step scalar
+// loops of a lane made the backward 35 us for 9 216 rows; the MFMA form is 9.)
 #include "asac_common.h"
 
 namespace asac {
@@ -15,7 +18,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLinMaxK = ASAC_LINEAR_TANH_MAX_IN;      // 64
 constexpr int kLinMaxO = ASAC_LINEAR_TANH_MAX_OUT;     // 16
-constexpr int kLinRows = 128;                          // rows (= lanes) per workgroup
+constexpr int kLinRows = 64, kLinThreads = 256;        // rows per workgroup (4 waves: one 16-row tile each)
+constexpr int64_t kLinTailMax = 12288;                 // partial floats (workgroups x O (K + 1)) the last workgroup sums itself
 
 struct LinArgs {
     const float* x;         // the input rows: x [N][K0] | x1 [N][K - K0] side by side (x1 NULL: K0 == K) — the
@@ -41,108 +45,158 @@ struct LinArgs {
     unsigned int* counter;
 };
 
-// W^T padded to 16 columns: wt[k][o] (zero beyond O), so a lane's 16 accumulators read four float4 per k
+// ---- shared pieces: 64 rows a workgroup of 4 waves; the rows staged in LDS as they lie in memory (coalesced), the products on
+// 16x16x4 f32 MFMA with the ROWS as the N dimension ---------------------------------------------------------------------------
+constexpr int kWtPitch = 20;       // W^T rows at a pitch of 20 floats: the 16-byte reads of 16 lanes (k = lane) hit distinct banks
+constexpr int kXsPitch = kLinMaxK + 1;
+
 __device__ __forceinline__ void stage_wt(const LinArgs& a, float* wt) {
-    for (int i = threadIdx.x; i < a.K * kLinMaxO; i += blockDim.x) {
+    for (int i = threadIdx.x; i < a.K * kLinMaxO; i += kLinThreads) {
         const int k = i / kLinMaxO, o = i - k * kLinMaxO;
-        wt[i] = o < a.O ? a.w[o * a.K + k] : 0.f;
+        wt[k * kWtPitch + o] = o < a.O ? a.w[o * a.K + k] : 0.f;
     }
 }
 
-__global__ __launch_bounds__(kLinRows) void k_linear_tanh_fwd(const LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float wt[kLinMaxK * kLinMaxO];
-    __shared__ float bias[kLinMaxO];
-    stage_wt(a, wt);
-    if (threadIdx.x < kLinMaxO) bias[threadIdx.x] = (int)threadIdx.x < a.O ? a.b[threadIdx.x] : 0.f;
-    __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * kLinRows + threadIdx.x;
-    if (r >= a.N) return;
-    float acc[kLinMaxO];
+// where the two parts of a row start (the second indexed by k like the first)
+__device__ __forceinline__ void stage_offsets(const LinArgs& a, int64_t r0, int rows, int64_t* roff, int64_t* roff1) {
+    if (threadIdx.x < kLinRows) {
+        const int64_t rs = (int)threadIdx.x < rows ? r0 + threadIdx.x : r0;
+        roff[threadIdx.x] = a.x_T ? (rs / a.x_T) * a.x_sb + (rs % a.x_T) * a.x_stride : rs * a.x_stride;
+        roff1[threadIdx.x] = a.x1 ? rs * a.x1_stride - a.K0 : 0;
+    }
+}
+
+// xs[row][k] <- the workgroup's rows (zero beyond `rows`): thread t starts at element t of the [64][K] block and steps by 256
+// elements; eight loads in flight, then their eight LDS stores
+__device__ __forceinline__ void stage_rows(const LinArgs& a, int rows, const int64_t* roff, const int64_t* roff1, float* xs) {
+    const int K = a.K, dr = kLinThreads / K, dk = kLinThreads - dr * K;
+    int row = threadIdx.x / K, k = threadIdx.x - row * K;
+    while (row < kLinRows) {
+        float v[8];
+        int at[8];
 #pragma unroll
-    for (int o = 0; o < kLinMaxO; ++o) acc[o] = 0.f;
-    const float* xr = a.x + (a.x_T ? (r / a.x_T) * a.x_sb + (r % a.x_T) * a.x_stride : r * a.x_stride);
-    const float* xr1 = a.x1 ? a.x1 + r * a.x1_stride - a.K0 : xr;      // (indexed by k like the first part)
-    for (int k = 0; k < a.K; ++k) {
-        const float xv = k < a.K0 ? xr[k] : xr1[k];
-        const float4* w4 = reinterpret_cast<const float4*>(wt + k * kLinMaxO);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = w4[q];
-            acc[4 * q + 0] += xv * w.x;
-            acc[4 * q + 1] += xv * w.y;
-            acc[4 * q + 2] += xv * w.z;
-            acc[4 * q + 3] += xv * w.w;
+        for (int u = 0; u < 8; ++u) {
+            v[u] = 0.f;
+            at[u] = row < kLinRows ? row * kXsPitch + k : -1;
+            if (row < rows) v[u] = k < a.K0 ? a.x[roff[row] + k] : a.x1[roff1[row] + k];
+            row += dr, k += dk;
+            if (k >= K) k -= K, ++row;
         }
-    }
-    float* yr = a.y + r * a.O;
 #pragma unroll
-    for (int o = 0; o < kLinMaxO; ++o)
-        if (o < a.O) yr[o] = tanhf(acc[o] + bias[o]);
+        for (int u = 0; u < 8; ++u)
+            if (at[u] >= 0) xs[at[u]] = v[u];
+    }
 }
 
-__global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
-    __shared__ __attribute__((aligned(16))) float wt[kLinMaxK * kLinMaxO];
-    __shared__ float gs[kLinRows * kLinMaxO];          // g = gy * (1 - y^2), [row][16]
-    __shared__ float xs[kLinRows * (kLinMaxK + 1)];    // the workgroup's input rows and a column of ones, [row][K + 1]
-    __shared__ bool last;
-    stage_wt(a, wt);
+// y^T[o][row] = sum_k W[o][k] x[row][k]: A lane (i = o, slot q) = W^T[k = 4 s + q][o], B lane (j = row, slot q) = x[row][4 s + q]
+__global__ __launch_bounds__(kLinThreads) void k_linear_tanh_fwd(const LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float wt[kLinMaxK * kWtPitch];
+    __shared__ float bias[kLinMaxO];
+    __shared__ float xs[kLinRows * kXsPitch];
+    __shared__ int64_t roff[kLinRows], roff1[kLinRows];
     const int64_t r0 = (int64_t)blockIdx.x * kLinRows;
     const int rows = (int)min((int64_t)kLinRows, a.N - r0);
-    const int64_t r = r0 + threadIdx.x;
-    const bool live = (int)threadIdx.x < rows;
-    float g[kLinMaxO];
-    const int64_t gy_row = live ? r / a.gy_window : 0;
-    const bool gy_on = live && (a.gy_window == 1 || (int)(r - gy_row * a.gy_window) == a.gy_position);
-    const int64_t gy_rows = a.N / a.gy_window;
-#pragma unroll
-    for (int o = 0; o < kLinMaxO; ++o) {
-        float v = 0.f;
-        if (gy_on && o < a.O) {
-            const float yv = a.y[r * a.O + o];
-            float gsum = a.gy[gy_row * a.O + o];
-            for (int e = 1; e < a.gy_members; ++e) gsum += a.gy[(e * gy_rows + gy_row) * a.O + o];     // member order
-            v = gsum * (1.f - yv * yv);
-        }
-        g[o] = v;
-        gs[threadIdx.x * kLinMaxO + o] = v;
+    stage_wt(a, wt);
+    if (threadIdx.x < kLinMaxO) bias[threadIdx.x] = (int)threadIdx.x < a.O ? a.b[threadIdx.x] : 0.f;
+    stage_offsets(a, r0, rows, roff, roff1);
+    __syncthreads();
+    stage_rows(a, rows, roff, roff1, xs);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    const float* xrow = xs + (16 * wave + i) * kXsPitch;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int steps = (a.K + 3) >> 2;
+    for (int s = 0; s < steps; s += 2) {
+        const int k0 = 4 * s + q, k1 = k0 + 4;
+        const float a0 = k0 < a.K ? wt[k0 * kWtPitch + i] : 0.f, b0 = k0 < a.K ? xrow[k0] : 0.f;
+        const float a1 = k1 < a.K ? wt[k1 * kWtPitch + i] : 0.f, b1 = k1 < a.K ? xrow[k1] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
     }
-    const int XS = a.K + 1;
+    const f32x4 acc = acc0 + acc1;                       // acc[r] = pre-activation of output 4 q + r, row 16 wave + i
+    const int64_t r = r0 + 16 * wave + i;
+    if (r >= a.N) return;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int o = 4 * q + rr;
+        if (o < a.O) a.y[r * a.O + o] = tanhf(acc[rr] + bias[o]);
+    }
+}
+
+// TAIL: the last workgroup to arrive sums the partials (few, small partials: one launch); else the caller reduces them with
+// csrc/xty.hip's slice reduction
+template <bool TAIL>
+__global__ __launch_bounds__(kLinThreads) void k_linear_tanh_bwd(const LinArgs a) {
+    __shared__ __attribute__((aligned(16))) float wt[kLinMaxK * kWtPitch];
+    __shared__ __attribute__((aligned(16))) float gs[kLinRows * kLinMaxO];          // g = gy * (1 - y^2), [row][16]
+    __shared__ float xs[kLinRows * kXsPitch];          // the workgroup's input rows and a column of ones, [row][K + 1]
+    __shared__ int64_t roff[kLinRows], roff1[kLinRows];
+    __shared__ bool last;
+    const int64_t r0 = (int64_t)blockIdx.x * kLinRows;
+    const int rows = (int)min((int64_t)kLinRows, a.N - r0);
+    stage_wt(a, wt);
+    stage_offsets(a, r0, rows, roff, roff1);
     {
-        const int64_t rs = live ? r : r0;
-        const float* xr = a.x + (a.x_T ? (rs / a.x_T) * a.x_sb + (rs % a.x_T) * a.x_stride : rs * a.x_stride);
-        const float* xr1 = a.x1 ? a.x1 + rs * a.x1_stride - a.K0 : xr;
-        for (int k = 0; k < a.K; ++k) xs[threadIdx.x * XS + k] = live ? (k < a.K0 ? xr[k] : xr1[k]) : 0.f;
-        xs[threadIdx.x * XS + a.K] = 1.f;
+        // g: thread t -> row t / 4, outputs 4 (t % 4) ... + 3
+        const int row = threadIdx.x >> 2, o0 = 4 * (threadIdx.x & 3);
+        const int64_t r = r0 + row;
+        const bool live = row < rows;
+        const int64_t gy_row = live ? r / a.gy_window : 0;
+        const bool gy_on = live && (a.gy_window == 1 || (int)(r - gy_row * a.gy_window) == a.gy_position);
+        const int64_t gy_rows = a.N / a.gy_window;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int o = o0 + rr;
+            float v = 0.f;
+            if (gy_on && o < a.O) {
+                const float yv = a.y[r * a.O + o];
+                float gsum = a.gy[gy_row * a.O + o];
+                for (int e = 1; e < a.gy_members; ++e) gsum += a.gy[(e * gy_rows + gy_row) * a.O + o];     // member order
+                v = gsum * (1.f - yv * yv);
+            }
+            gs[row * kLinMaxO + o] = v;
+        }
     }
     __syncthreads();
-    if ((a.gx || a.gx1) && live) {
-        float* gxr = a.gx ? a.gx + r * a.K0 : nullptr;
-        float* gxr1 = a.gx1 ? a.gx1 + r * (a.K - a.K0) - a.K0 : nullptr;
-        for (int k = a.gx ? 0 : a.K0; k < (a.gx1 ? a.K : a.K0); ++k) {
-            const float4* w4 = reinterpret_cast<const float4*>(wt + k * kLinMaxO);
-            float s = 0.f;
+    stage_rows(a, rows, roff, roff1, xs);
+    if (threadIdx.x < kLinRows) xs[threadIdx.x * kXsPitch + a.K] = 1.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+    if (a.gx || a.gx1) {
+        // gx^T[k][row] = sum_o W[o][k] g[row][o]: A lane (i = k, slot q) = W^T[k][4 q + s], B lane (j = row, slot q) = g[row][4 q + s]
+        // for the four steps s; the result holds four consecutive k of a row
+        const int K1 = a.K - a.K0;
+        const int64_t r = r0 + 16 * wave + i;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + (16 * wave + i) * kLinMaxO + 4 * q);
+        for (int kt = 0; 16 * kt < a.K; ++kt) {
+            const int kw = 16 * kt + i;
+            f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+            if (kw < a.K) wv = *reinterpret_cast<const f32x4*>(wt + kw * kWtPitch + 4 * q);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w = w4[q];
-                s += g[4 * q + 0] * w.x;
-                s += g[4 * q + 1] * w.y;
-                s += g[4 * q + 2] * w.z;
-                s += g[4 * q + 3] * w.w;
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], gv[s], acc, 0, 0, 0);
+            if (r >= a.N) continue;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int k = 16 * kt + 4 * q + rr;
+                if (k < a.K0) {
+                    if (a.gx) a.gx[r * a.K0 + k] = acc[rr];
+                } else if (k < a.K && a.gx1) {
+                    a.gx1[r * K1 + (k - a.K0)] = acc[rr];
+                }
             }
-            if (k < a.K0) gxr[k] = s;
-            else gxr1[k] = s;
         }
     }
+    __syncthreads();
     // partial parameter gradients of this workgroup, G^T [O x rows] times (X | 1) [rows x (K + 1)] on the matrix
-    // cores: element t = o * (K + 1) + k, column K (the ones) being the bias.  16x16x4 f32 MFMA, A lane (i, kk) =
-    // g[row 4 step + kk][o = i], B lane (j, kk) = x[row 4 step + kk][column 16 tile + j]; a wave takes every
-    // other column tile.  Dead rows carry g = 0.
+    // cores, column K (the ones) being the bias; stored as [O][K] | [O] (the layout of the gradient and of csrc/xty.hip's
+    // partials).  A lane (i, kk) = g[row 4 step + kk][o = i], B lane (j, kk) = x[row 4 step + kk][column 16 tile + j]; a
+    // wave takes every fourth column tile.  Dead rows carry g = 0.
     const int P = a.O * (a.K + 1);
     float* mine = a.partial + (int64_t)blockIdx.x * P;
     {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+        const int kk = q;
         const int tiles = (a.K + 1 + 15) / 16;
-        for (int tile = wave; tile < tiles; tile += kLinRows / 64) {
+        for (int tile = wave; tile < tiles; tile += kLinThreads / 64) {
             const int col = tile * 16 + i, colc = min(col, a.K);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             const bool real = col <= a.K;
@@ -152,7 +206,7 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
                 for (int u = 0; u < 8; ++u) {
                     const int row = 4 * (s0 + u) + kk;
                     av[u] = gs[row * kLinMaxO + i];
-                    xv[u] = xs[row * XS + colc];
+                    xv[u] = xs[row * kXsPitch + colc];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u += 2) {
@@ -164,35 +218,41 @@ __global__ __launch_bounds__(kLinRows) void k_linear_tanh_bwd(const LinArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int o = 4 * kk + rr;
-                if (o < a.O && col <= a.K) mine[o * (a.K + 1) + col] = acc[rr];
+                if (o < a.O && col <= a.K) {
+                    float* dst = mine + (col < a.K ? o * a.K + col : a.O * a.K + o);
+                    // (TAIL: written through to where every workgroup sees it — no release fence, which would write back
+                    // this XCD's whole L2)
+                    if (TAIL) __hip_atomic_store(dst, acc[rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *dst = acc[rr];
+                }
             }
         }
     }
-    // the last workgroup to arrive sums the partials in workgroup order
-    __threadfence();
+    if (!TAIL) return;
+    // the last workgroup to arrive sums the partials in workgroup order (relaxed device-scope accesses ordered by the wait
+    // for this wave's stores and the barrier)
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
     if (!last) return;
-    __threadfence();
-    // (plain loads: this workgroup has not touched the other workgroups' partials before, and the fences order them
-    // after the arrival count; sixteen are requested at a time, then added in workgroup order)
+    // sixteen partials requested at a time, then added in workgroup order
     const int nb = (int)gridDim.x;
-    for (int t = threadIdx.x; t < P; t += kLinRows) {
-        const int o = t / (a.K + 1), k = t - o * (a.K + 1);
-        const float* col = a.partial + t;
+    for (int t = threadIdx.x; t < P; t += kLinThreads) {
+        float* col = a.partial + t;
         float s = 0.f;
         for (int b0 = 0; b0 < nb; b0 += 16) {
             float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = col[(int64_t)min(b0 + u, nb - 1) * P];
+            for (int u = 0; u < 16; ++u)
+                v[u] = __hip_atomic_load(col + (int64_t)min(b0 + u, nb - 1) * P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < 16; ++u) s += b0 + u < nb ? v[u] : 0.f;
         }
-        float* dst = a.gp + (k < a.K ? o * a.K + k : a.O * a.K + o);
+        float* dst = a.gp + t;
         *dst = a.accumulate ? *dst + s : s;
     }
-    if (threadIdx.x == 0) *a.counter = 0u;       // ready for the next launch
+    if (threadIdx.x == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
 }
 
 static bool lin_dims_ok(int64_t N, int K, int O) { return N > 0 && K > 0 && K <= kLinMaxK && O > 0 && O <= kLinMaxO; }
@@ -224,7 +284,7 @@ int asac_linear_tanh_forward2w(const float* x0, int64_t x0_row_stride, int x0_wi
     a.x_T = x0_window_T, a.x_sb = x0_sample_stride;
     a.x = x0, a.x_stride = x0_row_stride, a.K0 = K0, a.x1 = x1, a.x1_stride = x1_row_stride;
     a.w = weight, a.b = bias, a.N = N, a.K = K, a.O = O, a.y = y;
-    ASAC_LAUNCH(k_linear_tanh_fwd, dim3((unsigned)((N + kLinRows - 1) / kLinRows)), dim3(kLinRows), 0, as_stream(stream), a);
+    ASAC_LAUNCH(k_linear_tanh_fwd, dim3((unsigned)((N + kLinRows - 1) / kLinRows)), dim3(kLinThreads), 0, as_stream(stream), a);
     return finish_launch("asac_linear_tanh_forward");
 }
 
@@ -262,7 +322,12 @@ int asac_linear_tanh_backward2w(const float* x0, int64_t x0_row_stride, int x0_w
     a.gy_position = grad_position, a.gx = grad_x0, a.gx1 = grad_x1, a.gp = grad_params, a.accumulate = accumulate;
     a.partial = workspace;
     a.counter = reinterpret_cast<unsigned int*>(workspace + blocks * (int64_t)O * (K + 1));
-    ASAC_LAUNCH(k_linear_tanh_bwd, dim3((unsigned)blocks), dim3(kLinRows), 0, as_stream(stream), a);
+    if (blocks * O * (K + 1) <= kLinTailMax) {
+        ASAC_LAUNCH(k_linear_tanh_bwd<true>, dim3((unsigned)blocks), dim3(kLinThreads), 0, as_stream(stream), a);
+    } else {
+        ASAC_LAUNCH(k_linear_tanh_bwd<false>, dim3((unsigned)blocks), dim3(kLinThreads), 0, as_stream(stream), a);
+        xty_reduce_launch(workspace, (int)blocks, O * K, O, grad_params, grad_params + O * K, accumulate, as_stream(stream));
+    }
     return finish_launch("asac_linear_tanh_backward");
 }
 

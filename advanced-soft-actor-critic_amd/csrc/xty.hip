@@ -136,6 +136,14 @@ inline int row_blocks(int64_t rows) {
 }  // namespace xty
 }  // namespace asac
 
+namespace asac {
+// csrc/linear.hip's partial parameter gradients share the layout: summed by the same slice reduction
+void xty_reduce_launch(const float* part, int blocks, int mn, int m, float* out, float* colsum, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(xty::k_xty_reduce, dim3((unsigned)((mn + m + 63) / 64)), dim3(64 * xty::kRedSlices), 0, stream, part, blocks, mn, m,
+                       out, colsum, accumulate);
+}
+}  // namespace asac
+
 using namespace asac;
 using namespace asac::xty;
 

@@ -20,7 +20,7 @@ def _ref(x, w, b, gy):
 
 
 @pytest.mark.parametrize('N,K,O', [(1, 1, 1), (127, 18, 8), (128, 8, 8), (129, 5, 3), (4608, 18, 8), (9216, 8, 8),
-                                   (1000, 64, 16), (333, 33, 16)])
+                                   (1000, 64, 16), (333, 33, 16), (9216, 64, 8), (20736, 64, 16), (9217, 63, 8)])
 def test_linear_tanh_kernels(N, K, O):
     from asac_amd import native
     torch.manual_seed(N + K)
