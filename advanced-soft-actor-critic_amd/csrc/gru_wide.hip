@@ -201,24 +201,43 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
             wt[i][kt] = *reinterpret_cast<const f32x4*>(a.w_hh_t + (int64_t)(16 * ub + x) * (3 * H) + 16 * kt + 4 * q);
     }
     const int lead = lead_of(a.pad, a.pad_sb, row, a.L);
+    // the step's inputs are requested one step ahead (the stores of a step may alias them for all the compiler knows: without
+    // this every step waited for its own loads)
+    f32x4 g_n[NBW], rg_n[NBW], zg_n[NBW], ng_n[NBW], hn_n[NBW], hp_n[NBW];
+    uint8_t pad_n = 0;
+    auto request = [&](int t) {
+        pad_n = a.pad ? a.pad[row * a.pad_sb + t] : 0;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            const int col = 16 * ub + 4 * q;
+            g_n[i] = live ? *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col) : zero4();
+            const float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
+            rg_n[i] = *reinterpret_cast<const f32x4*>(gp), zg_n[i] = *reinterpret_cast<const f32x4*>(gp + H);
+            ng_n[i] = *reinterpret_cast<const f32x4*>(gp + 2 * H), hn_n[i] = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+            if (t > 0) hp_n[i] = *reinterpret_cast<const f32x4*>(a.hraw + (row * a.L + t - 1) * H + col);
+            else hp_n[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + col) : zero4();
+        }
+    };
+    request(a.L - 1);
     for (int t = a.L - 1; t >= 0; --t) {
         const int cur = t & 1;
-        const bool padded = a.pad ? a.pad[row * a.pad_sb + t] != 0 : false;
+        const bool padded = pad_n != 0;
         const bool active = t >= lead;
+        f32x4 g_c[NBW], rg_c[NBW], zg_c[NBW], ng_c[NBW], hn_c[NBW], hp_c[NBW];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+            g_c[i] = g_n[i], rg_c[i] = rg_n[i], zg_c[i] = zg_n[i], ng_c[i] = ng_n[i], hn_c[i] = hn_n[i], hp_c[i] = hp_n[i];
+        if (t > 0) request(t - 1);
         f32x4 direct[NBW];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
             const int col = 16 * ub + 4 * q;
-            f32x4 g = zero4();
-            if (!padded && live) g = *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col);
-            const float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
-            const f32x4 rg = *reinterpret_cast<const f32x4*>(gp), zg = *reinterpret_cast<const f32x4*>(gp + H),
-                        ng = *reinterpret_cast<const f32x4*>(gp + 2 * H), hn = *reinterpret_cast<const f32x4*>(gp + 3 * H);
-            f32x4 hp;
-            if (t > 0) hp = *reinterpret_cast<const f32x4*>(a.hraw + (row * a.L + t - 1) * H + col);
-            else hp = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + col) : zero4();
+            const f32x4 g = padded ? zero4() : g_c[i];
+            const f32x4 rg = rg_c[i], zg = zg_c[i], ng = ng_c[i], hn = hn_c[i], hp = hp_c[i];
             f32x4 d_r, d_z, d_n, d_nh;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
