@@ -70,19 +70,23 @@ __device__ __forceinline__ int lead_of(const uint8_t* pad, int64_t pad_sb, int64
     return 0;
 }
 
-template <int HB>
+// The time loop is written so that the compiler can wait for a step's inputs BY COUNT (`s_waitcnt vmcnt(n)`, the later stores
+// still in flight) instead of draining the queue every step (a store round trip a step: 0.4 of 1.65 us with the saves):
+//   * two input register sets, the loop unrolled by two — no register copies that would pin a wait to the loop's back edge;
+//   * the same vector-memory instructions on every path: lanes beyond the batch replicate the last row (same inputs, same
+//     arithmetic) and rewrite its values; with SAVE (h_raw and gates given) the twin's second network, which saves nothing,
+//     stores its output in their place; the request after the last step re-reads it; without a mask the byte comes from w_hh.
+template <int HB, bool SAVE>
 __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     constexpr int H = 16 * HB, NBW = (HB + 3) / 4;
     __shared__ f32x4 s_h[2][HB][64];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
+    __builtin_assume(w >= 0 && w < 4);
     const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
-    const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
     const bool second = a.twin_B > 0 && (int64_t)blockIdx.x * 16 >= a.twin_B;      // (workgroup-uniform: twin_B % 16 == 0)
     const float* w_hh = second ? a.w_hh2 : a.w_hh;
     const float* b_hh = second ? a.b_hh2 : a.b_hh;
-    const int64_t srow = second ? row - a.twin_B : row;      // the row of h0 / pad (shared by the two networks)
-    float* const hraw = second ? nullptr : a.hraw;
-    float* const gates = second ? nullptr : a.gates;
+    const int64_t srow = second ? row - a.twin_B : row;      // the row of h0 / pad / the saves (shared by the two networks)
     f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
@@ -99,31 +103,26 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
         s_h[0][ub][l] = h[i];
     }
     const int lead = lead_of(a.pad, a.pad_sb, srow, a.L);
-    // the step's inputs are requested one step ahead
-    f32x4 gi_n[NBW][3];
-    uint8_t pad_n = 0;
-    auto request = [&](int t) {
+    struct StepIn {
+        f32x4 gi[NBW][3];
+        uint8_t pad;
+    };
+    const uint8_t* const pad_row = a.pad ? a.pad + srow * a.pad_sb : reinterpret_cast<const uint8_t*>(a.w_hh);
+    const int pad_step = a.pad ? 1 : 0;
+    auto request = [&](int t, StepIn& in) {
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
-                gi_n[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
+                in.gi[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
         }
-        pad_n = a.pad ? a.pad[srow * a.pad_sb + t] : 0;
+        in.pad = pad_row[t * pad_step];
     };
-    request(0);
-    __syncthreads();
-    for (int t = 0; t < a.L; ++t) {
+    auto step = [&](int t, const StepIn& in) {
         const int cur = t & 1;
-        f32x4 gi[NBW][3];
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-#pragma unroll
-            for (int gate = 0; gate < 3; ++gate) gi[i][gate] = gi_n[i][gate];
-        const bool padded = pad_n != 0, active = t >= lead;
-        if (t + 1 < a.L) request(t + 1);
+        const bool padded = a.pad && in.pad != 0, active = t >= lead;
         f32x4 hb[HB];
 #pragma unroll
         for (int kt = 0; kt < HB; ++kt) hb[kt] = s_h[cur][kt][l];
@@ -143,31 +142,49 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
             f32x4 rg, zg, ng, hn, hv, ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                rg[r] = sigmoidf_(gi[i][0][r] + (ar[r] + bh[i][0][r]));
-                zg[r] = sigmoidf_(gi[i][1][r] + (az[r] + bh[i][1][r]));
+                rg[r] = sigmoidf_(in.gi[i][0][r] + (ar[r] + bh[i][0][r]));
+                zg[r] = sigmoidf_(in.gi[i][1][r] + (az[r] + bh[i][1][r]));
                 hn[r] = an[r] + bh[i][2][r];
-                ng[r] = tanhf_(gi[i][2][r] + rg[r] * hn[r]);
+                ng[r] = tanhf_(in.gi[i][2][r] + rg[r] * hn[r]);
                 const float hnew = (1.f - zg[r]) * ng[r] + zg[r] * h[i][r];
                 hv[r] = active ? hnew : h[i][r];
                 ov[r] = padded ? 0.f : hv[r];
             }
             h[i] = hv;
             s_h[cur ^ 1][ub][l] = hv;
-            if (live) {
-                const int col = 16 * ub + 4 * q;
-                *reinterpret_cast<f32x4*>(a.out + row * a.out_sb + t * a.out_st + col) = ov;
-                if (hraw) *reinterpret_cast<f32x4*>(hraw + (row * a.L + t) * H + col) = hv;
-                if (gates) {
-                    float* gp = gates + (row * a.L + t) * (4 * H) + col;
-                    *reinterpret_cast<f32x4*>(gp) = rg;
-                    *reinterpret_cast<f32x4*>(gp + H) = zg;
-                    *reinterpret_cast<f32x4*>(gp + 2 * H) = ng;
-                    *reinterpret_cast<f32x4*>(gp + 3 * H) = hn;
-                }
+            const int col = 16 * ub + 4 * q;
+            float* const op = a.out + row * a.out_sb + t * a.out_st + col;
+            *reinterpret_cast<f32x4*>(op) = ov;
+            if (SAVE) {
+                float* const gp = a.gates + (srow * a.L + t) * (4 * H) + col;
+                *reinterpret_cast<f32x4*>(second ? op : a.hraw + (srow * a.L + t) * H + col) = second ? ov : hv;
+                *reinterpret_cast<f32x4*>(second ? op : gp) = second ? ov : rg;
+                *reinterpret_cast<f32x4*>(second ? op : gp + H) = second ? ov : zg;
+                *reinterpret_cast<f32x4*>(second ? op : gp + 2 * H) = second ? ov : ng;
+                *reinterpret_cast<f32x4*>(second ? op : gp + 3 * H) = second ? ov : hn;
             }
         }
         lds_barrier();
+    };
+    StepIn in_a, in_b;
+    request(0, in_a);
+    __syncthreads();
+    // (the first pair outside the loop: the loop is then entered in the state its back edge leaves — requested inputs followed
+    // by a step's stores — and the count holds on both paths)
+    int t = 0;
+    if (a.L >= 2) {
+        request(1, in_b);
+        step(0, in_a);
+        request(min(2, a.L - 1), in_a);
+        step(1, in_b);
+        for (t = 2; t + 1 < a.L; t += 2) {
+            request(t + 1, in_b);
+            step(t, in_a);
+            request(min(t + 2, a.L - 1), in_a);
+            step(t + 1, in_b);
+        }
     }
+    if (t < a.L) step(t, in_a);      // (odd L: in_a holds step L - 1)
 }
 
 struct BwdArgs {
@@ -183,12 +200,14 @@ struct BwdArgs {
     int32_t B, L;
 };
 
+// (the time loop is shaped like k_gruw_fwd's: two input register sets, the same vector-memory instructions on every path)
 template <int HB>
 __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
     constexpr int H = 16 * HB, NBW = (HB + 3) / 4, KT = 3 * HB;
     __shared__ f32x4 s_g[2][KT][64];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
-    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
+    __builtin_assume(w >= 0 && w < 4);
+    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);      // (lanes beyond the batch replicate the last row)
     const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
     f32x4 wt[NBW][KT], dh[NBW];
 #pragma unroll
@@ -201,43 +220,42 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
             wt[i][kt] = *reinterpret_cast<const f32x4*>(a.w_hh_t + (int64_t)(16 * ub + x) * (3 * H) + 16 * kt + 4 * q);
     }
     const int lead = lead_of(a.pad, a.pad_sb, row, a.L);
-    // the step's inputs are requested one step ahead (the stores of a step may alias them for all the compiler knows: without
-    // this every step waited for its own loads)
-    f32x4 g_n[NBW], rg_n[NBW], zg_n[NBW], ng_n[NBW], hn_n[NBW], hp_n[NBW];
-    uint8_t pad_n = 0;
-    auto request = [&](int t) {
-        pad_n = a.pad ? a.pad[row * a.pad_sb + t] : 0;
+    struct StepIn {
+        f32x4 g[NBW], rg[NBW], zg[NBW], ng[NBW], hn[NBW], hp[NBW];
+        uint8_t pad;
+    };
+    const uint8_t* const pad_row = a.pad ? a.pad + row * a.pad_sb : reinterpret_cast<const uint8_t*>(a.w_hh_t);
+    const int pad_step = a.pad ? 1 : 0;
+    auto request = [&](int t, StepIn& in) {
+        in.pad = pad_row[t * pad_step];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
             const int col = 16 * ub + 4 * q;
-            g_n[i] = live ? *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col) : zero4();
+            in.g[i] = *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col);
             const float* gp = a.gates + (row * a.L + t) * (4 * H) + col;
-            rg_n[i] = *reinterpret_cast<const f32x4*>(gp), zg_n[i] = *reinterpret_cast<const f32x4*>(gp + H);
-            ng_n[i] = *reinterpret_cast<const f32x4*>(gp + 2 * H), hn_n[i] = *reinterpret_cast<const f32x4*>(gp + 3 * H);
-            if (t > 0) hp_n[i] = *reinterpret_cast<const f32x4*>(a.hraw + (row * a.L + t - 1) * H + col);
-            else hp_n[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + row * a.h0_sb + col) : zero4();
+            in.rg[i] = *reinterpret_cast<const f32x4*>(gp), in.zg[i] = *reinterpret_cast<const f32x4*>(gp + H);
+            in.ng[i] = *reinterpret_cast<const f32x4*>(gp + 2 * H), in.hn[i] = *reinterpret_cast<const f32x4*>(gp + 3 * H);
+            // the state before the step: h_raw of the step before, h0 before step 0 — or zero: then any address, the value is dropped
+            const float* hp_at = t > 0 ? a.hraw + (row * a.L + t - 1) * H + col
+                                       : (a.h0 ? a.h0 + row * a.h0_sb + col : a.hraw + row * a.L * H + col);
+            in.hp[i] = *reinterpret_cast<const f32x4*>(hp_at);      // (dropped in the step when there is no such state)
         }
     };
-    request(a.L - 1);
-    for (int t = a.L - 1; t >= 0; --t) {
+    auto step = [&](int t, const StepIn& in) {
         const int cur = t & 1;
-        const bool padded = pad_n != 0;
+        const bool padded = a.pad && in.pad != 0;
         const bool active = t >= lead;
-        f32x4 g_c[NBW], rg_c[NBW], zg_c[NBW], ng_c[NBW], hn_c[NBW], hp_c[NBW];
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-            g_c[i] = g_n[i], rg_c[i] = rg_n[i], zg_c[i] = zg_n[i], ng_c[i] = ng_n[i], hn_c[i] = hn_n[i], hp_c[i] = hp_n[i];
-        if (t > 0) request(t - 1);
         f32x4 direct[NBW];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
             const int col = 16 * ub + 4 * q;
-            const f32x4 g = padded ? zero4() : g_c[i];
-            const f32x4 rg = rg_c[i], zg = zg_c[i], ng = ng_c[i], hn = hn_c[i], hp = hp_c[i];
+            const f32x4 g = padded ? zero4() : in.g[i];
+            const f32x4 rg = in.rg[i], zg = in.zg[i], ng = in.ng[i], hn = in.hn[i];
+            const f32x4 hp = (t > 0 || a.h0) ? in.hp[i] : zero4();
             f32x4 d_r, d_z, d_n, d_nh;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -252,16 +270,14 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
                 d_nh[r] = active ? dn_pre * rg[r] : 0.f;
                 direct[i][r] = active ? dht * zg[r] : dht;
             }
-            if (live) {
-                float* o = a.dgi + (row * a.L + t) * (3 * H) + col;
-                *reinterpret_cast<f32x4*>(o) = d_r;
-                *reinterpret_cast<f32x4*>(o + H) = d_z;
-                *reinterpret_cast<f32x4*>(o + 2 * H) = d_n;
-                float* o2 = a.dgh + (row * a.L + t) * (3 * H) + col;
-                *reinterpret_cast<f32x4*>(o2) = d_r;
-                *reinterpret_cast<f32x4*>(o2 + H) = d_z;
-                *reinterpret_cast<f32x4*>(o2 + 2 * H) = d_nh;
-            }
+            float* o = a.dgi + (row * a.L + t) * (3 * H) + col;
+            *reinterpret_cast<f32x4*>(o) = d_r;
+            *reinterpret_cast<f32x4*>(o + H) = d_z;
+            *reinterpret_cast<f32x4*>(o + 2 * H) = d_n;
+            float* o2 = a.dgh + (row * a.L + t) * (3 * H) + col;
+            *reinterpret_cast<f32x4*>(o2) = d_r;
+            *reinterpret_cast<f32x4*>(o2 + H) = d_z;
+            *reinterpret_cast<f32x4*>(o2 + 2 * H) = d_nh;
             s_g[cur][0 * HB + ub][l] = d_r;
             s_g[cur][1 * HB + ub][l] = d_z;
             s_g[cur][2 * HB + ub][l] = d_nh;
@@ -279,7 +295,24 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
             }
             dh[i] = direct[i] + (acc0 + acc1);
         }
+    };
+    // steps L - 1 ... 0, in pairs; the first pair outside the loop (see k_gruw_fwd)
+    StepIn in_a, in_b;
+    int t = a.L - 1;
+    request(t, in_a);
+    if (a.L >= 2) {
+        request(t - 1, in_b);
+        step(t, in_a);
+        request(max(t - 2, 0), in_a);
+        step(t - 1, in_b);
+        for (t -= 2; t >= 1; t -= 2) {
+            request(t - 1, in_b);
+            step(t, in_a);
+            request(max(t - 2, 0), in_a);
+            step(t - 1, in_b);
+        }
     }
+    if (t == 0) step(0, in_a);      // (odd L, or L == 1: in_a holds step 0)
     if (a.dh0 && live) {
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
@@ -291,6 +324,19 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static void launch_fwd(int hidden, bool save, dim3 grid, hipStream_t s, const FwdArgs& a) {
+    const dim3 block(kThreads);
+    if (save) {
+        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, true>), grid, block, 0, s, a);
+        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, true>), grid, block, 0, s, a);
+        else ASAC_LAUNCH((k_gruw_fwd<8, true>), grid, block, 0, s, a);
+    } else {
+        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, false>), grid, block, 0, s, a);
+        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, false>), grid, block, 0, s, a);
+        else ASAC_LAUNCH((k_gruw_fwd<8, false>), grid, block, 0, s, a);
+    }
+}
 
 }  // namespace gruw
 }  // namespace asac
@@ -309,18 +355,16 @@ int asac_gru_wide_forward(const float* gi, int64_t gi_stride_b, int64_t gi_strid
     if (!gi || !w_hh || !b_hh || !out || B <= 0 || L <= 0 || !asac_gru_wide_supported(hidden) || !aligned16(gi) ||
         !aligned16(w_hh) || !aligned16(b_hh) || !aligned16(out) || (h0 && !aligned16(h0)) || (gi_stride_b & 3) ||
         (gi_stride_t & 3) || (out_stride_b & 3) || (out_stride_t & 3) || (h0_stride_b & 3) || (h_raw && !aligned16(h_raw)) ||
-        (gates && !aligned16(gates)))
+        (gates && !aligned16(gates)) || (h_raw == nullptr) != (gates == nullptr))
         return bad_arg("asac_gru_wide_forward");
     FwdArgs a;
     a.gi = gi, a.gi_sb = gi_stride_b, a.gi_st = gi_stride_t, a.w_hh = w_hh, a.b_hh = b_hh, a.h0 = h0, a.h0_sb = h0_stride_b;
     a.pad = padding_mask, a.pad_sb = mask_stride_b, a.out = out, a.out_sb = out_stride_b, a.out_st = out_stride_t;
     a.hraw = h_raw, a.gates = gates, a.B = B, a.L = L;
     a.w_hh2 = a.b_hh2 = nullptr, a.twin_B = 0;
-    const dim3 grid((unsigned)((B + 15) / 16)), block(kThreads);
+    const dim3 grid((unsigned)((B + 15) / 16));
     hipStream_t s = as_stream(stream);
-    if (hidden == 32) ASAC_LAUNCH(k_gruw_fwd<2>, grid, block, 0, s, a);
-    else if (hidden == 64) ASAC_LAUNCH(k_gruw_fwd<4>, grid, block, 0, s, a);
-    else ASAC_LAUNCH(k_gruw_fwd<8>, grid, block, 0, s, a);
+    launch_fwd(hidden, h_raw != nullptr, grid, s, a);
     return finish_launch("asac_gru_wide_forward");
 }
 
@@ -332,18 +376,16 @@ int asac_gru_wide_forward_twin(const float* gi, int64_t gi_stride_b, int64_t gi_
         !asac_gru_wide_supported(hidden) || !aligned16(gi) || !aligned16(w_hh) || !aligned16(b_hh) || !aligned16(w_hh_twin) ||
         !aligned16(b_hh_twin) || !aligned16(out) || (h0 && !aligned16(h0)) || (gi_stride_b & 3) || (gi_stride_t & 3) ||
         (out_stride_b & 3) || (out_stride_t & 3) || (h0_stride_b & 3) || (h_raw && !aligned16(h_raw)) ||
-        (gates && !aligned16(gates)))
+        (gates && !aligned16(gates)) || (h_raw == nullptr) != (gates == nullptr))
         return bad_arg("asac_gru_wide_forward_twin");
     FwdArgs a;
     a.gi = gi, a.gi_sb = gi_stride_b, a.gi_st = gi_stride_t, a.w_hh = w_hh, a.b_hh = b_hh, a.h0 = h0, a.h0_sb = h0_stride_b;
     a.pad = padding_mask, a.pad_sb = mask_stride_b, a.out = out, a.out_sb = out_stride_b, a.out_st = out_stride_t;
     a.hraw = h_raw, a.gates = gates, a.B = 2 * B, a.L = L;
     a.w_hh2 = w_hh_twin, a.b_hh2 = b_hh_twin, a.twin_B = B;
-    const dim3 grid((unsigned)(2 * B / 16)), block(kThreads);
+    const dim3 grid((unsigned)(2 * B / 16));
     hipStream_t s = as_stream(stream);
-    if (hidden == 32) ASAC_LAUNCH(k_gruw_fwd<2>, grid, block, 0, s, a);
-    else if (hidden == 64) ASAC_LAUNCH(k_gruw_fwd<4>, grid, block, 0, s, a);
-    else ASAC_LAUNCH(k_gruw_fwd<8>, grid, block, 0, s, a);
+    launch_fwd(hidden, h_raw != nullptr, grid, s, a);
     return finish_launch("asac_gru_wide_forward_twin");
 }
 
