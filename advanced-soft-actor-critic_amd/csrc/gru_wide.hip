@@ -17,6 +17,7 @@
 #include "asac_common.h"
 
 #include <cmath>
+#include <type_traits>
 
 namespace asac {
 namespace gruw {
@@ -70,6 +71,109 @@ __device__ __forceinline__ int lead_of(const uint8_t* pad, int64_t pad_sb, int64
     return 0;
 }
 
+// The round-4 form of the forward loop (one input set copied at the top of the step, the stores in their own step): kept for
+// hidden 128 WITH the saves, where two unit blocks a wave leave no registers for a second input set or for deferred stores
+// (measured 331 us against 427 for the reshaped loop at 256 x 81; every other case is faster reshaped).
+template <int HB>
+__global__ void __launch_bounds__(kThreads) k_gruw_fwd_one_set(const FwdArgs a) {
+    constexpr int H = 16 * HB, NBW = (HB + 3) / 4;
+    __shared__ f32x4 s_h[2][HB][64];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
+    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
+    const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
+    const bool second = a.twin_B > 0 && (int64_t)blockIdx.x * 16 >= a.twin_B;      // (workgroup-uniform: twin_B % 16 == 0)
+    const float* w_hh = second ? a.w_hh2 : a.w_hh;
+    const float* b_hh = second ? a.b_hh2 : a.b_hh;
+    const int64_t srow = second ? row - a.twin_B : row;      // the row of h0 / pad (shared by the two networks)
+    float* const hraw = second ? nullptr : a.hraw;
+    float* const gates = second ? nullptr : a.gates;
+    f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int ub = w + 4 * i;
+        if (ub >= HB) continue;
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate) {
+#pragma unroll
+            for (int kt = 0; kt < HB; ++kt)
+                wr[i][gate][kt] = *reinterpret_cast<const f32x4*>(w_hh + (int64_t)(gate * H + 16 * ub + x) * H + 16 * kt + 4 * q);
+            bh[i][gate] = *reinterpret_cast<const f32x4*>(b_hh + gate * H + 16 * ub + 4 * q);
+        }
+        h[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + srow * a.h0_sb + 16 * ub + 4 * q) : zero4();
+        s_h[0][ub][l] = h[i];
+    }
+    const int lead = lead_of(a.pad, a.pad_sb, srow, a.L);
+    // the step's inputs are requested one step ahead
+    f32x4 gi_n[NBW][3];
+    uint8_t pad_n = 0;
+    auto request = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+                gi_n[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
+        }
+        pad_n = a.pad ? a.pad[srow * a.pad_sb + t] : 0;
+    };
+    request(0);
+    __syncthreads();
+    for (int t = 0; t < a.L; ++t) {
+        const int cur = t & 1;
+        f32x4 gi[NBW][3];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i)
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) gi[i][gate] = gi_n[i][gate];
+        const bool padded = pad_n != 0, active = t >= lead;
+        if (t + 1 < a.L) request(t + 1);
+        f32x4 hb[HB];
+#pragma unroll
+        for (int kt = 0; kt < HB; ++kt) hb[kt] = s_h[cur][kt][l];
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int ub = w + 4 * i;
+            if (ub >= HB) continue;
+            f32x4 ar = zero4(), az = zero4(), an = zero4();
+#pragma unroll
+            for (int kt = 0; kt < HB; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ar = GW_MF(wr[i][0][kt][r], hb[kt][r], ar);
+                    az = GW_MF(wr[i][1][kt][r], hb[kt][r], az);
+                    an = GW_MF(wr[i][2][kt][r], hb[kt][r], an);
+                }
+            f32x4 rg, zg, ng, hn, hv, ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rg[r] = sigmoidf_(gi[i][0][r] + (ar[r] + bh[i][0][r]));
+                zg[r] = sigmoidf_(gi[i][1][r] + (az[r] + bh[i][1][r]));
+                hn[r] = an[r] + bh[i][2][r];
+                ng[r] = tanhf_(gi[i][2][r] + rg[r] * hn[r]);
+                const float hnew = (1.f - zg[r]) * ng[r] + zg[r] * h[i][r];
+                hv[r] = active ? hnew : h[i][r];
+                ov[r] = padded ? 0.f : hv[r];
+            }
+            h[i] = hv;
+            s_h[cur ^ 1][ub][l] = hv;
+            if (live) {
+                const int col = 16 * ub + 4 * q;
+                *reinterpret_cast<f32x4*>(a.out + row * a.out_sb + t * a.out_st + col) = ov;
+                if (hraw) *reinterpret_cast<f32x4*>(hraw + (row * a.L + t) * H + col) = hv;
+                if (gates) {
+                    float* gp = gates + (row * a.L + t) * (4 * H) + col;
+                    *reinterpret_cast<f32x4*>(gp) = rg;
+                    *reinterpret_cast<f32x4*>(gp + H) = zg;
+                    *reinterpret_cast<f32x4*>(gp + 2 * H) = ng;
+                    *reinterpret_cast<f32x4*>(gp + 3 * H) = hn;
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // The time loop is written so that the compiler can wait for a step's inputs BY COUNT (`s_waitcnt vmcnt(n)`, the later stores
 // still in flight) instead of draining the queue every step (a store round trip a step: 0.4 of 1.65 us with the saves):
 //   * two input register sets, the loop unrolled by two — no register copies that would pin a wait to the loop's back edge;
@@ -120,7 +224,20 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
         }
         in.pad = pad_row[t * pad_step];
     };
-    auto step = [&](int t, const StepIn& in) {
+    // a step's results leave in the NEXT step, between its products (one store per few tiles): issued together at the end of
+    // their own step, the four waves' 24 KB queued at the CU's one vector-memory port (64 B a cycle) and every wave stood at the
+    // barrier until its last store had been taken (0.4 of the step's 1.6 us)
+    constexpr int NS = SAVE ? 6 : 1;
+    f32x4 late[NBW][NS];        // ov | hv, rg, zg, ng, hn of the step before
+    auto store_late = [&](int t, int i, int sidx) {
+        const int col = 16 * (w + 4 * i) + 4 * q;
+        float* const op = a.out + row * a.out_sb + t * a.out_st + col;
+        float* dst = op;
+        if (sidx == 1) dst = a.hraw + (srow * a.L + t) * H + col;
+        if (sidx >= 2) dst = a.gates + (srow * a.L + t) * (4 * H) + (sidx - 2) * H + col;
+        *reinterpret_cast<f32x4*>(second ? op : dst) = late[i][second ? 0 : sidx];
+    };
+    auto step = [&](int t, const StepIn& in, auto has_late) {
         const int cur = t & 1;
         const bool padded = a.pad && in.pad != 0, active = t >= lead;
         f32x4 hb[HB];
@@ -132,13 +249,20 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
             if (ub >= HB) continue;
             f32x4 ar = zero4(), az = zero4(), an = zero4();
 #pragma unroll
-            for (int kt = 0; kt < HB; ++kt)
+            for (int kt = 0; kt < HB; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ar = GW_MF(wr[i][0][kt][r], hb[kt][r], ar);
                     az = GW_MF(wr[i][1][kt][r], hb[kt][r], az);
                     an = GW_MF(wr[i][2][kt][r], hb[kt][r], an);
                 }
+                if (decltype(has_late)::value) {
+#pragma unroll
+                    for (int sidx = 0; sidx < NS; ++sidx)
+                        if (sidx * HB / NS == kt) store_late(t - 1, i, sidx);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             f32x4 rg, zg, ng, hn, hv, ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -152,20 +276,13 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
             }
             h[i] = hv;
             s_h[cur ^ 1][ub][l] = hv;
-            const int col = 16 * ub + 4 * q;
-            float* const op = a.out + row * a.out_sb + t * a.out_st + col;
-            *reinterpret_cast<f32x4*>(op) = ov;
-            if (SAVE) {
-                float* const gp = a.gates + (srow * a.L + t) * (4 * H) + col;
-                *reinterpret_cast<f32x4*>(second ? op : a.hraw + (srow * a.L + t) * H + col) = second ? ov : hv;
-                *reinterpret_cast<f32x4*>(second ? op : gp) = second ? ov : rg;
-                *reinterpret_cast<f32x4*>(second ? op : gp + H) = second ? ov : zg;
-                *reinterpret_cast<f32x4*>(second ? op : gp + 2 * H) = second ? ov : ng;
-                *reinterpret_cast<f32x4*>(second ? op : gp + 3 * H) = second ? ov : hn;
-            }
+            late[i][0] = ov;
+            if (SAVE) late[i][1 % NS] = hv, late[i][2 % NS] = rg, late[i][3 % NS] = zg, late[i][4 % NS] = ng, late[i][5 % NS] = hn;
         }
         lds_barrier();
     };
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
     StepIn in_a, in_b;
     request(0, in_a);
     __syncthreads();
@@ -174,17 +291,26 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     int t = 0;
     if (a.L >= 2) {
         request(1, in_b);
-        step(0, in_a);
+        step(0, in_a, no);
         request(min(2, a.L - 1), in_a);
-        step(1, in_b);
+        step(1, in_b, yes);
         for (t = 2; t + 1 < a.L; t += 2) {
             request(t + 1, in_b);
-            step(t, in_a);
+            step(t, in_a, yes);
             request(min(t + 2, a.L - 1), in_a);
-            step(t + 1, in_b);
+            step(t + 1, in_b, yes);
         }
+        if (t < a.L) step(t, in_a, yes);      // (odd L: in_a holds step L - 1)
+    } else {
+        step(0, in_a, no);
     }
-    if (t < a.L) step(t, in_a);      // (odd L: in_a holds step L - 1)
+    // the last step's results
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (w + 4 * i >= HB) continue;
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) store_late(a.L - 1, i, sidx);
+    }
 }
 
 struct BwdArgs {
@@ -247,12 +373,11 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
         const int cur = t & 1;
         const bool padded = a.pad && in.pad != 0;
         const bool active = t >= lead;
-        f32x4 direct[NBW];
+        f32x4 direct[NBW], st_v[NBW][4];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
-            const int col = 16 * ub + 4 * q;
             const f32x4 g = padded ? zero4() : in.g[i];
             const f32x4 rg = in.rg[i], zg = in.zg[i], ng = in.ng[i], hn = in.hn[i];
             const f32x4 hp = (t > 0 || a.h0) ? in.hp[i] : zero4();
@@ -270,14 +395,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
                 d_nh[r] = active ? dn_pre * rg[r] : 0.f;
                 direct[i][r] = active ? dht * zg[r] : dht;
             }
-            float* o = a.dgi + (row * a.L + t) * (3 * H) + col;
-            *reinterpret_cast<f32x4*>(o) = d_r;
-            *reinterpret_cast<f32x4*>(o + H) = d_z;
-            *reinterpret_cast<f32x4*>(o + 2 * H) = d_n;
-            float* o2 = a.dgh + (row * a.L + t) * (3 * H) + col;
-            *reinterpret_cast<f32x4*>(o2) = d_r;
-            *reinterpret_cast<f32x4*>(o2 + H) = d_z;
-            *reinterpret_cast<f32x4*>(o2 + 2 * H) = d_nh;
+            st_v[i][0] = d_r, st_v[i][1] = d_z, st_v[i][2] = d_n, st_v[i][3] = d_nh;
             s_g[cur][0 * HB + ub][l] = d_r;
             s_g[cur][1 * HB + ub][l] = d_z;
             s_g[cur][2 * HB + ub][l] = d_nh;
@@ -288,10 +406,25 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
             const int ub = w + 4 * i;
             if (ub >= HB) continue;
             f32x4 acc0 = zero4(), acc1 = zero4();      // two chains: the products are the whole step
+            // the step's six stores go out BETWEEN the products, one per pair of tiles: issued together before the barrier, the
+            // four waves' 24 KB queued at the CU's one vector-memory port (64 B a cycle) and every wave stood at the barrier
+            // until its last store had been taken (0.7 of the step's 2.1 us)
+            const int col = 16 * ub + 4 * q;
+            float* const o = a.dgi + (row * a.L + t) * (3 * H) + col;
+            float* const o2 = a.dgh + (row * a.L + t) * (3 * H) + col;
 #pragma unroll
             for (int kt = 0; kt < KT; kt += 2) {
                 acc0 = mfma4(wt[i][kt], s_g[cur][kt][l], acc0);
                 if (kt + 1 < KT) acc1 = mfma4(wt[i][kt + 1], s_g[cur][kt + 1][l], acc1);
+                constexpr int kChunks = (KT + 1) / 2;
+                const int c = kt / 2;
+#pragma unroll
+                for (int sidx = 0; sidx < 6; ++sidx) {
+                    if (sidx * kChunks / 6 != c) continue;
+                    float* const dst = (sidx < 3 ? o : o2) + (sidx % 3) * H;
+                    *reinterpret_cast<f32x4*>(dst) = st_v[i][sidx == 5 ? 3 : (sidx % 3 == 2 ? 2 : sidx % 3)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             dh[i] = direct[i] + (acc0 + acc1);
         }
@@ -330,7 +463,7 @@ static void launch_fwd(int hidden, bool save, dim3 grid, hipStream_t s, const Fw
     if (save) {
         if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, true>), grid, block, 0, s, a);
         else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, true>), grid, block, 0, s, a);
-        else ASAC_LAUNCH((k_gruw_fwd<8, true>), grid, block, 0, s, a);
+        else ASAC_LAUNCH(k_gruw_fwd_one_set<8>, grid, block, 0, s, a);
     } else {
         if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, false>), grid, block, 0, s, a);
         else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, false>), grid, block, 0, s, a);
