@@ -121,16 +121,29 @@ class _GruWideFn(torch.autograd.Function):
             h_prev = torch.cat([h_first, h_raw[:, :-1]], dim=1).reshape(B * L, H)
             inp2 = inp.reshape(B * L, -1)
             if native.xty_supported(B * L, 3 * H, max(inp2.shape[1], H)):
-                # weight and bias gradients as products over the B * L rows on MFMA, both in one launch pair (`asac_xty_multi`)
+                # weight and bias gradients as products over the B * L rows on MFMA, both in one launch pair (`asac_xty_multi`);
+                # under the learner's direct mode added straight into the `.grad` views (no accumulation launches)
+                from .fused_mlp import direct_enabled, direct_skips
+                from .fused_rows_linear import queue_param_grads
+                params = weights[4 * l:4 * l + 4]
+                direct = (direct_enabled() and not direct_skips(*params)
+                          and all(p_.requires_grad and p_.grad is not None and p_.grad.is_contiguous() for p_ in params))
                 jobs = []
                 if ctx.needs_input_grad[5 + 4 * l]:
-                    g_w[4 * l] = torch.empty(3 * H, inp2.shape[1], dtype=dt, device=dev)
-                    g_w[4 * l + 2] = torch.empty(3 * H, dtype=dt, device=dev)
-                    jobs.append((dgi2, inp2 if inp2.stride(1) == 1 else inp2.contiguous(), g_w[4 * l], g_w[4 * l + 2]))
+                    xin = inp2 if inp2.stride(1) == 1 else inp2.contiguous()
+                    if direct:
+                        queue_param_grads(dgi2, xin, params[0].grad, params[2].grad)
+                    else:
+                        g_w[4 * l] = torch.empty(3 * H, inp2.shape[1], dtype=dt, device=dev)
+                        g_w[4 * l + 2] = torch.empty(3 * H, dtype=dt, device=dev)
+                        jobs.append((dgi2, xin, g_w[4 * l], g_w[4 * l + 2]))
                 if ctx.needs_input_grad[5 + 4 * l + 1]:
-                    g_w[4 * l + 1] = torch.empty(3 * H, H, dtype=dt, device=dev)
-                    g_w[4 * l + 3] = torch.empty(3 * H, dtype=dt, device=dev)
-                    jobs.append((dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3]))
+                    if direct:
+                        queue_param_grads(dgh2, h_prev, params[1].grad, params[3].grad)
+                    else:
+                        g_w[4 * l + 1] = torch.empty(3 * H, H, dtype=dt, device=dev)
+                        g_w[4 * l + 3] = torch.empty(3 * H, dtype=dt, device=dev)
+                        jobs.append((dgh2, h_prev, g_w[4 * l + 1], g_w[4 * l + 3]))
                 if len(jobs) == 2:
                     native.xty_multi(jobs)
                 elif jobs:

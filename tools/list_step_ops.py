@@ -26,16 +26,17 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         agent.train()
         torch.cuda.synchronize()
-    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.cpu_parent is None
-           or (e.cpu_parent is not None and not e.cpu_parent.name.startswith('aten::') and e.name.startswith('aten::'))]
-    evs = [e for e in evs if e.name.startswith('aten::')]
+    # every aten op that launched a kernel itself (not through a child aten op), in launch order, with the innermost
+    # python frames of this repository that issued it
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith('aten::')
+           and getattr(e, 'kernels', None)
+           and not any(c.name.startswith('aten::') and getattr(c, 'kernels', None) for c in (e.cpu_children or []))]
     evs.sort(key=lambda e: e.time_range.start)
     for e in evs:
-        kern = [k.name[:50] for k in e.kernels] if hasattr(e, 'kernels') else []
-        if not kern:
-            continue
-        stack = [s for s in (e.stack or []) if 'advanced-soft-actor-critic_amd' in s]
-        print(f'{e.name:32s} {kern[0]:52s} {stack[0].split("advanced-soft-actor-critic_amd/")[-1] if stack else ""}')
+        kern = e.kernels[0].name[:44]
+        stack = [s_.split('/root/repo/')[-1].split('repo/')[-1] for s_ in (e.stack or []) if 'site-packages' not in s_ and 'dist-packages' not in s_
+                 and '.py' in s_]
+        print(f'{e.name:24s} {kern:46s} {" <- ".join(x[-60:] for x in stack[:2])}')
 
 
 if __name__ == '__main__':
