@@ -532,8 +532,11 @@ __global__ void __launch_bounds__(kThreads) k_dec_bwd3(const Bwd3Args a) {
                 const int64_t state = (int64_t)g * 16 + 2 * i8 + sth;
                 const bool live = xx < 30 && state < a.N;
                 const int64_t idx = live ? (state * 3 + oc) * 900 + yy * 30 + xx : 0;
-                rg[oc * 8 + i8] = live ? a.gout[idx] : 0.f;
-                ro[oc * 8 + i8] = live ? a.out[idx] : 1.f;
+                // (the loads themselves are unconditional — index 0 for the lanes without an item: a load under a lane
+                // condition becomes a branch of its own with its own wait, 48 serial round trips per row instead of one batch)
+                const float gv = a.gout[idx], ov = a.out[idx];
+                rg[oc * 8 + i8] = live ? gv : 0.f;
+                ro[oc * 8 + i8] = live ? ov : 1.f;
             }
     };
     auto row_store = [&](int yy) {

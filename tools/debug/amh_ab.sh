@@ -1,2 +1,8 @@
 cd /root/repo
-timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_fused_attn_mh_gpu.py tests/test_fused_decoder_gpu.py -x -q 2>&1 | tail -3
+python tools/debug/amh_probe.py
+python tools/debug/amh_probe.py 1024 20 8 8
+for i in 1 2; do for lib in libasac_hip_old.so libasac_hip.so; do
+printf '%-22s ' $lib
+ASAC_HIP_LIB=/root/repo/advanced-soft-actor-critic_amd/lib/$lib timeout 600 python bench.py --config cfg5 --no-extras --no-cpu-baseline --profile-steps 0 --steps 400 --warmup 40 --run-length 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done; done
