@@ -461,10 +461,12 @@ class SAC_Base(AuxHeadsMixin):
             if dp is not None:
                 self._fpi = StockMLP(dp, self._params.flat, self._params.grad, seg['policy'][0],
                                      seg['policy'][1] - seg['policy'][0], 1, dev, list(self.model_policy.parameters()))
-        if self._fq is not None and self._fq.wide:
-            # critics whose first layer is wider than 64 inputs (64-wide state + action): one launch per network pass, the
-            # chains that pack several networks / sidecar jobs into one launch are not taken
-            self._use_sidecars = False
+        self._wide_critics = self._fq is not None and self._fq.wide
+        if self._wide_critics:
+            # critics whose first layer is wider than 64 inputs (64-wide state + action): one launch per network pass — the
+            # chains that pack several networks into one launch are not taken and no critic launch can host a sidecar job.
+            # The jobs that do not need one still ride: the sampler in the step prologue, the write-backs' passes and the
+            # temperature step in the TD error's return launch and the priority update (as after the fused policy chain)
             self._la_gather_sidecar = False
         self._logger.info(f'fused stock MLP path: Q={self._fq is not None} policy={self._fpi is not None}')
         # When the stock networks and the temperatures are the only trainable parameters, every gradient
@@ -1909,7 +1911,7 @@ class SAC_Base(AuxHeadsMixin):
         the new temperature, evaluates the value that step will write (`pending_alpha`).  -> False: not applicable."""
         rb, b, n = self.replay_buffer, self.burn_in_step, self.n_step
         if not (self._fused_td_chain and self.use_priority and self._same_states(w) and self._use_sidecars
-                and rb.sharded is None and self.curiosity is None and not self.use_rnd):
+                and not self._wide_critics and rb.sharded is None and self.curiosity is None and not self.use_rnd):
             return False
         B_, L_, A = *w.bnx_states.shape[:2], self.c_action_size
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -2000,6 +2002,12 @@ class SAC_Base(AuxHeadsMixin):
             xb = StockMLP._rows(w.bnx_states[:, b], self.state_size)
             ab = StockMLP._rows(w.bnx_actions[:, b], self.c_action_size)
             riders = [sc for sc in (post.sc_write, post.sc_alpha) if sc is not None]
+            if riders and self._wide_critics:
+                # no critic launch to ride in: the write-back's second pass goes with the TD error's return, the temperature
+                # step with the priority update (the return evaluates the value that step will write)
+                self._vtrace_sidecars = [post.sc_write] if post.sc_write is not None else None
+                self._pending_alpha = post.sc_alpha
+                riders = []
             if post.td_sample is not None:
                 job_q, _ = self._fq.job(xb, ab, out=self._cq_td_buf)
                 job_tq, td_q_table = self._ftq.job(
