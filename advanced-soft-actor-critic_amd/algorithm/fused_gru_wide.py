@@ -24,6 +24,17 @@ def fused_gru_wide_supported(x: torch.Tensor, cells) -> bool:
             and all(c.hidden_size == H and c.bias and c.num_layers == 1 and not c.bidirectional for c in cells))
 
 
+def _input_products(x2, w_ih, b_ih, out) -> None:
+    """out [rows, 3H] = x2 w_ih^T + b_ih: a narrow input (observation ++ action) as one MFMA launch (`asac_rows_affine_forward`:
+    the work is writing the result), a wide one (the layer below) as the library's GEMM"""
+    from asac_amd import native
+    K, N = x2.shape[1], w_ih.shape[0]
+    if native.rows_affine_supported(K, N) and x2.stride(1) == 1 and out.is_contiguous():
+        native.rows_affine_forward(x2, w_ih.contiguous(), b_ih.contiguous(), out)
+    else:
+        torch.addmm(b_ih, x2, w_ih.t(), out=out)
+
+
 class _GruWideFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h0, padding_mask, grad_mode, twin, *weights):
@@ -46,8 +57,8 @@ class _GruWideFn(torch.autograd.Function):
             tw_ih, tw_hh, tb_ih, tb_hh = (t.detach() for t in twin[0])
             x2 = x.reshape(B * L, -1)
             gi2 = torch.empty(2 * B, L, 3 * H, dtype=x.dtype, device=x.device)
-            torch.addmm(b_ih, x2, w_ih.t(), out=gi2[:B].view(B * L, 3 * H))
-            torch.addmm(tb_ih, x2, tw_ih.t(), out=gi2[B:].view(B * L, 3 * H))
+            _input_products(x2, w_ih, b_ih, gi2[:B].view(B * L, 3 * H))
+            _input_products(x2, tw_ih, tb_ih, gi2[B:].view(B * L, 3 * H))
             hn2 = torch.empty(2 * B, L, 1, H, dtype=x.dtype, device=x.device)
             h_raw = torch.empty(B, L, H, dtype=x.dtype, device=x.device) if need_grad else None
             gates = torch.empty(B, L, 4 * H, dtype=x.dtype, device=x.device) if need_grad else None
@@ -65,7 +76,8 @@ class _GruWideFn(torch.autograd.Function):
         saved, inp = [], x
         for l in range(layers):
             w_ih, w_hh, b_ih, b_hh = (t.detach() for t in weights[4 * l:4 * l + 4])
-            gi = torch.addmm(b_ih, inp.reshape(B * L, -1), w_ih.t()).view(B, L, 3 * H)       # library GEMM
+            gi = torch.empty(B, L, 3 * H, dtype=x.dtype, device=x.device)
+            _input_products(inp.reshape(B * L, -1), w_ih, b_ih, gi.view(B * L, 3 * H))
             h_raw = torch.empty(B, L, H, dtype=x.dtype, device=x.device) if need_grad else None
             gates = torch.empty(B, L, 4 * H, dtype=x.dtype, device=x.device) if need_grad else None
             native.gru_wide_forward(gi, w_hh.contiguous(), b_hh.contiguous(), None if h0 is None else h0[:, l], mask,

@@ -189,6 +189,62 @@ __global__ void __launch_bounds__(kThreads) k_rows_res_bwd(const ResArgs a) {
     }
 }
 
+struct AffineArgs {
+    const float* x; int64_t xs;              // [rows][K], row stride xs
+    const float* w; const float* b;          // [N][K], [N]
+    int64_t rows;
+    int32_t K, N;
+    float* y;                                // [rows][N] dense
+};
+
+// y = x W^T + b for a NARROW input (K <= 64: observation ++ action in front of a recurrent layer — the input products
+// `x W_ih^T + b_ih` of all steps, reference seq_layers.py:14-114 through nn.GRU) and a wide output (N = 3 H): the library
+// GEMM takes 13-14 us for 20 736 x 8 -> 192; the work is writing 16 MB.  A workgroup owns 16 rows, its waves the output
+// tiles w, w + 4, ...; the x tile (K / 4 scalars a lane) is the B operand of every tile.
+template <int STEPS>      // k-steps of four: K <= 4 STEPS
+__global__ void __launch_bounds__(kThreads) k_rows_affine(const AffineArgs a) {
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, q = l >> 4, x = l & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + x;
+    const bool live = row < a.rows;
+    const float* xp = a.x + (live ? row : a.rows - 1) * a.xs;
+    float xv[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const int k = 4 * s + q;
+        const float got = xp[min(k, a.K - 1)];
+        xv[s] = k < a.K ? got : 0.f;
+    }
+    const int NT = a.N >> 4;
+    // TB of the wave's tiles at a time: their weight operands requested together with the rows (one round trip), then the
+    // products and the stores
+    constexpr int TB = STEPS <= 4 ? 4 : 1;
+    for (int nt0 = wv; nt0 < NT; nt0 += TB * kWaves) {
+        float wq[TB][STEPS];
+        f32x4 bias[TB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int nt = min(nt0 + j * kWaves, NT - 1);
+            const float* wp = a.w + (int64_t)(16 * nt + x) * a.K;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int k = 4 * s + q;
+                const float got = wp[min(k, a.K - 1)];
+                wq[j][s] = k < a.K ? got : 0.f;
+            }
+            bias[j] = ld4(a.b + 16 * nt + 4 * q);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int nt = nt0 + j * kWaves;
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) acc = RP_MF(wq[j][s], xv[s], acc);
+            acc += bias[j];
+            if (live && nt < NT) st4(a.y + row * a.N + 16 * nt + 4 * q, acc);
+        }
+    }
+}
+
 inline bool width_ok(int E) { return E == 32 || E == 64 || E == 128; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -267,6 +323,22 @@ int asac_rows_resblock_backward(const float* grad_y, const float* pre, const flo
     const dim3 grid((unsigned)((rows + 15) / 16));
     RP_LAUNCH(k_rows_res_bwd, width, grid, as_stream(stream), a);
     return finish_launch("asac_rows_resblock_backward");
+}
+
+int asac_rows_affine_supported(int K, int N) { return K >= 1 && K <= 64 && N >= 16 && N <= 1024 && (N & 15) == 0; }
+
+int asac_rows_affine_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias, int64_t rows,
+                             int N, float* y, void* stream) {
+    if (!x || !weight || !bias || !y || rows <= 0 || !asac_rows_affine_supported(K, N) || x_row_stride < K || !aligned16(bias) ||
+        !aligned16(y))
+        return bad_arg("asac_rows_affine_forward");
+    AffineArgs a{};
+    a.x = x, a.xs = x_row_stride, a.w = weight, a.b = bias, a.rows = rows, a.K = K, a.N = N, a.y = y;
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    if (K <= 8) ASAC_LAUNCH(k_rows_affine<2>, grid, dim3(kThreads), 0, as_stream(stream), a);
+    else if (K <= 16) ASAC_LAUNCH(k_rows_affine<4>, grid, dim3(kThreads), 0, as_stream(stream), a);
+    else ASAC_LAUNCH(k_rows_affine<16>, grid, dim3(kThreads), 0, as_stream(stream), a);
+    return finish_launch("asac_rows_affine_forward");
 }
 
 }  // extern "C"

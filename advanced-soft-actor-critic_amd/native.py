@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 68
+ABI_VERSION = 69
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -392,6 +392,9 @@ _SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_rows_resblock_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
+    'asac_rows_affine_supported': (C.c_int, [C.c_int, C.c_int]),
+    'asac_rows_affine_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
     'asac_gru_wide_supported': (C.c_int, [C.c_int]),
     'asac_gru_wide_forward_twin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -1982,6 +1985,23 @@ def rows_proj_backward(grads, tails, weights, grad_x):
     _last_work = 2.0 * B * sum(tails) * E * E
     _check(load().asac_rows_proj_backward(_ptr_array(grads), (C.c_int * len(tails))(*tails), len(grads), _ptr_array(weights), B,
                                           L, E, _p(grad_x), _stream()), 'asac_rows_proj_backward')
+
+
+def rows_affine_supported(K, N) -> bool:
+    return bool(load().asac_rows_affine_supported(int(K), int(N)))
+
+
+@_profiled
+def rows_affine_forward(x, weight, bias, y):
+    """y [rows, N] = x [rows, K] weight^T + bias (K <= 64, N a multiple of 16): one launch; x may have a row stride"""
+    global _last_work
+    rows, K = x.shape
+    N = weight.shape[0]
+    assert x.stride(1) == 1 and x.dtype == torch.float32 and x.is_cuda and y.shape == (rows, N)
+    _dense_f32(weight, bias, y)
+    _last_work = 2.0 * rows * K * N
+    _check(load().asac_rows_affine_forward(_p(x), x.stride(0), K, _p(weight), _p(bias), rows, N, _p(y), _stream()),
+           'asac_rows_affine_forward')
 
 
 @_profiled

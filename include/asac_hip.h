@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 68
+#define ASAC_ABI_VERSION 69
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -940,6 +940,12 @@ int asac_rows_resblock_forward(const float* x, int64_t x_row_stride, const float
                                const float* row_scale, int64_t rows, int width, float* y, float* pre, void* stream);
 int asac_rows_resblock_backward(const float* grad_y, const float* pre, const float* weight, const float* row_scale,
                                 int64_t rows, int width, float* grad_x, float* grad_pre, void* stream);
+/* y [rows][N] = x [rows][K] weight[N][K]^T + bias[N] for a narrow input (K <= 64) and a wide output (N a multiple of 16, <= 1024):
+ * the input products `x W_ih^T + b_ih` of every step in front of a recurrence (reference seq_layers.py:14-114 through nn.GRU;
+ * observation ++ action -> 3 x hidden); x with a row stride in floats, y dense and 16-byte aligned. */
+int asac_rows_affine_supported(int K, int N);
+int asac_rows_affine_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias, int64_t rows,
+                             int N, float* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core for short windows: the scores / mask / softmax / weighted-sum part of

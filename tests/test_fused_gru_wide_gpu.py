@@ -121,3 +121,17 @@ def test_wide_twin_pass_equals_two_passes(H, B, L):
             assert launches['asac_gru_wide_forward_twin']['calls'] == 1
     got, launches = both(twin, a[:B - 3], b[:B - 3], h0[:B - 3], mask[:B - 3])
     assert 'asac_gru_wide_forward_twin' not in launches and launches['asac_gru_wide_forward']['calls'] == 2
+
+
+@pytest.mark.parametrize('rows,K,N', [(20736, 8, 192), (100, 5, 96), (17, 64, 384), (33, 1, 16)])
+def test_input_products_of_a_narrow_input(rows, K, N):
+    """`asac_rows_affine_forward`: x W_ih^T + b_ih for every step in front of the recurrence, x read through a row stride"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    gen = torch.Generator().manual_seed(rows)
+    big = torch.randn(rows, K + 3, generator=gen)
+    w, b = torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    y = torch.full((rows, N), float('nan'), device='cuda')
+    native.rows_affine_forward(big.cuda()[:, 1:K + 1], w.cuda(), b.cuda(), y)
+    want = big[:, 1:K + 1].double() @ w.double().t() + b.double()
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
