@@ -99,3 +99,63 @@ def rows_linear(linear: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
             and x.numel() // linear.in_features >= MIN_ROWS and x.stride(-1) == 1):
         return _RowsLinearFn.apply(x, linear.weight, linear.bias)
     return linear(x)
+
+
+class _AffineGeluFn(torch.autograd.Function):
+    """gelu(x W^T + b) over the rows of a window batch, narrow input (K <= 64), as one MFMA launch
+    (`asac_rows_affine_gelu_forward`, csrc/rows_proj.hip); backward: `gelu_backward` on the saved pre-activation, the
+    parameter gradients as a product over the rows (`asac_xty`), the input gradient (if anyone needs it) as the library's GEMM"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from asac_amd import native
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        N = weight.shape[0]
+        y = torch.empty(x2.shape[0], N, dtype=x.dtype, device=x.device)
+        pre = torch.empty_like(y)
+        native.rows_affine_gelu_forward(x2, weight.detach().contiguous(), bias.detach().contiguous(), y, pre)
+        ctx.save_for_backward(x2, pre, weight)
+        ctx.params, ctx.lead = (weight, bias), x.shape[:-1]
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from asac_amd import native
+        from algorithm.fused_mlp import direct_enabled, direct_skips
+        x2, pre, weight = ctx.saved_tensors
+        gpre = torch.ops.aten.gelu_backward(gy.reshape(pre.shape).contiguous(), pre, approximate='none')
+        gx = (gpre @ weight.detach()).view(*ctx.lead, weight.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        w_param, b_param = ctx.params
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not direct_skips(w_param, b_param):
+            w_grad, b_grad = w_param.grad, b_param.grad
+            if (direct_enabled() and w_grad is not None and b_grad is not None and w_grad.is_contiguous()
+                    and b_grad.is_contiguous()):
+                queue_param_grads(gpre, x2, w_grad, b_grad)
+            else:
+                gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
+                native.xty(gpre, x2, gw, gb)
+        return gx, gw, gb
+
+
+def rows_resblock(block, x):
+    """`ResBlock.forward` over >= MIN_ROWS rows on the device as one launch per pass, or None: without a residual path
+    (widths differ) from a narrow input — `_AffineGeluFn`; with one at the widths of csrc/rows_proj.hip — the output-block
+    function of the attention layers (`seq_layers._OutResRowsFn`)"""
+    from torch import nn
+    lin = block.linear
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and type(block.act) is nn.GELU
+            and getattr(block.act, 'approximate', 'none') == 'none' and lin.bias is not None and x.dim() >= 2
+            and x.shape[-1] == lin.in_features and x.numel() // lin.in_features >= MIN_ROWS and x.stride(-1) == 1):
+        return None
+    from asac_amd import native
+    if not block.residual:
+        if native.rows_affine_supported(lin.in_features, lin.out_features):
+            return _AffineGeluFn.apply(x, lin.weight, lin.bias)
+        return None
+    if native.rows_proj_supported(lin.in_features):
+        from algorithm.nn_models.layers.seq_layers import _OutResRowsFn
+        return _OutResRowsFn.apply(x, lin.weight, lin.bias, None)
+    return None

@@ -195,13 +195,14 @@ struct AffineArgs {
     int64_t rows;
     int32_t K, N;
     float* y;                                // [rows][N] dense
+    float* pre;                              // GELU form: the pre-activation, saved for the backward
 };
 
 // y = x W^T + b for a NARROW input (K <= 64: observation ++ action in front of a recurrent layer — the input products
 // `x W_ih^T + b_ih` of all steps, reference seq_layers.py:14-114 through nn.GRU) and a wide output (N = 3 H): the library
 // GEMM takes 13-14 us for 20 736 x 8 -> 192; the work is writing 16 MB.  A workgroup owns 16 rows, its waves the output
 // tiles w, w + 4, ...; the x tile (K / 4 scalars a lane) is the B operand of every tile.
-template <int STEPS>      // k-steps of four: K <= 4 STEPS
+template <int STEPS, bool GELU>      // k-steps of four: K <= 4 STEPS;  GELU: y = gelu(x W^T + b), the sum itself to `pre`
 __global__ void __launch_bounds__(kThreads) k_rows_affine(const AffineArgs a) {
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, q = l >> 4, x = l & 15;
     const int64_t row = (int64_t)blockIdx.x * 16 + x;
@@ -240,7 +241,14 @@ __global__ void __launch_bounds__(kThreads) k_rows_affine(const AffineArgs a) {
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) acc = RP_MF(wq[j][s], xv[s], acc);
             acc += bias[j];
-            if (live && nt < NT) st4(a.y + row * a.N + 16 * nt + 4 * q, acc);
+            if (live && nt < NT) {
+                if (GELU) {
+                    st4(a.pre + row * a.N + 16 * nt + 4 * q, acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = gelu_f(acc[r]);
+                }
+                st4(a.y + row * a.N + 16 * nt + 4 * q, acc);
+            }
         }
     }
 }
@@ -327,18 +335,36 @@ int asac_rows_resblock_backward(const float* grad_y, const float* pre, const flo
 
 int asac_rows_affine_supported(int K, int N) { return K >= 1 && K <= 64 && N >= 16 && N <= 1024 && (N & 15) == 0; }
 
+static int affine_launch(const char* what, const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias,
+                         int64_t rows, int N, float* y, float* pre, void* stream) {
+    if (!x || !weight || !bias || !y || rows <= 0 || !asac_rows_affine_supported(K, N) || x_row_stride < K || !aligned16(bias) ||
+        !aligned16(y) || (pre && !aligned16(pre)))
+        return bad_arg(what);
+    AffineArgs a{};
+    a.x = x, a.xs = x_row_stride, a.w = weight, a.b = bias, a.rows = rows, a.K = K, a.N = N, a.y = y, a.pre = pre;
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    hipStream_t s = as_stream(stream);
+    if (pre) {
+        if (K <= 8) ASAC_LAUNCH((k_rows_affine<2, true>), grid, dim3(kThreads), 0, s, a);
+        else if (K <= 16) ASAC_LAUNCH((k_rows_affine<4, true>), grid, dim3(kThreads), 0, s, a);
+        else ASAC_LAUNCH((k_rows_affine<16, true>), grid, dim3(kThreads), 0, s, a);
+    } else {
+        if (K <= 8) ASAC_LAUNCH((k_rows_affine<2, false>), grid, dim3(kThreads), 0, s, a);
+        else if (K <= 16) ASAC_LAUNCH((k_rows_affine<4, false>), grid, dim3(kThreads), 0, s, a);
+        else ASAC_LAUNCH((k_rows_affine<16, false>), grid, dim3(kThreads), 0, s, a);
+    }
+    return finish_launch(what);
+}
+
 int asac_rows_affine_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias, int64_t rows,
                              int N, float* y, void* stream) {
-    if (!x || !weight || !bias || !y || rows <= 0 || !asac_rows_affine_supported(K, N) || x_row_stride < K || !aligned16(bias) ||
-        !aligned16(y))
-        return bad_arg("asac_rows_affine_forward");
-    AffineArgs a{};
-    a.x = x, a.xs = x_row_stride, a.w = weight, a.b = bias, a.rows = rows, a.K = K, a.N = N, a.y = y;
-    const dim3 grid((unsigned)((rows + 15) / 16));
-    if (K <= 8) ASAC_LAUNCH(k_rows_affine<2>, grid, dim3(kThreads), 0, as_stream(stream), a);
-    else if (K <= 16) ASAC_LAUNCH(k_rows_affine<4>, grid, dim3(kThreads), 0, as_stream(stream), a);
-    else ASAC_LAUNCH(k_rows_affine<16>, grid, dim3(kThreads), 0, as_stream(stream), a);
-    return finish_launch("asac_rows_affine_forward");
+    return affine_launch("asac_rows_affine_forward", x, x_row_stride, K, weight, bias, rows, N, y, nullptr, stream);
+}
+
+int asac_rows_affine_gelu_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias,
+                                  int64_t rows, int N, float* y, float* pre, void* stream) {
+    if (!pre) return bad_arg("asac_rows_affine_gelu_forward");
+    return affine_launch("asac_rows_affine_gelu_forward", x, x_row_stride, K, weight, bias, rows, N, y, pre, stream);
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 69
+ABI_VERSION = 70
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -395,6 +395,8 @@ _SIGNATURES = {
     'asac_rows_affine_supported': (C.c_int, [C.c_int, C.c_int]),
     'asac_rows_affine_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                            C.c_void_p]),
+    'asac_rows_affine_gelu_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_gru_wide_supported': (C.c_int, [C.c_int]),
     'asac_gru_wide_forward_twin': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -2002,6 +2004,19 @@ def rows_affine_forward(x, weight, bias, y):
     _last_work = 2.0 * rows * K * N
     _check(load().asac_rows_affine_forward(_p(x), x.stride(0), K, _p(weight), _p(bias), rows, N, _p(y), _stream()),
            'asac_rows_affine_forward')
+
+
+@_profiled
+def rows_affine_gelu_forward(x, weight, bias, y, pre):
+    """y = gelu(x weight^T + bias), pre = x weight^T + bias; as `rows_affine_forward`"""
+    global _last_work
+    rows, K = x.shape
+    N = weight.shape[0]
+    assert x.stride(1) == 1 and x.dtype == torch.float32 and x.is_cuda and y.shape == (rows, N) and pre.shape == (rows, N)
+    _dense_f32(weight, bias, y, pre)
+    _last_work = 2.0 * rows * K * N
+    _check(load().asac_rows_affine_gelu_forward(_p(x), x.stride(0), K, _p(weight), _p(bias), rows, N, _p(y), _p(pre), _stream()),
+           'asac_rows_affine_gelu_forward')
 
 
 @_profiled

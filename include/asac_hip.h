@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 69
+#define ASAC_ABI_VERSION 70
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -946,6 +946,10 @@ int asac_rows_resblock_backward(const float* grad_y, const float* pre, const flo
 int asac_rows_affine_supported(int K, int N);
 int asac_rows_affine_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias, int64_t rows,
                              int N, float* y, void* stream);
+/* ... with the GELU of a `ResBlock` without a residual path (widths differ: the embedding `LinearLayers(n_in, 64, dense_depth 1)`
+ * in front of a sequence encoder, linear_layers.py:24-119): y = gelu(x W^T + b), pre = x W^T + b (dense, saved for the backward). */
+int asac_rows_affine_gelu_forward(const float* x, int64_t x_row_stride, int K, const float* weight, const float* bias,
+                                  int64_t rows, int N, float* y, float* pre, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core for short windows: the scores / mask / softmax / weighted-sum part of

@@ -269,3 +269,33 @@ def test_xty_multi_is_the_single_products():
     np.testing.assert_allclose(jobs[0][2].cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-3)
     with pytest.raises(RuntimeError):
         native.xty_multi([jobs[0], jobs[0]])         # one output twice
+
+
+def test_resblock_over_rows_is_one_launch_per_pass():
+    """`ResBlock.forward` over thousands of rows on the device: Linear + GELU from a narrow input (no residual path: the
+    embedding in front of a sequence encoder) through `asac_rows_affine_gelu_forward`, Linear + GELU + x at 64 channels through
+    `asac_rows_resblock_*` — values and every gradient as the CPU modules"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    import algorithm.nn_models as m
+    torch.manual_seed(0)
+    ref = m.LinearLayers(8, dense_n=64, dense_depth=2)            # ResBlock(8, 64) without, ResBlock(64, 64) with a residual path
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(1)
+    x, g = torch.randn(512, 9, 8, generator=gen), torch.randn(512, 9, 64, generator=gen)
+
+    def run(layer, device):
+        xd = x.clone().to(device).requires_grad_(True)
+        out = layer(xd)
+        (out * g.to(device)).sum().backward()
+        return [t.detach().cpu().numpy() for t in (out, xd.grad, *(p.grad for p in layer.parameters()))]
+
+    want = run(ref, 'cpu')
+    with native.LaunchProfiler() as prof:
+        got = run(dev, 'cuda')
+    seen = prof.summary()
+    for name in ('asac_rows_affine_gelu_forward', 'asac_rows_resblock_forward', 'asac_rows_resblock_backward'):
+        assert seen[name]['calls'] == 1, (name, sorted(seen))
+    for n_, (a, b) in enumerate(zip(got, want)):
+        atol = 3e-5 if n_ < 2 else 2e-7 * x.shape[0] * x.shape[1] * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
+        np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')

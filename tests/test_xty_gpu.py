@@ -64,8 +64,11 @@ def test_rows_linear_is_the_module_with_another_backward():
     o_r, gx_r, gp_r, seen_r = run(ref, False)
     o_d, gx_d, gp_d, seen_d = run(dev, True)
     assert 'asac_xty' not in seen_r and seen_d['asac_xty']['calls'] == 3
-    assert torch.equal(o_r, o_d), 'the forward is the same library product'
-    np.testing.assert_allclose(gx_d.cpu().numpy(), gx_r.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # (the two ResBlocks of the stack run as one launch per pass now — `asac_rows_affine_gelu_forward`, `asac_rows_resblock_*`:
+    # the library's own GELU arithmetic and MFMA order, not the library product bit for bit)
+    assert seen_d['asac_rows_affine_gelu_forward']['calls'] == 1 and seen_d['asac_rows_resblock_forward']['calls'] == 1
+    np.testing.assert_allclose(o_d.cpu().numpy(), o_r.cpu().numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gx_d.cpu().numpy(), gx_r.cpu().numpy(), rtol=1e-4, atol=2e-5)
     for a, b in zip(gp_d, gp_r):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(b.abs().max()))
     # short inputs and inference keep the plain module
