@@ -268,6 +268,12 @@ class SAC_Base(AuxHeadsMixin):
         self._lookahead = int(hip_config.get('lookahead', 0))
         assert self._lookahead in (0, 1), 'hip_config lookahead: 0 (synchronous sampling) or 1 (one batch in flight)'
         self._la_branch = bool(hip_config.get('lookahead_branch', False))   # a graph branch for the draw: measured slower
+        # the target representation's pass over the window beside the online one: a second stream (a branch of the captured
+        # graph) — the passes share nothing but their inputs; for representations without a twin launch (GRU layers have one).
+        # Measured SLOWER (cfg4 3 015 -> 2 461, cfg5 444 -> 434, cfg4_84 900 -> 883 steps/s: a fork / join inside a replayed
+        # graph costs more than the small launches it hides) — off, as `lookahead_branch`
+        self._rep_branch = bool(hip_config.get('rep_branch', False))
+        self._rep_stream = None
         self._la_gather_sidecar = bool(hip_config.get('lookahead_gather_sidecar', True)) and self._use_sidecars
         self._la_gather = None
         self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
@@ -1856,11 +1862,22 @@ class SAC_Base(AuxHeadsMixin):
             tail = lambda x: None if x is None else x[:, b:]  # noqa: E731
             idx, pad, obs, pre, hidden = w.rep_in
             rep_in, pb = (tail(idx), tail(pad), [o[:, b:] for o in obs], tail(pre), tail(hidden)), 0
+        branch = self._rep_branch and not self._rep_twin and w.rep_trainable
         with (self._rep_twin if self._rep_twin else contextlib.nullcontext()), cat_mode():
+            if branch:
+                if self._rep_stream is None:
+                    self._rep_stream = torch.cuda.Stream(device=self.device)
+                main = torch.cuda.current_stream()
+                self._rep_stream.wait_stream(main)
+                with torch.cuda.stream(self._rep_stream), torch.no_grad():
+                    w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
             with torch.no_grad() if one_position else contextlib.nullcontext():
                 bnx_states, next_hidden = self.get_l_states(*rep_in, is_target=False)
-            with torch.no_grad():
-                w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
+            if branch:
+                main.wait_stream(self._rep_stream)
+            else:
+                with torch.no_grad():
+                    w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
         w.nx_target_states = w.bnx_target_states[:, pb:]
         state_base = (bnx_states, pb)
         if one_position:
