@@ -1,5 +1,6 @@
 cd /root/repo
-for c in cfg4 cfg5 cfg4_84; do for v in false true; do
-printf "$c rep_branch=$v "
-ASAC_BENCH_HIP_CONFIG="{\"rep_branch\": $v}" timeout 600 python bench.py --config $c --no-extras --no-cpu-baseline --profile-steps 0 --steps 800 --warmup 60 --run-length 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
-done; done
+timeout 600 python -m pytest tests/test_fused_gru_wide_gpu.py -x -q 2>&1 | grep -E "passed|failed"
+python tools/debug/gruw_probe.py
+ASAC_HIP_LIB=/root/repo/advanced-soft-actor-critic_amd/lib/libasac_hip_old.so python tools/debug/gruw_probe.py
+python tools/debug/gruw_probe.py 256 81 128
+ASAC_HIP_LIB=/root/repo/advanced-soft-actor-critic_amd/lib/libasac_hip_old.so python tools/debug/gruw_probe.py 256 81 128
