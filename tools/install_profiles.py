@@ -29,7 +29,7 @@ for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',
                          'bench.py cfg2 (--steps 100 --warmup 10 --fill 20000, hipgraph replay) under rocprofv3 --pmc (two passes); per-launch averages'),
                         *[(f'{c}_pmc_traffic.json', f'{TAG}_{c}_pmc_traffic',
                            f'bench.py --config {c} (--steps 60 --warmup 10 --fill 20000, hipgraph replay) under rocprofv3 --pmc (two passes); per-launch averages')
-                          for c in ('cfg3', 'cfg4', 'cfg4_84', 'cfg5') if (R / f'{c}_pmc_traffic.json').exists()]):
+                          for c in ('cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84', 'cfg5', 'cfg_attn_h64') if (R / f'{c}_pmc_traffic.json').exists()]):
     d = {k: v for k, v in json.load(open(R / src)).items() if k.startswith('asac::')}
     json.dump(d, open(P / f'{dst}.json', 'w'), indent=1, sort_keys=True)
     lines = [f'# {title}', '# fetch x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md "HBM"); write is raw',

@@ -30,7 +30,7 @@ for c in cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg5_without_prediction cfg_attn_h64; d
   python $R/tools/summarize_rocprof.py $(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1) 220 40 $O/${c}_kernel_stats.json > $O/${c}_kernel_stats_summary.txt
 done
 # HBM traffic of the representation kernels (cfg3 GRU, cfg4 / cfg5 convolution stack and attention): two PMC passes each
-for c in cfg3 cfg4 cfg4_84 cfg5; do
+for c in ${PMC_CFGS:-cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg_attn_h64}; do
   rm -rf /tmp/pmc_r_$c /tmp/pmc_w_$c
   st="--steps 60 --warmup 10"; if [ $c = cfg5 ]; then st="--steps 12 --warmup 4"; fi; if [ $c = cfg4_84 ]; then st="--steps 30 --warmup 6"; fi      # (cfg5: 200 launches a step)
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_r_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline $st --fill $( [ $c = cfg4_84 ] && echo 8000 || echo 20000 ) --profile-steps 0 --run-length 0 > /tmp/r_$c.log 2>&1
