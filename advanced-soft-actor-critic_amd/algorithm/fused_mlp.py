@@ -39,6 +39,10 @@ _direct_only = []
 @contextlib.contextmanager
 def direct_param_grads(only=None):
     global _direct_depth
+    if _direct_depth == 0:
+        # (a backward pass that raised may have left queued products and an armed end-of-backward callback behind)
+        from .fused_rows_linear import reset_queue
+        reset_queue()
     _direct_depth += 1
     _direct_only.append(None if only is None else {id(t) for t in only})
     try:

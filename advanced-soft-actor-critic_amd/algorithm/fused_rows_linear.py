@@ -34,6 +34,13 @@ def flush_param_grads():
         native.xty_multi(jobs, accumulate=True)
 
 
+def reset_queue():
+    """drop what a failed backward pass left behind (called when the learner opens a direct-mode backward)"""
+    global _armed
+    del _pending[:]
+    _armed = False
+
+
 def _end_of_backward():
     global _armed
     _armed = False
