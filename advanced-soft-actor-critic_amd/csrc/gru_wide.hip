@@ -11,7 +11,9 @@
 // scheme of csrc/decoder.hip: lane (q, x) of an accumulator holds units 4 q + r of a 16-unit block for row x, and that float4
 // IS the B operand of the next product's four k-steps).  The recurrent weights live in REGISTERS for the whole loop, read where
 // they lie (a lane's four k are 16 contiguous bytes of a W_hh row; the backward takes W_hh^T): wave w owns the unit blocks
-// w, w + 4, … with their r / z / n rows, so the gate arithmetic of a unit happens in one lane.  Per step: state tiles from LDS
+// w, w + WAVES, … with their r / z / n rows, so the gate arithmetic of a unit happens in one lane (four waves; eight for hidden
+// 128: one unit block a wave, as hidden 64 has — with two blocks a wave the loops below had no registers for their second input
+// set and the deferred stores: forward 331 -> 322 / 291 -> 272 us, backward 351 -> 298 us at 256 x 81).  Per step: state tiles from LDS
 // (double-buffered, one barrier), 3 H / 16 x H / 4 MFMAs over the workgroup, the gates, stores nobody waits on.
 // Padding as csrc/gru.hip: steps before a row's first unpadded one are skipped (state held), the output of a padded step is 0.
 #include "asac_common.h"
@@ -23,7 +25,6 @@ namespace asac {
 namespace gruw {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int kThreads = 256;
 
 #define GW_MF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -71,121 +72,18 @@ __device__ __forceinline__ int lead_of(const uint8_t* pad, int64_t pad_sb, int64
     return 0;
 }
 
-// The round-4 form of the forward loop (one input set copied at the top of the step, the stores in their own step): kept for
-// hidden 128 WITH the saves, where two unit blocks a wave leave no registers for a second input set or for deferred stores
-// (measured 331 us against 427 for the reshaped loop at 256 x 81; every other case is faster reshaped).
-template <int HB>
-__global__ void __launch_bounds__(kThreads) k_gruw_fwd_one_set(const FwdArgs a) {
-    constexpr int H = 16 * HB, NBW = (HB + 3) / 4;
-    __shared__ f32x4 s_h[2][HB][64];
-    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
-    const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
-    const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
-    const bool second = a.twin_B > 0 && (int64_t)blockIdx.x * 16 >= a.twin_B;      // (workgroup-uniform: twin_B % 16 == 0)
-    const float* w_hh = second ? a.w_hh2 : a.w_hh;
-    const float* b_hh = second ? a.b_hh2 : a.b_hh;
-    const int64_t srow = second ? row - a.twin_B : row;      // the row of h0 / pad (shared by the two networks)
-    float* const hraw = second ? nullptr : a.hraw;
-    float* const gates = second ? nullptr : a.gates;
-    f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
-#pragma unroll
-    for (int i = 0; i < NBW; ++i) {
-        const int ub = w + 4 * i;
-        if (ub >= HB) continue;
-#pragma unroll
-        for (int gate = 0; gate < 3; ++gate) {
-#pragma unroll
-            for (int kt = 0; kt < HB; ++kt)
-                wr[i][gate][kt] = *reinterpret_cast<const f32x4*>(w_hh + (int64_t)(gate * H + 16 * ub + x) * H + 16 * kt + 4 * q);
-            bh[i][gate] = *reinterpret_cast<const f32x4*>(b_hh + gate * H + 16 * ub + 4 * q);
-        }
-        h[i] = a.h0 ? *reinterpret_cast<const f32x4*>(a.h0 + srow * a.h0_sb + 16 * ub + 4 * q) : zero4();
-        s_h[0][ub][l] = h[i];
-    }
-    const int lead = lead_of(a.pad, a.pad_sb, srow, a.L);
-    // the step's inputs are requested one step ahead
-    f32x4 gi_n[NBW][3];
-    uint8_t pad_n = 0;
-    auto request = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
-            if (ub >= HB) continue;
-#pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
-                gi_n[i][gate] = *reinterpret_cast<const f32x4*>(a.gi + row * a.gi_sb + t * a.gi_st + gate * H + 16 * ub + 4 * q);
-        }
-        pad_n = a.pad ? a.pad[srow * a.pad_sb + t] : 0;
-    };
-    request(0);
-    __syncthreads();
-    for (int t = 0; t < a.L; ++t) {
-        const int cur = t & 1;
-        f32x4 gi[NBW][3];
-#pragma unroll
-        for (int i = 0; i < NBW; ++i)
-#pragma unroll
-            for (int gate = 0; gate < 3; ++gate) gi[i][gate] = gi_n[i][gate];
-        const bool padded = pad_n != 0, active = t >= lead;
-        if (t + 1 < a.L) request(t + 1);
-        f32x4 hb[HB];
-#pragma unroll
-        for (int kt = 0; kt < HB; ++kt) hb[kt] = s_h[cur][kt][l];
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
-            if (ub >= HB) continue;
-            f32x4 ar = zero4(), az = zero4(), an = zero4();
-#pragma unroll
-            for (int kt = 0; kt < HB; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ar = GW_MF(wr[i][0][kt][r], hb[kt][r], ar);
-                    az = GW_MF(wr[i][1][kt][r], hb[kt][r], az);
-                    an = GW_MF(wr[i][2][kt][r], hb[kt][r], an);
-                }
-            f32x4 rg, zg, ng, hn, hv, ov;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rg[r] = sigmoidf_(gi[i][0][r] + (ar[r] + bh[i][0][r]));
-                zg[r] = sigmoidf_(gi[i][1][r] + (az[r] + bh[i][1][r]));
-                hn[r] = an[r] + bh[i][2][r];
-                ng[r] = tanhf_(gi[i][2][r] + rg[r] * hn[r]);
-                const float hnew = (1.f - zg[r]) * ng[r] + zg[r] * h[i][r];
-                hv[r] = active ? hnew : h[i][r];
-                ov[r] = padded ? 0.f : hv[r];
-            }
-            h[i] = hv;
-            s_h[cur ^ 1][ub][l] = hv;
-            if (live) {
-                const int col = 16 * ub + 4 * q;
-                *reinterpret_cast<f32x4*>(a.out + row * a.out_sb + t * a.out_st + col) = ov;
-                if (hraw) *reinterpret_cast<f32x4*>(hraw + (row * a.L + t) * H + col) = hv;
-                if (gates) {
-                    float* gp = gates + (row * a.L + t) * (4 * H) + col;
-                    *reinterpret_cast<f32x4*>(gp) = rg;
-                    *reinterpret_cast<f32x4*>(gp + H) = zg;
-                    *reinterpret_cast<f32x4*>(gp + 2 * H) = ng;
-                    *reinterpret_cast<f32x4*>(gp + 3 * H) = hn;
-                }
-            }
-        }
-        lds_barrier();
-    }
-}
-
 // The time loop is written so that the compiler can wait for a step's inputs BY COUNT (`s_waitcnt vmcnt(n)`, the later stores
 // still in flight) instead of draining the queue every step (a store round trip a step: 0.4 of 1.65 us with the saves):
 //   * two input register sets, the loop unrolled by two — no register copies that would pin a wait to the loop's back edge;
 //   * the same vector-memory instructions on every path: lanes beyond the batch replicate the last row (same inputs, same
 //     arithmetic) and rewrite its values; with SAVE (h_raw and gates given) the twin's second network, which saves nothing,
 //     stores its output in their place; the request after the last step re-reads it; without a mask the byte comes from w_hh.
-template <int HB, bool SAVE>
-__global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
-    constexpr int H = 16 * HB, NBW = (HB + 3) / 4;
+template <int HB, bool SAVE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_gruw_fwd(const FwdArgs a) {
+    constexpr int H = 16 * HB, NBW = (HB + WAVES - 1) / WAVES;
     __shared__ f32x4 s_h[2][HB][64];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
-    __builtin_assume(w >= 0 && w < 4);
+    __builtin_assume(w >= 0 && w < WAVES);
     const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);
     const bool second = a.twin_B > 0 && (int64_t)blockIdx.x * 16 >= a.twin_B;      // (workgroup-uniform: twin_B % 16 == 0)
     const float* w_hh = second ? a.w_hh2 : a.w_hh;
@@ -194,7 +92,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     f32x4 wr[NBW][3][HB], bh[NBW][3], h[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int ub = w + 4 * i;
+        const int ub = w + WAVES * i;
         if (ub >= HB) continue;
 #pragma unroll
         for (int gate = 0; gate < 3; ++gate) {
@@ -216,7 +114,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     auto request = [&](int t, StepIn& in) {
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
@@ -230,7 +128,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     constexpr int NS = SAVE ? 6 : 1;
     f32x4 late[NBW][NS];        // ov | hv, rg, zg, ng, hn of the step before
     auto store_late = [&](int t, int i, int sidx) {
-        const int col = 16 * (w + 4 * i) + 4 * q;
+        const int col = 16 * (w + WAVES * i) + 4 * q;
         float* const op = a.out + row * a.out_sb + t * a.out_st + col;
         float* dst = op;
         if (sidx == 1) dst = a.hraw + (srow * a.L + t) * H + col;
@@ -245,7 +143,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
         for (int kt = 0; kt < HB; ++kt) hb[kt] = s_h[cur][kt][l];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
             f32x4 ar = zero4(), az = zero4(), an = zero4();
 #pragma unroll
@@ -307,7 +205,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_fwd(const FwdArgs a) {
     // the last step's results
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        if (w + 4 * i >= HB) continue;
+        if (w + WAVES * i >= HB) continue;
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) store_late(a.L - 1, i, sidx);
     }
@@ -327,18 +225,18 @@ struct BwdArgs {
 };
 
 // (the time loop is shaped like k_gruw_fwd's: two input register sets, the same vector-memory instructions on every path)
-template <int HB>
-__global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
-    constexpr int H = 16 * HB, NBW = (HB + 3) / 4, KT = 3 * HB;
+template <int HB, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_gruw_bwd(const BwdArgs a) {
+    constexpr int H = 16 * HB, NBW = (HB + WAVES - 1) / WAVES, KT = 3 * HB;
     __shared__ f32x4 s_g[2][KT][64];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, q = l >> 4, x = l & 15;
-    __builtin_assume(w >= 0 && w < 4);
+    __builtin_assume(w >= 0 && w < WAVES);
     const int64_t row = min((int64_t)blockIdx.x * 16 + x, (int64_t)a.B - 1);      // (lanes beyond the batch replicate the last row)
     const bool live = (int64_t)blockIdx.x * 16 + x < a.B;
     f32x4 wt[NBW][KT], dh[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int ub = w + 4 * i;
+        const int ub = w + WAVES * i;
         dh[i] = zero4();
         if (ub >= HB) continue;
 #pragma unroll
@@ -356,7 +254,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
         in.pad = pad_row[t * pad_step];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
             const int col = 16 * ub + 4 * q;
             in.g[i] = *reinterpret_cast<const f32x4*>(a.gout + row * a.go_sb + t * a.go_st + col);
@@ -376,7 +274,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
         f32x4 direct[NBW], st_v[NBW][4];
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
             const f32x4 g = padded ? zero4() : in.g[i];
             const f32x4 rg = in.rg[i], zg = in.zg[i], ng = in.ng[i], hn = in.hn[i];
@@ -403,7 +301,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
             f32x4 acc0 = zero4(), acc1 = zero4();      // two chains: the products are the whole step
             // the step's six stores go out BETWEEN the products, one per pair of tiles: issued together before the barrier, the
@@ -449,7 +347,7 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
     if (a.dh0 && live) {
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int ub = w + 4 * i;
+            const int ub = w + WAVES * i;
             if (ub >= HB) continue;
             *reinterpret_cast<f32x4*>(a.dh0 + row * H + 16 * ub + 4 * q) = dh[i];
         }
@@ -458,16 +356,17 @@ __global__ void __launch_bounds__(kThreads) k_gruw_bwd(const BwdArgs a) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// hidden 128: eight waves (one unit block each, as hidden 64 has with four) — with four, two unit blocks a wave left no registers
+// for the second input set and the deferred stores
 static void launch_fwd(int hidden, bool save, dim3 grid, hipStream_t s, const FwdArgs& a) {
-    const dim3 block(kThreads);
     if (save) {
-        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, true>), grid, block, 0, s, a);
-        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, true>), grid, block, 0, s, a);
-        else ASAC_LAUNCH(k_gruw_fwd_one_set<8>, grid, block, 0, s, a);
+        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, true, 4>), grid, dim3(256), 0, s, a);
+        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, true, 4>), grid, dim3(256), 0, s, a);
+        else ASAC_LAUNCH((k_gruw_fwd<8, true, 8>), grid, dim3(512), 0, s, a);
     } else {
-        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, false>), grid, block, 0, s, a);
-        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, false>), grid, block, 0, s, a);
-        else ASAC_LAUNCH((k_gruw_fwd<8, false>), grid, block, 0, s, a);
+        if (hidden == 32) ASAC_LAUNCH((k_gruw_fwd<2, false, 4>), grid, dim3(256), 0, s, a);
+        else if (hidden == 64) ASAC_LAUNCH((k_gruw_fwd<4, false, 4>), grid, dim3(256), 0, s, a);
+        else ASAC_LAUNCH((k_gruw_fwd<8, false, 8>), grid, dim3(512), 0, s, a);
     }
 }
 
@@ -535,11 +434,11 @@ int asac_gru_wide_backward(const float* grad_out, int64_t go_stride_b, int64_t g
     a.gout = grad_out, a.go_sb = go_stride_b, a.go_st = go_stride_t, a.w_hh_t = w_hh_t, a.gates = gates, a.hraw = h_raw;
     a.h0 = h0, a.h0_sb = h0_stride_b, a.pad = padding_mask, a.pad_sb = mask_stride_b;
     a.dgi = grad_gi, a.dgh = grad_gh, a.dh0 = grad_h0, a.B = B, a.L = L;
-    const dim3 grid((unsigned)((B + 15) / 16)), block(kThreads);
+    const dim3 grid((unsigned)((B + 15) / 16));
     hipStream_t s = as_stream(stream);
-    if (hidden == 32) ASAC_LAUNCH(k_gruw_bwd<2>, grid, block, 0, s, a);
-    else if (hidden == 64) ASAC_LAUNCH(k_gruw_bwd<4>, grid, block, 0, s, a);
-    else ASAC_LAUNCH(k_gruw_bwd<8>, grid, block, 0, s, a);
+    if (hidden == 32) ASAC_LAUNCH((k_gruw_bwd<2, 4>), grid, dim3(256), 0, s, a);
+    else if (hidden == 64) ASAC_LAUNCH((k_gruw_bwd<4, 4>), grid, dim3(256), 0, s, a);
+    else ASAC_LAUNCH((k_gruw_bwd<8, 8>), grid, dim3(512), 0, s, a);
     return finish_launch("asac_gru_wide_backward");
 }
 
