@@ -184,6 +184,8 @@ FUSED_PROJECTIONS = True      # q / k / v Linear projections inside the attentio
 FUSED_MULTIHEAD = os.environ.get('ASAC_ATTN_MH', '1') != '0'
 # the Linear layers around the multi-head core as one launch each (csrc/rows_proj.hip)   (0: library GEMMs — A/B runs)
 FUSED_ROWS_PROJ = os.environ.get('ASAC_ROWS_PROJ', '1') != '0'
+# ... and, for windows of <= 16 positions, the q / k / v projections inside the core's forward launch   (0: a launch of their own)
+FUSED_QKV_IN_CORE = os.environ.get('ASAC_QKV_IN_CORE', '1') != '0'
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -387,6 +389,61 @@ class _QkvRowsFn(torch.autograd.Function):
         return tuple(out)
 
 
+class _QkvAttnMhFn(torch.autograd.Function):
+    """`_QkvRowsFn` and `_AttnMhFn` as ONE forward launch for windows of <= 16 positions (`asac_attention_mh_proj_forward`:
+    the projections run in front of the scores inside the launch); backward: the core's launch, then the projections' input
+    gradient and parameter-gradient products as in `_QkvRowsFn`"""
+
+    @staticmethod
+    def forward(ctx, x, tail, wq, bq, wk, bk, wv, bv, mask, heads, row_zero=None):
+        from asac_amd import native
+        if x.stride(2) != 1 or (x.stride(0) | x.stride(1) | (x.data_ptr() >> 2)) & 3:
+            x = x.contiguous()
+        B, L, E = x.shape
+        dd = dict(dtype=x.dtype, device=x.device)
+        q, k, v = torch.empty(B, tail, E, **dd), torch.empty(B, L, E, **dd), torch.empty(B, L, E, **dd)
+        out, weights, keep = torch.empty(B, tail, E, **dd), torch.empty(B, tail, L, **dd), torch.empty(B, tail, **dd)
+        keep_rows = torch.empty(B, tail, **dd) if row_zero is not None else keep
+        need = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4, 5, 6, 7))
+        p_heads = torch.empty(B, heads, tail, L, **dd) if need else None
+        native.attention_mh_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
+                                         mask, heads, q, k, v, out, weights, keep, p_heads,
+                                         None if row_zero is None else row_zero.contiguous(),
+                                         keep_rows if row_zero is not None else None)
+        if need:
+            ctx.save_for_backward(x, q, k, v, p_heads, *([mask] if mask is not None else []))
+        ctx.tail, ctx.heads, ctx.has_mask, ctx.params = tail, heads, mask is not None, (wq, bq, wk, bk, wv, bv)
+        ctx.mark_non_differentiable(keep, keep_rows)
+        ctx.set_materialize_grads(False)
+        return out, weights, keep, keep_rows
+
+    @staticmethod
+    def backward(ctx, g_out, g_w, _g_keep, _g_keep_rows=None):
+        from asac_amd import native
+        if g_out is None and g_w is None:
+            return (None,) * 11
+        x, q, k, v, p_heads, *rest = ctx.saved_tensors
+        B, L, E = x.shape
+        if g_out is None:
+            g_out = torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+        g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        native.attention_mh_backward(q, k, v, rest[0] if ctx.has_mask else None, ctx.heads, p_heads, g_out.contiguous(),
+                                     None if g_w is None else g_w.contiguous(), g_q, g_k, g_v)
+        wq, bq, wk, bk, wv, bv = ctx.params
+        grads, tails = [g_q, g_k, g_v], [ctx.tail, L, L]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(B, L, E, dtype=x.dtype, device=x.device)
+            native.rows_proj_backward(grads, tails, [wq.detach(), wk.detach(), wv.detach()], gx)
+        x2 = x.reshape(-1, E)
+        xq2 = x2 if ctx.tail == L else x[:, -ctx.tail:].reshape(-1, E)
+        out = [gx, None]
+        for j, (g, xin) in enumerate(zip(grads, (xq2, x2, x2))):
+            out.extend(_rows_param_grads(ctx.needs_input_grad[2 + 2 * j:4 + 2 * j], ctx.params[2 * j:2 * j + 2],
+                                         g.view(-1, E), xin))
+        return (*out, None, None, None)
+
+
 class _OutResRowsFn(torch.autograd.Function):
     """`(x + gelu(linear(x))) * row_scale[..., None]` — the output ResBlock of an attention layer and its dead-row / padded-row
     factor — as one MFMA launch per pass (`asac_rows_resblock_*`, csrc/rows_proj.hip); the parameter gradients from `asac_xty`"""
@@ -564,9 +621,17 @@ class MultiheadAttention(nn.Module):
                         out = out * (~rz).to(out.dtype).unsqueeze(-1)
                 return out.reshape(*lead, *out.shape[1:]), weights.reshape(*lead, *weights.shape[1:])
 
+        fused_qkv = None
         if (self.pe is None or self.pe is False) and same_kv and _rows_proj_ok(self, query, key):
-            q, k, v = _QkvRowsFn.apply(key, q_len, *(t for ll in (self.q_proj, self.k_proj, self.v_proj)
-                                                     for t in (_plain_linear(ll).weight, _plain_linear(ll).bias)))
+            qkv_params = [t for ll in (self.q_proj, self.k_proj, self.v_proj) for t in (_plain_linear(ll).weight, _plain_linear(ll).bias)]
+            from asac_amd import native
+            if (FUSED_MULTIHEAD and FUSED_QKV_IN_CORE and (self.num_heads > 1 or self.head_dim > 16)
+                    and not (self.training and self.dropout > 0.)
+                    and native.attention_mh_proj_supported(q_len, k_len, self.num_heads, self.head_dim)):
+                fused_qkv = qkv_params      # windows of <= 16 positions: the projections run inside the core's forward launch
+                q = k = v = key
+            else:
+                q, k, v = _QkvRowsFn.apply(key, q_len, *qkv_params)
         else:
             q, k, v = self.q_proj(query), self.k_proj(key), self.v_proj(value)
         if self.pe in (POSITIONAL_ENCODING.ROPE, POSITIONAL_ENCODING.ROPE2):
@@ -589,7 +654,10 @@ class MultiheadAttention(nn.Module):
                 if rz is not None:
                     rz = rz.reshape(-1, rz.shape[-1])
                     rz = rz if rz.dtype in (torch.bool, torch.uint8) else rz != 0
-                out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
+                if fused_qkv is not None:
+                    out, weights, keep, keep_rows = _QkvAttnMhFn.apply(key, q_len, *fused_qkv, m, self.num_heads, rz)
+                else:
+                    out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
                 scale = keep_rows if rz is not None else (keep if m is not None else None)
                 lo = _plain_resblock(self.out_proj, self.embed_dim) if FUSED_ROWS_PROJ else None
                 if lo is not None and native.rows_proj_supported(self.embed_dim):

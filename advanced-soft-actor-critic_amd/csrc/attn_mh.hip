@@ -64,6 +64,9 @@ struct Args {
     const float* g_out;    // [B][Lq][E]
     const float* g_w;      // [B][Lq][Lk] or NULL
     float* g_q; float* g_k; float* g_v;
+    // forward with the projections inside (PEC > 0): q / k / v above are then OUTPUTS (saved for the backward)
+    const float* x; int64_t xs_b, xs_t;       // the block's input rows [B][Lk][E]; the queries are its last Lq positions
+    const float* pw[3]; const float* pb[3];   // q / k / v projection weights [E][E] and biases [E]
 };
 
 // 16 bytes of channels [c0, c0 + 4) of a row, zero beyond d (and for rows beyond the window)
@@ -76,7 +79,10 @@ __device__ __forceinline__ f32x4 row4(const float* base, bool live, int c0, int 
     return v;
 }
 
-template <bool BWD, int NT>
+// PEC > 0 (forward, one tile a side, E = 16 PEC): the q / k / v projections of the block's input run in front of the scores — the
+// input tile is the B operand of 3 E / 16 weight tiles dealt over the waves (the arithmetic of csrc/rows_proj.hip), the results
+// go to LDS for this launch and to q / k / v for the backward: one launch less per block pass (10 of ~25 us).
+template <bool BWD, int NT, int PEC = 0>
 __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     // per wave: P and dS tiles turned for the products over the queries; rows of 16 at a pitch of kTP = 20 floats: the four
     // lane quarters of a store then fall into four different 16-bank groups, rows stay 16-byte aligned for the b128 reads
@@ -86,9 +92,43 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     const int Lq = a.Lq, Lk = a.Lk, H = a.H, d = a.d, E = H * d;
     const int QT = (Lq + 15) >> 4, KT = (Lk + 15) >> 4, CT = (d + 15) >> 4;
     const float scale = 1.f / sqrtf((float)d);
+    constexpr int kPP = 16 * (PEC > 0 ? PEC : 1) + 4;      // LDS row pitch of the projected rows (conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) float s_qkv[PEC > 0 ? 3 : 1][PEC > 0 ? 16 : 1][PEC > 0 ? kPP : 4];
     const float* qb = a.q + (int64_t)b * Lq * E;
     const float* kb = a.k + (int64_t)b * Lk * E;
     const float* vb = a.v + (int64_t)b * Lk * E;
+    int RP = E;                                             // row pitch of q / k / v as the products below read them
+    if constexpr (PEC > 0) {
+        constexpr int EE = 16 * PEC;
+        const bool live = x < Lk;
+        const float* xp = a.x + (int64_t)b * a.xs_b + (int64_t)min(x, Lk - 1) * a.xs_t + 4 * qq;
+        f32x4 xv[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; ++c) xv[c] = live ? *reinterpret_cast<const f32x4*>(xp + 16 * c) : zero4();
+        const int skip = Lk - Lq;
+        for (int item = wv; item < 3 * PEC; item += kWaves) {
+            const int j = item / PEC, nt = item - j * PEC;
+            const float* wj = j == 0 ? a.pw[0] : (j == 1 ? a.pw[1] : a.pw[2]);
+            const float* bj = j == 0 ? a.pb[0] : (j == 1 ? a.pb[1] : a.pb[2]);
+            const float* wp = wj + (16 * nt + x) * EE + 4 * qq;
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int c = 0; c < PEC; ++c) acc = mfma4(*reinterpret_cast<const f32x4*>(wp + 16 * c), xv[c], acc);
+            acc += *reinterpret_cast<const f32x4*>(bj + 16 * nt + 4 * qq);      // acc[r] = y_j[row x][16 nt + 4 qq + r]
+            *reinterpret_cast<f32x4*>(&s_qkv[j][x][16 * nt + 4 * qq]) = acc;
+            if (live) {
+                if (j == 0) {
+                    if (x >= skip) *reinterpret_cast<f32x4*>(const_cast<float*>(qb) + (int64_t)(x - skip) * EE + 16 * nt + 4 * qq) = acc;
+                } else {
+                    float* dst = const_cast<float*>(j == 1 ? kb : vb);
+                    *reinterpret_cast<f32x4*>(dst + (int64_t)x * EE + 16 * nt + 4 * qq) = acc;
+                }
+            }
+        }
+        __syncthreads();
+        qb = &s_qkv[0][skip][0], kb = &s_qkv[1][0][0], vb = &s_qkv[2][0][0];
+        RP = kPP;
+    }
     // mask of this entry: lane (qq, x) of tile (km, qn) holds keys 16 km + 4 qq + r of query 16 qn + x
     bool blocked[NT][NT][4];
     bool dead[NT];
@@ -132,8 +172,8 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int kj = 16 * t + x, qi = 16 * t + x;
-                    ka[t] = row4(kb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
-                    qv[t] = row4(qb + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d) * scale;
+                    ka[t] = row4(kb + (int64_t)min(kj, Lk - 1) * RP + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
+                    qv[t] = row4(qb + (int64_t)min(qi, Lq - 1) * RP + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d) * scale;
                 }
 #pragma unroll
                 for (int km = 0; km < NT; ++km)
@@ -191,7 +231,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int kj = 16 * km + 4 * qq + r;
-                        va[km][r] = (c < d && kj < Lk) ? vb[(int64_t)kj * E + hc + c] : 0.f;
+                        va[km][r] = (c < d && kj < Lk) ? vb[(int64_t)kj * RP + hc + c] : 0.f;
                     }
 #pragma unroll
                 for (int qn = 0; qn < NT; ++qn) {
@@ -410,6 +450,40 @@ int asac_attention_mh_forward(const float* q, const float* k, const float* v, co
     a.row_zero = row_zero, a.keep_rows = keep_rows;
     launch<false>(a, as_stream(stream));
     return finish_launch("asac_attention_mh_forward");
+}
+
+int asac_attention_mh_proj_supported(int Lq, int Lk, int heads, int head_dim) {
+    const int E = heads * head_dim;
+    return asac_attention_mh_supported(Lq, Lk, heads, head_dim) && Lk <= 16 && Lq <= Lk && (E == 32 || E == 64 || E == 128) &&
+           head_dim % 4 == 0;
+}
+
+int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x_stride_t, const float* const* weights,
+                                   const float* const* biases, const uint8_t* mask, int64_t mask_stride_b,
+                                   int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                                   float* q, float* k, float* v, float* out, float* attn_weights, float* keep, float* p_heads,
+                                   const uint8_t* row_zero, float* keep_rows, void* stream) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!x || !weights || !biases || !q || !k || !v || !out || !attn_weights || !keep || B <= 0 ||
+        !asac_attention_mh_proj_supported(Lq, Lk, heads, head_dim) || !al(x) || (x_stride_b & 3) || (x_stride_t & 3) || !al(q) ||
+        !al(k) || !al(v))
+        return bad_arg("asac_attention_mh_proj_forward");
+    Args a{};
+    a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
+    a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = attn_weights, a.keep = keep, a.p_heads = p_heads;
+    a.row_zero = row_zero, a.keep_rows = keep_rows;
+    a.x = x, a.xs_b = x_stride_b, a.xs_t = x_stride_t;
+    for (int j = 0; j < 3; ++j) {
+        if (!weights[j] || !biases[j] || !al(weights[j]) || !al(biases[j])) return bad_arg("asac_attention_mh_proj_forward: job");
+        a.pw[j] = weights[j], a.pb[j] = biases[j];
+    }
+    const dim3 grid((unsigned)B);
+    const int E = heads * head_dim;
+    hipStream_t s = as_stream(stream);
+    if (E == 32) ASAC_LAUNCH((k_attn_mh<false, 1, 2>), grid, dim3(kThreads), 0, s, a);
+    else if (E == 64) ASAC_LAUNCH((k_attn_mh<false, 1, 4>), grid, dim3(kThreads), 0, s, a);
+    else ASAC_LAUNCH((k_attn_mh<false, 1, 8>), grid, dim3(kThreads), 0, s, a);
+    return finish_launch("asac_attention_mh_proj_forward");
 }
 
 int asac_attention_mh_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 70
+#define ASAC_ABI_VERSION 71
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -913,6 +913,19 @@ int asac_attention_mh_backward(const float* q, const float* k, const float* v, c
                                int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
                                const float* p_heads, const float* grad_out, const float* grad_weights, float* grad_q,
                                float* grad_k, float* grad_v, void* stream);
+
+/* asac_attention_mh_forward with the q / k / v projections of the block's input in front of the scores, in the same launch
+ * (`self.q_proj(query), self.k_proj(key), self.v_proj(value)` with value = key and query = the last Lq positions of key,
+ * seq_layers.py:239-333): x [B][Lk][E] with strides in floats (multiples of 4, 16-byte aligned), weights / biases = HOST arrays
+ * of the three [E][E] / [E] device pointers (q, k, v order); q [B][Lq][E], k / v [B][Lk][E] are OUTPUTS (dense; what the
+ * backward reads).  Windows Lq <= Lk <= 16, E = heads * head_dim in {32, 64, 128}, head_dim a multiple of 4.  The backward is
+ * asac_attention_mh_backward followed by asac_rows_proj_backward. */
+int asac_attention_mh_proj_supported(int Lq, int Lk, int heads, int head_dim);
+int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x_stride_t, const float* const* weights,
+                                   const float* const* biases, const uint8_t* mask, int64_t mask_stride_b,
+                                   int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                                   float* q, float* k, float* v, float* out, float* attn_weights, float* keep, float* p_heads,
+                                   const uint8_t* row_zero, float* keep_rows, void* stream);
 
 /* The Linear layers around that core over the rows of a batch of windows, one launch each (csrc/rows_proj.hip) — replaces, in
  * `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333): `self.q_proj(query), self.k_proj(key),

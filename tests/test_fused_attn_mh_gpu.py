@@ -236,8 +236,9 @@ def test_projections_and_output_block_around_the_core_are_one_launch_each(tail):
     with native.LaunchProfiler() as prof:
         got = run(dev, 'cuda')
     seen = prof.summary()
-    for name in ('asac_rows_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_forward', 'asac_rows_resblock_backward',
-                 'asac_attention_mh_forward', 'asac_attention_mh_backward'):
+    # (windows of <= 16 positions: the projections run inside the core's forward launch, `asac_attention_mh_proj_forward`)
+    for name in ('asac_attention_mh_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_forward',
+                 'asac_rows_resblock_backward', 'asac_attention_mh_backward'):
         assert seen[name]['calls'] == 1, (name, seen.keys())
     for n_, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a).all()
@@ -299,3 +300,50 @@ def test_resblock_over_rows_is_one_launch_per_pass():
     for n_, (a, b) in enumerate(zip(got, want)):
         atol = 3e-5 if n_ < 2 else 2e-7 * x.shape[0] * x.shape[1] * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
         np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')
+
+
+@pytest.mark.parametrize('B,L,tail,E,H', [(300, 9, 9, 64, 8), (300, 10, 3, 64, 8), (64, 16, 16, 128, 4), (33, 5, 1, 32, 2)])
+def test_projections_inside_the_core_forward(B, L, tail, E, H):
+    """windows of <= 16 positions: q / k / v are projected INSIDE the attention core's forward launch
+    (`asac_attention_mh_proj_forward`) — outputs, weights and every gradient as the CPU module; and bit for bit what the
+    two-launch form (`ASAC_QKV_IN_CORE=0`) gives, since the arithmetic is the same"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    import algorithm.nn_models as m
+    from algorithm.nn_models.layers import seq_layers
+    torch.manual_seed(0)
+    ref = m.MultiheadAttention(E, H, out_dense_depth=1)
+    dev = copy.deepcopy(ref).cuda()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(B, L, E, generator=gen)
+    mask, kpm = _mask('batch', B, tail, L, gen)
+    rowm = torch.rand(B, tail, generator=gen) < 0.2
+    g_out, g_w = torch.randn(B, tail, E, generator=gen), torch.randn(B, tail, L, generator=gen) * 0.2
+
+    def run(layer, device):
+        for p_ in layer.parameters():
+            p_.grad = None
+        xd = x.clone().to(device).requires_grad_(True)
+        key = xd * 1.0
+        out, w = layer(key[:, -tail:] if tail != L else key, key, key, key_padding_mask=kpm.to(device), attn_mask=mask.to(device),
+                       out_row_mask=rowm.to(device))
+        ((out * g_out.to(device)).sum() + (w * g_w.to(device)).sum()).backward()
+        return [t.detach().cpu().numpy() for t in (out, w, xd.grad, *(p.grad for p in layer.parameters()))]
+
+    want = run(ref, 'cpu')
+    with native.LaunchProfiler() as prof:
+        got = run(dev, 'cuda')
+    seen = prof.summary()
+    assert seen['asac_attention_mh_proj_forward']['calls'] == 1 and 'asac_rows_proj_forward' not in seen and 'asac_attention_mh_forward' not in seen
+    assert seen['asac_rows_proj_backward']['calls'] == 1 and seen['asac_attention_mh_backward']['calls'] == 1
+    for n_, (a, b) in enumerate(zip(got, want)):
+        assert np.isfinite(a).all()
+        atol = 3e-5 if n_ < 3 else 2e-7 * B * L * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
+        np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')
+    seq_layers.FUSED_QKV_IN_CORE = False
+    try:
+        two = run(dev, 'cuda')
+    finally:
+        seq_layers.FUSED_QKV_IN_CORE = True
+    for a, b in zip(got, two):
+        assert np.array_equal(a, b)
