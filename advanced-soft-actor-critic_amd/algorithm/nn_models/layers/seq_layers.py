@@ -395,7 +395,10 @@ class _QkvAttnMhFn(torch.autograd.Function):
     gradient and parameter-gradient products as in `_QkvRowsFn`"""
 
     @staticmethod
-    def forward(ctx, x, tail, wq, bq, wk, bk, wv, bv, mask, heads, row_zero=None):
+    def forward(ctx, x, tail, wq, bq, wk, bk, wv, bv, mask, heads, row_zero=None, out_block=None):
+        """`out_block` = (weight, bias) of the output ResBlock: it runs behind the core in the same launch and two more tensors
+        come back (y, pre) — non-differentiable HERE: `_OutResSavedFn` turns them into the block's output and carries its
+        backward"""
         from asac_amd import native
         if x.stride(2) != 1 or (x.stride(0) | x.stride(1) | (x.data_ptr() >> 2)) & 3:
             x = x.contiguous()
@@ -406,22 +409,30 @@ class _QkvAttnMhFn(torch.autograd.Function):
         keep_rows = torch.empty(B, tail, **dd) if row_zero is not None else keep
         need = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4, 5, 6, 7))
         p_heads = torch.empty(B, heads, tail, L, **dd) if need else None
+        y = pre = None
+        if out_block is not None:
+            y, pre = torch.empty(B, tail, E, **dd), torch.empty(B, tail, E, **dd)
         native.attention_mh_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
                                          mask, heads, q, k, v, out, weights, keep, p_heads,
                                          None if row_zero is None else row_zero.contiguous(),
-                                         keep_rows if row_zero is not None else None)
+                                         keep_rows if row_zero is not None else None,
+                                         *(() if out_block is None else (out_block[0].detach().contiguous(),
+                                                                         out_block[1].detach().contiguous(), y, pre)))
         if need:
             ctx.save_for_backward(x, q, k, v, p_heads, *([mask] if mask is not None else []))
         ctx.tail, ctx.heads, ctx.has_mask, ctx.params = tail, heads, mask is not None, (wq, bq, wk, bk, wv, bv)
-        ctx.mark_non_differentiable(keep, keep_rows)
         ctx.set_materialize_grads(False)
-        return out, weights, keep, keep_rows
+        if out_block is None:
+            ctx.mark_non_differentiable(keep, keep_rows)
+            return out, weights, keep, keep_rows
+        ctx.mark_non_differentiable(keep, keep_rows, y, pre)
+        return out, weights, keep, keep_rows, y, pre
 
     @staticmethod
-    def backward(ctx, g_out, g_w, _g_keep, _g_keep_rows=None):
+    def backward(ctx, g_out, g_w, _g_keep, _g_keep_rows=None, _g_y=None, _g_pre=None):
         from asac_amd import native
         if g_out is None and g_w is None:
-            return (None,) * 11
+            return (None,) * 12
         x, q, k, v, p_heads, *rest = ctx.saved_tensors
         B, L, E = x.shape
         if g_out is None:
@@ -441,7 +452,7 @@ class _QkvAttnMhFn(torch.autograd.Function):
         for j, (g, xin) in enumerate(zip(grads, (xq2, x2, x2))):
             out.extend(_rows_param_grads(ctx.needs_input_grad[2 + 2 * j:4 + 2 * j], ctx.params[2 * j:2 * j + 2],
                                          g.view(-1, E), xin))
-        return (*out, None, None, None)
+        return (*out, None, None, None, None)
 
 
 class _OutResRowsFn(torch.autograd.Function):
@@ -471,6 +482,25 @@ class _OutResRowsFn(torch.autograd.Function):
         native.rows_resblock_backward(gy2, pre, weight.detach(), rest[0] if rest else None, gx, gpre)
         gw, gb = _rows_param_grads(ctx.needs_input_grad[1:3], ctx.params, gpre, x2)
         return gx.view(ctx.lead), gw, gb, None
+
+
+class _OutResSavedFn(torch.autograd.Function):
+    """`_OutResRowsFn` whose forward already ran (inside `asac_attention_mh_proj_forward`): y and pre are handed in, the
+    backward is the same"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, row_scale, y_pre):
+        y, pre = y_pre          # (a tuple, not tensor arguments: the result must not be a view of an input)
+        x2 = x.reshape(-1, x.shape[-1])
+        sc = None if row_scale is None else row_scale.reshape(-1)
+        ctx.save_for_backward(x2, pre.view(x2.shape), *([sc] if sc is not None else []))
+        ctx.params, ctx.lead = (weight, bias), x.shape
+        return y.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx, gw, gb, _ = _OutResRowsFn.backward(ctx, gy)
+        return gx, gw, gb, None, None
 
 
 def _rows_proj_ok(module, query, key) -> bool:
@@ -654,13 +684,20 @@ class MultiheadAttention(nn.Module):
                 if rz is not None:
                     rz = rz.reshape(-1, rz.shape[-1])
                     rz = rz if rz.dtype in (torch.bool, torch.uint8) else rz != 0
-                if fused_qkv is not None:
+                lo = _plain_resblock(self.out_proj, self.embed_dim) if FUSED_ROWS_PROJ else None
+                y_pre = None
+                if fused_qkv is not None and lo is not None:
+                    # ... and the output ResBlock behind it: the block's forward is ONE launch
+                    out, weights, keep, keep_rows, *y_pre = _QkvAttnMhFn.apply(key, q_len, *fused_qkv, m, self.num_heads, rz,
+                                                                               (lo.weight, lo.bias))
+                elif fused_qkv is not None:
                     out, weights, keep, keep_rows = _QkvAttnMhFn.apply(key, q_len, *fused_qkv, m, self.num_heads, rz)
                 else:
                     out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
                 scale = keep_rows if rz is not None else (keep if m is not None else None)
-                lo = _plain_resblock(self.out_proj, self.embed_dim) if FUSED_ROWS_PROJ else None
-                if lo is not None and native.rows_proj_supported(self.embed_dim):
+                if y_pre:
+                    out = _OutResSavedFn.apply(out, lo.weight, lo.bias, scale, tuple(y_pre))
+                elif lo is not None and native.rows_proj_supported(self.embed_dim):
                     # the output ResBlock and the dead-row / padded-row factor: one launch
                     out = _OutResRowsFn.apply(out, lo.weight, lo.bias, scale)
                 else:

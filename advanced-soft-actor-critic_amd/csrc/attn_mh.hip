@@ -14,6 +14,7 @@
 // (dV = P dO, dK = dS Q) with P / dS turned through LDS.  "Dead" rows (every key blocked) attend unmasked and report
 // keep = 0, as csrc/attn.hip and the reference do.
 #include "asac_common.h"
+#include "asac_gelu.h"
 
 #include <cmath>
 
@@ -67,6 +68,9 @@ struct Args {
     // forward with the projections inside (PEC > 0): q / k / v above are then OUTPUTS (saved for the backward)
     const float* x; int64_t xs_b, xs_t;       // the block's input rows [B][Lk][E]; the queries are its last Lq positions
     const float* pw[3]; const float* pb[3];   // q / k / v projection weights [E][E] and biases [E]
+    // ... and the output ResBlock behind the core (ow non-NULL): y = (o + gelu(o ow^T + ob)) * keep_rows, pre = o ow^T + ob
+    const float* ow; const float* ob;
+    float* y; float* pre;                     // [B][Lq][E]
 };
 
 // 16 bytes of channels [c0, c0 + 4) of a row, zero beyond d (and for rows beyond the window)
@@ -94,6 +98,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     const float scale = 1.f / sqrtf((float)d);
     constexpr int kPP = 16 * (PEC > 0 ? PEC : 1) + 4;      // LDS row pitch of the projected rows (conflict-free 16-byte reads)
     __shared__ __attribute__((aligned(16))) float s_qkv[PEC > 0 ? 3 : 1][PEC > 0 ? 16 : 1][PEC > 0 ? kPP : 4];
+    __shared__ __attribute__((aligned(16))) float s_o[PEC > 0 ? 16 : 1][PEC > 0 ? kPP : 4];      // the core's output rows (for the ResBlock)
     const float* qb = a.q + (int64_t)b * Lq * E;
     const float* kb = a.k + (int64_t)b * Lk * E;
     const float* vb = a.v + (int64_t)b * Lk * E;
@@ -243,6 +248,9 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                     const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
                     if (qi < Lq) {
                         float* dst = a.out + ((int64_t)b * Lq + qi) * E + hc + c0;
+                        if constexpr (PEC > 0) {
+                            if (a.ow && c0 < d) *reinterpret_cast<f32x4*>(&s_o[qi][hc + c0]) = o;      // (head_dim % 4 == 0 here)
+                        }
                         if (c0 + 3 < d) *reinterpret_cast<f32x4*>(dst) = o;
                         else
 #pragma unroll
@@ -390,6 +398,34 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
             for (int qn = 0; qn < NT; ++qn) ws[(wv * NT * NT + km * NT + qn) * 64 + l] = wsum[km][qn];
         __syncthreads();
+        if constexpr (PEC > 0) {
+            if (a.ow) {
+                // the output ResBlock over the entry's <= 16 query rows (the arithmetic of csrc/rows_proj.hip's k_rows_res_fwd)
+                constexpr int EE = 16 * PEC;
+                const bool live = x < Lq;
+                f32x4 ov[PEC];
+#pragma unroll
+                for (int c = 0; c < PEC; ++c) ov[c] = live ? *reinterpret_cast<const f32x4*>(&s_o[x][16 * c + 4 * qq]) : zero4();
+                float sc = dead[0] ? 0.f : 1.f;
+                if (a.row_zero && live && a.row_zero[(int64_t)b * Lq + x]) sc = 0.f;
+                for (int nt = wv; nt < PEC; nt += kWaves) {
+                    const float* wp = a.ow + (16 * nt + x) * EE + 4 * qq;
+                    f32x4 acc = zero4();
+#pragma unroll
+                    for (int c = 0; c < PEC; ++c) acc = mfma4(*reinterpret_cast<const f32x4*>(wp + 16 * c), ov[c], acc);
+                    acc += *reinterpret_cast<const f32x4*>(a.ob + 16 * nt + 4 * qq);
+                    if (live) {
+                        const f32x4 res = *reinterpret_cast<const f32x4*>(&s_o[x][16 * nt + 4 * qq]);
+                        f32x4 yv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) yv[r] = (gelu_f(acc[r]) + res[r]) * sc;
+                        const int64_t at = ((int64_t)b * Lq + x) * EE + 16 * nt + 4 * qq;
+                        *reinterpret_cast<f32x4*>(a.y + at) = yv;
+                        *reinterpret_cast<f32x4*>(a.pre + at) = acc;
+                    }
+                }
+            }
+        }
         if (wv != 0) return;
         const float invH = 1.f / (float)H;
 #pragma unroll
@@ -462,17 +498,19 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
                                    const float* const* biases, const uint8_t* mask, int64_t mask_stride_b,
                                    int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
                                    float* q, float* k, float* v, float* out, float* attn_weights, float* keep, float* p_heads,
-                                   const uint8_t* row_zero, float* keep_rows, void* stream) {
+                                   const uint8_t* row_zero, float* keep_rows, const float* out_weight, const float* out_bias,
+                                   float* y, float* pre, void* stream) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!x || !weights || !biases || !q || !k || !v || !out || !attn_weights || !keep || B <= 0 ||
         !asac_attention_mh_proj_supported(Lq, Lk, heads, head_dim) || !al(x) || (x_stride_b & 3) || (x_stride_t & 3) || !al(q) ||
-        !al(k) || !al(v))
+        !al(k) || !al(v) || (out_weight && (!out_bias || !y || !pre || !al(out_weight) || !al(out_bias) || !al(y) || !al(pre))))
         return bad_arg("asac_attention_mh_proj_forward");
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = attn_weights, a.keep = keep, a.p_heads = p_heads;
     a.row_zero = row_zero, a.keep_rows = keep_rows;
     a.x = x, a.xs_b = x_stride_b, a.xs_t = x_stride_t;
+    a.ow = out_weight, a.ob = out_bias, a.y = y, a.pre = pre;
     for (int j = 0; j < 3; ++j) {
         if (!weights[j] || !biases[j] || !al(weights[j]) || !al(biases[j])) return bad_arg("asac_attention_mh_proj_forward: job");
         a.pw[j] = weights[j], a.pb[j] = biases[j];

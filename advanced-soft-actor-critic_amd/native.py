@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 71
+ABI_VERSION = 72
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -1947,7 +1947,7 @@ def attention_mh_proj_supported(Lq, Lk, heads, head_dim) -> bool:
 
 @_profiled
 def attention_mh_proj_forward(x, weights, biases, mask, heads, q, k, v, out, attn_weights, keep, p_heads, row_zero=None,
-                              keep_rows=None):
+                              keep_rows=None, out_weight=None, out_bias=None, y=None, pre=None):
     """`attention_mh_forward` of q / k / v = the three projections of x [B, Lk, E] (q: its last Lq positions), formed in the
     same launch and written to q / k / v for the backward"""
     global _last_work
@@ -1955,13 +1955,16 @@ def attention_mh_proj_forward(x, weights, biases, mask, heads, q, k, v, out, att
     Lq = q.shape[1]
     assert x.stride(2) == 1 and len(weights) == len(biases) == 3
     _last_work = 4.0 * B * Lq * Lk * E + 2.0 * B * (Lq + 2 * Lk) * E * E
-    _dense_f32(*weights, *biases, q, k, v, out, attn_weights, keep, p_heads)
+    _dense_f32(*weights, *biases, q, k, v, out, attn_weights, keep, p_heads, out_weight, out_bias, y, pre)
+    if out_weight is not None:
+        _last_work += 2.0 * B * Lq * E * E
     pm, sb, si, sj = _mask3(mask, B)
     if row_zero is not None:
         assert row_zero.shape == (B, Lq) and row_zero.is_contiguous() and row_zero.element_size() == 1 and keep_rows is not None
     _check(load().asac_attention_mh_proj_forward(_p(x), x.stride(0), x.stride(1), _ptr_array(weights), _ptr_array(biases), pm, sb,
                                                  si, sj, B, Lq, Lk, heads, E // heads, _p(q), _p(k), _p(v), _p(out),
-                                                 _p(attn_weights), _p(keep), _p(p_heads), _p(row_zero), _p(keep_rows), _stream()),
+                                                 _p(attn_weights), _p(keep), _p(p_heads), _p(row_zero), _p(keep_rows),
+                                                 _p(out_weight), _p(out_bias), _p(y), _p(pre), _stream()),
            'asac_attention_mh_proj_forward')
 
 

@@ -237,9 +237,9 @@ def test_projections_and_output_block_around_the_core_are_one_launch_each(tail):
         got = run(dev, 'cuda')
     seen = prof.summary()
     # (windows of <= 16 positions: the projections run inside the core's forward launch, `asac_attention_mh_proj_forward`)
-    for name in ('asac_attention_mh_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_forward',
-                 'asac_rows_resblock_backward', 'asac_attention_mh_backward'):
+    for name in ('asac_attention_mh_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_backward', 'asac_attention_mh_backward'):
         assert seen[name]['calls'] == 1, (name, seen.keys())
+    assert 'asac_rows_resblock_forward' not in seen and 'asac_rows_proj_forward' not in seen      # (the block's forward is one launch)
     for n_, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a).all()
         atol = 3e-5 if n_ < 3 else 2e-7 * B * L * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
@@ -335,6 +335,7 @@ def test_projections_inside_the_core_forward(B, L, tail, E, H):
         got = run(dev, 'cuda')
     seen = prof.summary()
     assert seen['asac_attention_mh_proj_forward']['calls'] == 1 and 'asac_rows_proj_forward' not in seen and 'asac_attention_mh_forward' not in seen
+    assert 'asac_rows_resblock_forward' not in seen and seen['asac_rows_resblock_backward']['calls'] == 1
     assert seen['asac_rows_proj_backward']['calls'] == 1 and seen['asac_attention_mh_backward']['calls'] == 1
     for n_, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a).all()
