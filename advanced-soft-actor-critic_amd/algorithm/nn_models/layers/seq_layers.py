@@ -186,6 +186,8 @@ FUSED_MULTIHEAD = os.environ.get('ASAC_ATTN_MH', '1') != '0'
 FUSED_ROWS_PROJ = os.environ.get('ASAC_ROWS_PROJ', '1') != '0'
 # ... and, for windows of <= 16 positions, the q / k / v projections inside the core's forward launch   (0: a launch of their own)
 FUSED_QKV_IN_CORE = os.environ.get('ASAC_QKV_IN_CORE', '1') != '0'
+# ... and the block's backward as one launch too   (0: ResBlock backward, core backward, projections' backward)
+FUSED_BLOCK_BACKWARD = os.environ.get('ASAC_ATTN_BLOCK_BWD', '1') != '0'
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -455,6 +457,66 @@ class _QkvAttnMhFn(torch.autograd.Function):
         return (*out, None, None, None, None)
 
 
+class _AttnBlockFn(torch.autograd.Function):
+    """The whole attention block for windows of <= 16 positions — q / k / v projections, core, output ResBlock with the
+    dead-row / padded-row factor — as ONE launch forward (`asac_attention_mh_proj_forward`) and ONE backward
+    (`asac_attention_mh_block_backward`), plus the four parameter-gradient products (`asac_xty`, queued)"""
+
+    @staticmethod
+    def forward(ctx, x, tail, wq, bq, wk, bk, wv, bv, wo, bo, mask, heads, row_zero, scaled):
+        from asac_amd import native
+        if x.stride(2) != 1 or (x.stride(0) | x.stride(1) | (x.data_ptr() >> 2)) & 3:
+            x = x.contiguous()
+        B, L, E = x.shape
+        dd = dict(dtype=x.dtype, device=x.device)
+        q, k, v = torch.empty(B, tail, E, **dd), torch.empty(B, L, E, **dd), torch.empty(B, L, E, **dd)
+        out, weights, keep = torch.empty(B, tail, E, **dd), torch.empty(B, tail, L, **dd), torch.empty(B, tail, **dd)
+        keep_rows = torch.empty(B, tail, **dd) if row_zero is not None else keep
+        need = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4, 5, 6, 7, 8, 9))
+        p_heads = torch.empty(B, heads, tail, L, **dd) if need else None
+        y, pre = torch.empty(B, tail, E, **dd), torch.empty(B, tail, E, **dd)
+        native.attention_mh_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
+                                         mask, heads, q, k, v, out, weights, keep, p_heads,
+                                         None if row_zero is None else row_zero.contiguous(),
+                                         keep_rows if row_zero is not None else None,
+                                         wo.detach().contiguous(), bo.detach().contiguous(), y, pre)
+        if need:
+            # (`scaled`: the block's output was multiplied by keep_rows — with a row mask — or by keep — with an attention mask)
+            ctx.save_for_backward(x, q, k, v, p_heads, out, pre, *([keep_rows] if scaled else []), *([mask] if mask is not None else []))
+        ctx.tail, ctx.heads, ctx.has_mask, ctx.scaled = tail, heads, mask is not None, scaled
+        ctx.params = (wq, bq, wk, bk, wv, bv, wo, bo)
+        ctx.mark_non_differentiable(keep, keep_rows)
+        ctx.set_materialize_grads(False)
+        return y, weights, keep, keep_rows
+
+    @staticmethod
+    def backward(ctx, g_y, g_w, _g_keep, _g_keep_rows=None):
+        from asac_amd import native
+        if g_y is None and g_w is None:
+            return (None,) * 14
+        x, q, k, v, p_heads, out, pre, *rest = ctx.saved_tensors
+        scale = rest.pop(0) if ctx.scaled else None
+        mask = rest[0] if ctx.has_mask else None
+        B, L, E = x.shape
+        if g_y is None:
+            g_y = torch.zeros(q.shape, dtype=q.dtype, device=q.device)
+        wq, bq, wk, bk, wv, bv, wo, bo = ctx.params
+        g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        g_pre, g_x = torch.empty_like(pre), torch.empty(B, L, E, dtype=x.dtype, device=x.device)
+        native.attention_mh_block_backward(q, k, v, mask, ctx.heads, p_heads, g_y.contiguous(), pre,
+                                           None if scale is None else scale.contiguous(), wo.detach().contiguous(),
+                                           None if g_w is None else g_w.contiguous(),
+                                           [wq.detach(), wk.detach(), wv.detach()], g_q, g_k, g_v, g_pre, g_x)
+        x2 = x.reshape(-1, E)
+        xq2 = x2 if ctx.tail == L else x[:, -ctx.tail:].reshape(-1, E)
+        grads = [g_x if ctx.needs_input_grad[0] else None, None]
+        # (the output block's product first: the order the three-launch form queues them in)
+        go = _rows_param_grads(ctx.needs_input_grad[8:10], (wo, bo), g_pre.view(-1, E), out.view(-1, E))
+        for j, (g, xin) in enumerate(zip((g_q, g_k, g_v), (xq2, x2, x2))):
+            grads.extend(_rows_param_grads(ctx.needs_input_grad[2 + 2 * j:4 + 2 * j], ctx.params[2 * j:2 * j + 2], g.view(-1, E), xin))
+        return (*grads, *go, None, None, None, None)
+
+
 class _OutResRowsFn(torch.autograd.Function):
     """`(x + gelu(linear(x))) * row_scale[..., None]` — the output ResBlock of an attention layer and its dead-row / padded-row
     factor — as one MFMA launch per pass (`asac_rows_resblock_*`, csrc/rows_proj.hip); the parameter gradients from `asac_xty`"""
@@ -686,8 +748,13 @@ class MultiheadAttention(nn.Module):
                     rz = rz if rz.dtype in (torch.bool, torch.uint8) else rz != 0
                 lo = _plain_resblock(self.out_proj, self.embed_dim) if FUSED_ROWS_PROJ else None
                 y_pre = None
-                if fused_qkv is not None and lo is not None:
-                    # ... and the output ResBlock behind it: the block's forward is ONE launch
+                block_done = False
+                if fused_qkv is not None and lo is not None and FUSED_BLOCK_BACKWARD:
+                    # ... and the output ResBlock behind it: the block is ONE launch forward and ONE backward
+                    out, weights, keep, keep_rows = _AttnBlockFn.apply(key, q_len, *fused_qkv, lo.weight, lo.bias, m, self.num_heads,
+                                                                       rz, rz is not None or m is not None)
+                    block_done = True
+                elif fused_qkv is not None and lo is not None:
                     out, weights, keep, keep_rows, *y_pre = _QkvAttnMhFn.apply(key, q_len, *fused_qkv, m, self.num_heads, rz,
                                                                                (lo.weight, lo.bias))
                 elif fused_qkv is not None:
@@ -695,7 +762,9 @@ class MultiheadAttention(nn.Module):
                 else:
                     out, weights, keep, keep_rows = _AttnMhFn.apply(q, k, v, m, self.num_heads, rz)
                 scale = keep_rows if rz is not None else (keep if m is not None else None)
-                if y_pre:
+                if block_done:
+                    pass
+                elif y_pre:
                     out = _OutResSavedFn.apply(out, lo.weight, lo.bias, scale, tuple(y_pre))
                 elif lo is not None and native.rows_proj_supported(self.embed_dim):
                     # the output ResBlock and the dead-row / padded-row factor: one launch

@@ -71,6 +71,9 @@ struct Args {
     // ... and the output ResBlock behind the core (ow non-NULL): y = (o + gelu(o ow^T + ob)) * keep_rows, pre = o ow^T + ob
     const float* ow; const float* ob;
     float* y; float* pre;                     // [B][Lq][E]
+    // block backward (BWD with PEC > 0): the ResBlock's backward in front of the core's, the projections' input gradient behind
+    const float* gy; const float* scale_in;   // gradient of y [B][Lq][E]; the forward's keep_rows [B][Lq] or NULL
+    float* gpre; float* gx;                   // gradient of `pre` [B][Lq][E] and of the block's input [B][Lk][E]
 };
 
 // 16 bytes of channels [c0, c0 + 4) of a row, zero beyond d (and for rows beyond the window)
@@ -97,13 +100,16 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
     const int QT = (Lq + 15) >> 4, KT = (Lk + 15) >> 4, CT = (d + 15) >> 4;
     const float scale = 1.f / sqrtf((float)d);
     constexpr int kPP = 16 * (PEC > 0 ? PEC : 1) + 4;      // LDS row pitch of the projected rows (conflict-free 16-byte reads)
-    __shared__ __attribute__((aligned(16))) float s_qkv[PEC > 0 ? 3 : 1][PEC > 0 ? 16 : 1][PEC > 0 ? kPP : 4];
-    __shared__ __attribute__((aligned(16))) float s_o[PEC > 0 ? 16 : 1][PEC > 0 ? kPP : 4];      // the core's output rows (for the ResBlock)
+    constexpr bool kF = PEC > 0 && !BWD, kB = PEC > 0 && BWD;
+    __shared__ __attribute__((aligned(16))) float s_qkv[kF ? 3 : 1][kF ? 16 : 1][kF ? kPP : 4];
+    __shared__ __attribute__((aligned(16))) float s_o[kF ? 16 : 1][kF ? kPP : 4];      // the core's output rows (for the ResBlock)
+    __shared__ __attribute__((aligned(16))) float s_go[kB ? 16 : 1][kB ? kPP : 4];     // backward: gradient of the core's output
+    __shared__ __attribute__((aligned(16))) float s_g3[kB ? 3 : 1][kB ? 16 : 1][kB ? kPP : 4];      // ... and of q / k / v
     const float* qb = a.q + (int64_t)b * Lq * E;
     const float* kb = a.k + (int64_t)b * Lk * E;
     const float* vb = a.v + (int64_t)b * Lk * E;
     int RP = E;                                             // row pitch of q / k / v as the products below read them
-    if constexpr (PEC > 0) {
+    if constexpr (kF) {
         constexpr int EE = 16 * PEC;
         const bool live = x < Lk;
         const float* xp = a.x + (int64_t)b * a.xs_b + (int64_t)min(x, Lk - 1) * a.xs_t + 4 * qq;
@@ -161,6 +167,41 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
         for (int qn = 0; qn < NT; ++qn) wsum[km][qn] = zero4();
     float* tbuf = &s_t[wv][0][0];
+    const float* gob = BWD ? a.g_out + (int64_t)b * Lq * E : nullptr;
+    int GP = E;                                             // row pitch of the core's output gradient
+    // four strided words of a weight column block: W[n0 + s][k], s < 4 (E x E)
+    auto wcol4 = [&](const float* w, int n0, int k) {
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = w[(n0 + s) * E + k];
+        return v;
+    };
+    if constexpr (kB) {
+        // the output ResBlock's backward over the entry's <= 16 query rows (the arithmetic of k_rows_res_bwd): g = gy * scale,
+        // gpre = g * gelu'(pre) -> memory (its product over the rows is the block's weight gradient), g + gpre W -> LDS
+        constexpr int EE = 16 * PEC;
+        const bool live = x < Lq;
+        const int64_t rr = ((int64_t)b * Lq + min(x, Lq - 1)) * EE + 4 * qq;
+        const float sc = a.scale_in ? a.scale_in[(int64_t)b * Lq + min(x, Lq - 1)] : 1.f;
+        f32x4 gp[PEC];
+#pragma unroll
+        for (int c = 0; c < PEC; ++c) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gy + rr + 16 * c) * sc, z = *reinterpret_cast<const f32x4*>(a.pre + rr + 16 * c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gp[c][r] = live ? g[r] * gelu_grad(z[r]) : 0.f;
+            if (live && (c & (kWaves - 1)) == wv) *reinterpret_cast<f32x4*>(a.gpre + rr + 16 * c) = gp[c];
+        }
+        for (int kt = wv; kt < PEC; kt += kWaves) {
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int c = 0; c < PEC; ++c) acc = mfma4(wcol4(a.ow, 16 * c + 4 * qq, 16 * kt + x), gp[c], acc);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gy + rr + 16 * kt) * sc + acc;
+            *reinterpret_cast<f32x4*>(&s_go[x][16 * kt + 4 * qq]) = live ? g : zero4();
+        }
+        __syncthreads();
+        gob = &s_go[0][0];
+        GP = kPP;
+    }
 
     for (int h = wv; h < H; h += kWaves) {
         const int hc = h * d;
@@ -248,7 +289,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                     const int qi = 16 * qn + x, c0 = 16 * ct + 4 * qq;
                     if (qi < Lq) {
                         float* dst = a.out + ((int64_t)b * Lq + qi) * E + hc + c0;
-                        if constexpr (PEC > 0) {
+                        if constexpr (kF) {
                             if (a.ow && c0 < d) *reinterpret_cast<f32x4*>(&s_o[qi][hc + c0]) = o;      // (head_dim % 4 == 0 here)
                         }
                         if (c0 + 3 < d) *reinterpret_cast<f32x4*>(dst) = o;
@@ -272,7 +313,6 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                         P[km][qn][r] = (qi < Lq && kj < Lk) ? a.p_heads[(((int64_t)b * H + h) * Lq + qi) * Lk + kj] : 0.f;
                     }
             }
-            const float* gob = a.g_out + (int64_t)b * Lq * E;
             // dP[key][query] = sum_c V[key][c] dO[query][c]  (+ the head's share of the averaged weights' gradient)
             f32x4 dP[NT][NT];
 #pragma unroll
@@ -285,7 +325,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                 for (int t = 0; t < NT; ++t) {
                     const int kj = 16 * t + x, qi = 16 * t + x;
                     va[t] = row4(vb + (int64_t)min(kj, Lk - 1) * E + hc, t < KT && kj < Lk, 16 * ct + 4 * qq, d);
-                    go[t] = row4(gob + (int64_t)min(qi, Lq - 1) * E + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d);
+                    go[t] = row4(gob + (int64_t)min(qi, Lq - 1) * GP + hc, t < QT && qi < Lq, 16 * ct + 4 * qq, d);
                 }
 #pragma unroll
                 for (int km = 0; km < NT; ++km)
@@ -337,6 +377,9 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (c0 + r < d) dst[r] = o[r] * scale;
+                        if constexpr (kB) {
+                            if (c0 < d) *reinterpret_cast<f32x4*>(&s_g3[0][qi][hc + c0]) = o * scale;      // (head_dim % 4 == 0 here)
+                        }
                     }
                 }
             }
@@ -362,7 +405,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                     for (int s = 0; s < 4; ++s) {
                         const int qi = 16 * qn + 4 * s + qq;
                         const bool ok = c < d && qi < Lq;
-                        ga[qn][s] = ok ? gob[(int64_t)qi * E + hc + c] : 0.f;
+                        ga[qn][s] = ok ? gob[(int64_t)qi * GP + hc + c] : 0.f;
                         qa[qn][s] = ok ? qb[(int64_t)qi * E + hc + c] : 0.f;
                     }
 #pragma unroll
@@ -385,9 +428,39 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
                                 a.g_v[((int64_t)b * Lk + kj) * E + hc + c0 + r] = dv[r];
                                 a.g_k[((int64_t)b * Lk + kj) * E + hc + c0 + r] = dk[r] * scale;
                             }
+                        if constexpr (kB) {
+                            if (c0 < d) {
+                                *reinterpret_cast<f32x4*>(&s_g3[2][kj][hc + c0]) = dv;
+                                *reinterpret_cast<f32x4*>(&s_g3[1][kj][hc + c0]) = dk * scale;
+                            }
+                        }
                     }
                 }
             }
+        }
+    }
+    if constexpr (kB) {
+        // the projections' input gradient (the arithmetic of k_rows_proj_bwd): gx = g_q W_q + g_k W_k + g_v W_v, the queries
+        // being the entry's last Lq positions
+        constexpr int EE = 16 * PEC;
+        __syncthreads();
+        const bool live = x < Lk;
+        const int skip = Lk - Lq;
+        f32x4 gv[3][PEC];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rj = j == 0 ? x - skip : x;
+            const bool on = live && rj >= 0;
+#pragma unroll
+            for (int c = 0; c < PEC; ++c) gv[j][c] = on ? *reinterpret_cast<const f32x4*>(&s_g3[j][max(rj, 0)][16 * c + 4 * qq]) : zero4();
+        }
+        for (int kt = wv; kt < PEC; kt += kWaves) {
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < PEC; ++c) acc = mfma4(wcol4(a.pw[j], 16 * c + 4 * qq, 16 * kt + x), gv[j][c], acc);
+            if (live) *reinterpret_cast<f32x4*>(a.gx + ((int64_t)b * Lk + x) * EE + 16 * kt + 4 * qq) = acc;
         }
     }
     if (!BWD) {
@@ -398,7 +471,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
             for (int qn = 0; qn < NT; ++qn) ws[(wv * NT * NT + km * NT + qn) * 64 + l] = wsum[km][qn];
         __syncthreads();
-        if constexpr (PEC > 0) {
+        if constexpr (kF) {
             if (a.ow) {
                 // the output ResBlock over the entry's <= 16 query rows (the arithmetic of csrc/rows_proj.hip's k_rows_res_fwd)
                 constexpr int EE = 16 * PEC;
@@ -522,6 +595,34 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
     else if (E == 64) ASAC_LAUNCH((k_attn_mh<false, 1, 4>), grid, dim3(kThreads), 0, s, a);
     else ASAC_LAUNCH((k_attn_mh<false, 1, 8>), grid, dim3(kThreads), 0, s, a);
     return finish_launch("asac_attention_mh_proj_forward");
+}
+
+int asac_attention_mh_block_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
+                                     int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
+                                     const float* p_heads, const float* grad_y, const float* pre, const float* row_scale,
+                                     const float* out_weight, const float* grad_weights, const float* const* proj_weights,
+                                     float* grad_q, float* grad_k, float* grad_v, float* grad_pre, float* grad_x, void* stream) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!q || !k || !v || !p_heads || !grad_y || !pre || !out_weight || !proj_weights || !grad_q || !grad_k || !grad_v || !grad_pre ||
+        !grad_x || B <= 0 || !asac_attention_mh_proj_supported(Lq, Lk, heads, head_dim) || !al(grad_y) || !al(pre) || !al(grad_pre) ||
+        !al(grad_x))
+        return bad_arg("asac_attention_mh_block_backward");
+    Args a{};
+    a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
+    a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim;
+    a.p_heads = const_cast<float*>(p_heads), a.g_w = grad_weights, a.g_q = grad_q, a.g_k = grad_k, a.g_v = grad_v;
+    a.gy = grad_y, a.pre = const_cast<float*>(pre), a.scale_in = row_scale, a.ow = out_weight, a.gpre = grad_pre, a.gx = grad_x;
+    for (int j = 0; j < 3; ++j) {
+        if (!proj_weights[j]) return bad_arg("asac_attention_mh_block_backward: weights");
+        a.pw[j] = proj_weights[j];
+    }
+    const dim3 grid((unsigned)B);
+    const int E = heads * head_dim;
+    hipStream_t s = as_stream(stream);
+    if (E == 32) ASAC_LAUNCH((k_attn_mh<true, 1, 2>), grid, dim3(kThreads), 0, s, a);
+    else if (E == 64) ASAC_LAUNCH((k_attn_mh<true, 1, 4>), grid, dim3(kThreads), 0, s, a);
+    else ASAC_LAUNCH((k_attn_mh<true, 1, 8>), grid, dim3(kThreads), 0, s, a);
+    return finish_launch("asac_attention_mh_block_backward");
 }
 
 int asac_attention_mh_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,

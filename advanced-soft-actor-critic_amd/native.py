@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 72
+ABI_VERSION = 73
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -385,6 +385,10 @@ _SIGNATURES = {
                                                  C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]),
+    'asac_attention_mh_block_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_attention_mh_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -1966,6 +1970,24 @@ def attention_mh_proj_forward(x, weights, biases, mask, heads, q, k, v, out, att
                                                  _p(attn_weights), _p(keep), _p(p_heads), _p(row_zero), _p(keep_rows),
                                                  _p(out_weight), _p(out_bias), _p(y), _p(pre), _stream()),
            'asac_attention_mh_proj_forward')
+
+
+@_profiled
+def attention_mh_block_backward(q, k, v, mask, heads, p_heads, grad_y, pre, row_scale, out_weight, grad_weights, proj_weights,
+                                grad_q, grad_k, grad_v, grad_pre, grad_x):
+    """the backward of `attention_mh_proj_forward` with its output block: ResBlock backward, core backward and the projections'
+    input gradient as one launch"""
+    global _last_work
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    _last_work = 10.0 * B * Lq * Lk * E + 2.0 * B * (2 * Lq + 2 * Lk) * E * E
+    _dense_f32(q, k, v, p_heads, grad_y, pre, row_scale, out_weight, grad_weights, *proj_weights, grad_q, grad_k, grad_v, grad_pre,
+               grad_x)
+    pm, sb, si, sj = _mask3(mask, B)
+    _check(load().asac_attention_mh_block_backward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(p_heads),
+                                                   _p(grad_y), _p(pre), _p(row_scale), _p(out_weight), _p(grad_weights),
+                                                   _ptr_array(proj_weights), _p(grad_q), _p(grad_k), _p(grad_v), _p(grad_pre),
+                                                   _p(grad_x), _stream()), 'asac_attention_mh_block_backward')
 
 
 @_profiled

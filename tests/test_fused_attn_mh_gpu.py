@@ -237,9 +237,12 @@ def test_projections_and_output_block_around_the_core_are_one_launch_each(tail):
         got = run(dev, 'cuda')
     seen = prof.summary()
     # (windows of <= 16 positions: the projections run inside the core's forward launch, `asac_attention_mh_proj_forward`)
-    for name in ('asac_attention_mh_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_backward', 'asac_attention_mh_backward'):
+    # (the block is one launch forward and one backward)
+    for name in ('asac_attention_mh_proj_forward', 'asac_attention_mh_block_backward'):
         assert seen[name]['calls'] == 1, (name, seen.keys())
-    assert 'asac_rows_resblock_forward' not in seen and 'asac_rows_proj_forward' not in seen      # (the block's forward is one launch)
+    for name in ('asac_rows_resblock_forward', 'asac_rows_proj_forward', 'asac_rows_proj_backward', 'asac_rows_resblock_backward',
+                 'asac_attention_mh_backward', 'asac_attention_mh_forward'):
+        assert name not in seen, name
     for n_, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a).all()
         atol = 3e-5 if n_ < 3 else 2e-7 * B * L * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
@@ -335,16 +338,19 @@ def test_projections_inside_the_core_forward(B, L, tail, E, H):
         got = run(dev, 'cuda')
     seen = prof.summary()
     assert seen['asac_attention_mh_proj_forward']['calls'] == 1 and 'asac_rows_proj_forward' not in seen and 'asac_attention_mh_forward' not in seen
-    assert 'asac_rows_resblock_forward' not in seen and seen['asac_rows_resblock_backward']['calls'] == 1
-    assert seen['asac_rows_proj_backward']['calls'] == 1 and seen['asac_attention_mh_backward']['calls'] == 1
+    assert 'asac_rows_resblock_forward' not in seen and seen['asac_attention_mh_block_backward']['calls'] == 1
+    assert 'asac_rows_proj_backward' not in seen and 'asac_attention_mh_backward' not in seen and 'asac_rows_resblock_backward' not in seen
     for n_, (a, b) in enumerate(zip(got, want)):
         assert np.isfinite(a).all()
         atol = 3e-5 if n_ < 3 else 2e-7 * B * L * max(1.0, float(np.abs(b).max()) ** 0.5) + 3e-5
         np.testing.assert_allclose(a, b, rtol=3e-4, atol=atol, err_msg=f'output {n_}')
-    seq_layers.FUSED_QKV_IN_CORE = False
+    # ... and bit for bit the launches they replace: one-launch forward with the three-launch backward, and three + three
+    seq_layers.FUSED_BLOCK_BACKWARD = False
     try:
+        mixed = run(dev, 'cuda')
+        seq_layers.FUSED_QKV_IN_CORE = False
         two = run(dev, 'cuda')
     finally:
-        seq_layers.FUSED_QKV_IN_CORE = True
-    for a, b in zip(got, two):
-        assert np.array_equal(a, b)
+        seq_layers.FUSED_QKV_IN_CORE = seq_layers.FUSED_BLOCK_BACKWARD = True
+    for a, b, c in zip(got, mixed, two):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
