@@ -151,6 +151,12 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_obs_decoder_backward': 'asac::dec::k_dec_bwd3+asac::dec::k_dec_bwd2dx+asac::dec::k_dec_bwd2dw+asac::dec::k_dec_reduce',
               'asac_cosine_gate_add': 'asac::k_cosine_gate_add',
               'asac_attention_mh_forward': 'asac::amh::k_attn_mh', 'asac_attention_mh_backward': 'asac::amh::k_attn_mh',
+              'asac_attention_mh_proj_forward': 'asac::amh::k_attn_mh', 'asac_attention_mh_block_backward': 'asac::amh::k_attn_mh',
+              'asac_rows_proj_forward': 'asac::rowsp::k_rows_proj_fwd', 'asac_rows_proj_backward': 'asac::rowsp::k_rows_proj_bwd',
+              'asac_rows_resblock_forward': 'asac::rowsp::k_rows_res_fwd', 'asac_rows_resblock_backward': 'asac::rowsp::k_rows_res_bwd',
+              'asac_rows_affine_forward': 'asac::rowsp::k_rows_affine', 'asac_rows_affine_gelu_forward': 'asac::rowsp::k_rows_affine',
+              'asac_xty': 'asac::xty::k_xty', 'asac_xty_multi': 'asac::xty::k_xty_multi',
+              'asac_gru_wide_forward_twin': 'asac::gruw::k_gruw_fwd',
               'asac_gru_wide_forward': 'asac::gruw::k_gruw_fwd', 'asac_gru_wide_backward': 'asac::gruw::k_gruw_bwd',
               'asac_normal_nll_kl': 'asac::k_normal_nll_kl', 'asac_normal_nll_kl_logstd': 'asac::k_normal_nll_kl',
               'asac_masked_mse': 'asac::k_masked_mse'}
