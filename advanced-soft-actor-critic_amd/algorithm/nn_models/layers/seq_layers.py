@@ -416,7 +416,7 @@ class _QkvAttnMhFn(torch.autograd.Function):
             y, pre = torch.empty(B, tail, E, **dd), torch.empty(B, tail, E, **dd)
         native.attention_mh_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
                                          mask, heads, q, k, v, out, weights, keep, p_heads,
-                                         None if row_zero is None else row_zero.contiguous(),
+                                         None if row_zero is None else (row_zero if row_zero.stride(-1) == 1 else row_zero.contiguous()),
                                          keep_rows if row_zero is not None else None,
                                          *(() if out_block is None else (out_block[0].detach().contiguous(),
                                                                          out_block[1].detach().contiguous(), y, pre)))
@@ -477,7 +477,7 @@ class _AttnBlockFn(torch.autograd.Function):
         y, pre = torch.empty(B, tail, E, **dd), torch.empty(B, tail, E, **dd)
         native.attention_mh_proj_forward(x, [wq.detach(), wk.detach(), wv.detach()], [bq.detach(), bk.detach(), bv.detach()],
                                          mask, heads, q, k, v, out, weights, keep, p_heads,
-                                         None if row_zero is None else row_zero.contiguous(),
+                                         None if row_zero is None else (row_zero if row_zero.stride(-1) == 1 else row_zero.contiguous()),
                                          keep_rows if row_zero is not None else None,
                                          wo.detach().contiguous(), bo.detach().contiguous(), y, pre)
         if need:

@@ -58,7 +58,8 @@ struct Args {
     float* out;            // [B][Lq][E]
     float* w_avg;          // [B][Lq][Lk]  mean over heads of softmax, * keep
     float* keep;           // [B][Lq]
-    const uint8_t* row_zero;   // [B][Lq] or NULL: the caller's padded positions (rows whose OUTPUT it zeroes)
+    const uint8_t* row_zero;   // [B][Lq] (batch stride rz_sb) or NULL: the caller's padded positions (rows whose OUTPUT it zeroes)
+    int64_t rz_sb;
     float* keep_rows;      // [B][Lq] or NULL: keep * !row_zero — the one factor the caller multiplies the output with
     float* p_heads;        // [B][H][Lq][Lk] per-head softmax (saved for the backward) or NULL
     // backward
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
 #pragma unroll
                 for (int c = 0; c < PEC; ++c) ov[c] = live ? *reinterpret_cast<const f32x4*>(&s_o[x][16 * c + 4 * qq]) : zero4();
                 float sc = dead[0] ? 0.f : 1.f;
-                if (a.row_zero && live && a.row_zero[(int64_t)b * Lq + x]) sc = 0.f;
+                if (a.row_zero && live && a.row_zero[(int64_t)b * a.rz_sb + x]) sc = 0.f;
                 for (int nt = wv; nt < PEC; nt += kWaves) {
                     const float* wp = a.ow + (16 * nt + x) * EE + 4 * qq;
                     f32x4 acc = zero4();
@@ -509,7 +510,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             if (qq == 0) {
                 a.keep[(int64_t)b * Lq + qi] = kp;
                 if (a.keep_rows)
-                    a.keep_rows[(int64_t)b * Lq + qi] = (a.row_zero && a.row_zero[(int64_t)b * Lq + qi]) ? 0.f : kp;
+                    a.keep_rows[(int64_t)b * Lq + qi] = (a.row_zero && a.row_zero[(int64_t)b * a.rz_sb + qi]) ? 0.f : kp;
             }
 #pragma unroll
             for (int km = 0; km < NT; ++km) {
@@ -556,7 +557,7 @@ int asac_attention_mh_forward(const float* q, const float* k, const float* v, co
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = weights, a.keep = keep, a.p_heads = p_heads;
-    a.row_zero = row_zero, a.keep_rows = keep_rows;
+    a.row_zero = row_zero, a.rz_sb = Lq, a.keep_rows = keep_rows;
     launch<false>(a, as_stream(stream));
     return finish_launch("asac_attention_mh_forward");
 }
@@ -571,17 +572,17 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
                                    const float* const* biases, const uint8_t* mask, int64_t mask_stride_b,
                                    int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
                                    float* q, float* k, float* v, float* out, float* attn_weights, float* keep, float* p_heads,
-                                   const uint8_t* row_zero, float* keep_rows, const float* out_weight, const float* out_bias,
-                                   float* y, float* pre, void* stream) {
+                                   const uint8_t* row_zero, int64_t row_zero_stride_b, float* keep_rows, const float* out_weight,
+                                   const float* out_bias, float* y, float* pre, void* stream) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!x || !weights || !biases || !q || !k || !v || !out || !attn_weights || !keep || B <= 0 ||
         !asac_attention_mh_proj_supported(Lq, Lk, heads, head_dim) || !al(x) || (x_stride_b & 3) || (x_stride_t & 3) || !al(q) ||
-        !al(k) || !al(v) || (out_weight && (!out_bias || !y || !pre || !al(out_weight) || !al(out_bias) || !al(y) || !al(pre))))
+        !al(k) || !al(v) || (row_zero && row_zero_stride_b < Lq) || (out_weight && (!out_bias || !y || !pre || !al(out_weight) || !al(out_bias) || !al(y) || !al(pre))))
         return bad_arg("asac_attention_mh_proj_forward");
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim, a.out = out, a.w_avg = attn_weights, a.keep = keep, a.p_heads = p_heads;
-    a.row_zero = row_zero, a.keep_rows = keep_rows;
+    a.row_zero = row_zero, a.rz_sb = row_zero_stride_b, a.keep_rows = keep_rows;
     a.x = x, a.xs_b = x_stride_b, a.xs_t = x_stride_t;
     a.ow = out_weight, a.ob = out_bias, a.y = y, a.pre = pre;
     for (int j = 0; j < 3; ++j) {

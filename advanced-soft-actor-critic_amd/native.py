@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 73
+ABI_VERSION = 74
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -384,7 +384,7 @@ _SIGNATURES = {
     'asac_attention_mh_proj_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                  C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p, C.c_void_p]),
+                                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_attention_mh_block_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -1963,11 +1963,12 @@ def attention_mh_proj_forward(x, weights, biases, mask, heads, q, k, v, out, att
     if out_weight is not None:
         _last_work += 2.0 * B * Lq * E * E
     pm, sb, si, sj = _mask3(mask, B)
-    if row_zero is not None:
-        assert row_zero.shape == (B, Lq) and row_zero.is_contiguous() and row_zero.element_size() == 1 and keep_rows is not None
+    if row_zero is not None:      # (a slice of a wider mask is read in place: batch stride)
+        assert row_zero.shape == (B, Lq) and row_zero.stride(1) == 1 and row_zero.element_size() == 1 and keep_rows is not None
     _check(load().asac_attention_mh_proj_forward(_p(x), x.stride(0), x.stride(1), _ptr_array(weights), _ptr_array(biases), pm, sb,
                                                  si, sj, B, Lq, Lk, heads, E // heads, _p(q), _p(k), _p(v), _p(out),
-                                                 _p(attn_weights), _p(keep), _p(p_heads), _p(row_zero), _p(keep_rows),
+                                                 _p(attn_weights), _p(keep), _p(p_heads), _p(row_zero),
+                                                 0 if row_zero is None else row_zero.stride(0), _p(keep_rows),
                                                  _p(out_weight), _p(out_bias), _p(y), _p(pre), _stream()),
            'asac_attention_mh_proj_forward')
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 73
+#define ASAC_ABI_VERSION 74
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -918,7 +918,7 @@ int asac_attention_mh_backward(const float* q, const float* k, const float* v, c
  * (`self.q_proj(query), self.k_proj(key), self.v_proj(value)` with value = key and query = the last Lq positions of key,
  * seq_layers.py:239-333): x [B][Lk][E] with strides in floats (multiples of 4, 16-byte aligned), weights / biases = HOST arrays
  * of the three [E][E] / [E] device pointers (q, k, v order); q [B][Lq][E], k / v [B][Lk][E] are OUTPUTS (dense; what the
- * backward reads).  Windows Lq <= Lk <= 16, E = heads * head_dim in {32, 64, 128}, head_dim a multiple of 4.  out_weight non-NULL:
+ * backward reads); row_zero [B][Lq] with a batch stride in bytes (a slice of a wider mask is read in place).  Windows Lq <= Lk <= 16, E = heads * head_dim in {32, 64, 128}, head_dim a multiple of 4.  out_weight non-NULL:
  * the output ResBlock of asac_rows_resblock_forward runs behind the core in the same launch — y / pre [B][Lq][E] as there, with
  * row_scale = keep * !row_zero (`out` still receives the core's own output: the ResBlock's input).  The backward is
  * asac_rows_resblock_backward (if fused), asac_attention_mh_backward, asac_rows_proj_backward. */
@@ -927,8 +927,8 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
                                    const float* const* biases, const uint8_t* mask, int64_t mask_stride_b,
                                    int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
                                    float* q, float* k, float* v, float* out, float* attn_weights, float* keep, float* p_heads,
-                                   const uint8_t* row_zero, float* keep_rows, const float* out_weight, const float* out_bias,
-                                   float* y, float* pre, void* stream);
+                                   const uint8_t* row_zero, int64_t row_zero_stride_b, float* keep_rows, const float* out_weight,
+                                   const float* out_bias, float* y, float* pre, void* stream);
 
 /* The backward of asac_attention_mh_proj_forward WITH its output block as one launch: asac_rows_resblock_backward in front of the
  * core's backward (grad_y, pre, row_scale = the forward's keep_rows or NULL, out_weight -> grad_pre [B][Lq][E], and the gradient

@@ -73,3 +73,19 @@ def test_product_path_refuses_cpu_devices():
     import numpy as np
     with pytest.raises(native.AsacNativeError):     # the agent side's episode slabs live in HBM as well
         EpisodeSlab([(6,)], [np.float32], 2, (0,), 16, torch.device('cpu'), np.zeros(2, np.float32))
+
+
+def test_binding_argument_counts_match_the_header():
+    """every ctypes signature lists as many arguments as the header declares (ctypes accepts EXTRA arguments silently and
+    converts them by its default rules — a Python int would travel as a 32-bit int where the C side expects int64)"""
+    import re
+    from asac_amd import native
+    hdr = re.sub(r'/\*.*?\*/', '', (ROOT / 'include' / 'asac_hip.h').read_text(), flags=re.S)
+    bad = []
+    for name, (_res, args) in native._SIGNATURES.items():
+        m = re.search(r'\b' + name + r'\s*\(([^;{]*?)\)\s*;', hdr, re.S)
+        assert m, f'{name}: bound but not declared'
+        params = [p_ for p_ in m.group(1).split(',') if p_.strip() and p_.strip() != 'void']
+        if len(params) != len(args):
+            bad.append((name, len(params), len(args)))
+    assert not bad, bad
