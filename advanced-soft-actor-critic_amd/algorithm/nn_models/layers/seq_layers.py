@@ -503,7 +503,9 @@ class _AttnBlockFn(torch.autograd.Function):
         wq, bq, wk, bk, wv, bv, wo, bo = ctx.params
         g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         g_pre, g_x = torch.empty_like(pre), torch.empty(B, L, E, dtype=x.dtype, device=x.device)
-        native.attention_mh_block_backward(q, k, v, mask, ctx.heads, p_heads, g_y.contiguous(), pre,
+        if g_y.stride(2) != 1 or (g_y.stride(0) | g_y.stride(1) | (g_y.data_ptr() >> 2)) & 3:
+            g_y = g_y.contiguous()      # (otherwise a slice — the gradient of a concatenation's part — is read in place)
+        native.attention_mh_block_backward(q, k, v, mask, ctx.heads, p_heads, g_y, pre,
                                            None if scale is None else scale.contiguous(), wo.detach().contiguous(),
                                            None if g_w is None else g_w.contiguous(),
                                            [wq.detach(), wk.detach(), wv.detach()], g_q, g_k, g_v, g_pre, g_x)

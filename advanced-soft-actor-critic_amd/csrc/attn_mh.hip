@@ -73,7 +73,8 @@ struct Args {
     const float* ow; const float* ob;
     float* y; float* pre;                     // [B][Lq][E]
     // block backward (BWD with PEC > 0): the ResBlock's backward in front of the core's, the projections' input gradient behind
-    const float* gy; const float* scale_in;   // gradient of y [B][Lq][E]; the forward's keep_rows [B][Lq] or NULL
+    const float* gy; const float* scale_in;   // gradient of y [B][Lq][E] (strides gy_sb, gy_st); the forward's keep_rows [B][Lq] or NULL
+    int64_t gy_sb, gy_st;
     float* gpre; float* gx;                   // gradient of `pre` [B][Lq][E] and of the block's input [B][Lk][E]
 };
 
@@ -183,11 +184,12 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
         constexpr int EE = 16 * PEC;
         const bool live = x < Lq;
         const int64_t rr = ((int64_t)b * Lq + min(x, Lq - 1)) * EE + 4 * qq;
+        const float* gyr = a.gy + (int64_t)b * a.gy_sb + (int64_t)min(x, Lq - 1) * a.gy_st + 4 * qq;      // (a slice is read in place)
         const float sc = a.scale_in ? a.scale_in[(int64_t)b * Lq + min(x, Lq - 1)] : 1.f;
         f32x4 gp[PEC];
 #pragma unroll
         for (int c = 0; c < PEC; ++c) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gy + rr + 16 * c) * sc, z = *reinterpret_cast<const f32x4*>(a.pre + rr + 16 * c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gyr + 16 * c) * sc, z = *reinterpret_cast<const f32x4*>(a.pre + rr + 16 * c);
 #pragma unroll
             for (int r = 0; r < 4; ++r) gp[c][r] = live ? g[r] * gelu_grad(z[r]) : 0.f;
             if (live && (c & (kWaves - 1)) == wv) *reinterpret_cast<f32x4*>(a.gpre + rr + 16 * c) = gp[c];
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(kThreads) k_attn_mh(const Args a) {
             f32x4 acc = zero4();
 #pragma unroll
             for (int c = 0; c < PEC; ++c) acc = mfma4(wcol4(a.ow, 16 * c + 4 * qq, 16 * kt + x), gp[c], acc);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(a.gy + rr + 16 * kt) * sc + acc;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gyr + 16 * kt) * sc + acc;
             *reinterpret_cast<f32x4*>(&s_go[x][16 * kt + 4 * qq]) = live ? g : zero4();
         }
         __syncthreads();
@@ -600,19 +602,20 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
 
 int asac_attention_mh_block_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
                                      int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
-                                     const float* p_heads, const float* grad_y, const float* pre, const float* row_scale,
-                                     const float* out_weight, const float* grad_weights, const float* const* proj_weights,
-                                     float* grad_q, float* grad_k, float* grad_v, float* grad_pre, float* grad_x, void* stream) {
+                                     const float* p_heads, const float* grad_y, int64_t grad_y_stride_b, int64_t grad_y_stride_t,
+                                     const float* pre, const float* row_scale, const float* out_weight, const float* grad_weights,
+                                     const float* const* proj_weights, float* grad_q, float* grad_k, float* grad_v, float* grad_pre,
+                                     float* grad_x, void* stream) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!q || !k || !v || !p_heads || !grad_y || !pre || !out_weight || !proj_weights || !grad_q || !grad_k || !grad_v || !grad_pre ||
         !grad_x || B <= 0 || !asac_attention_mh_proj_supported(Lq, Lk, heads, head_dim) || !al(grad_y) || !al(pre) || !al(grad_pre) ||
-        !al(grad_x))
+        !al(grad_x) || (grad_y_stride_b & 3) || (grad_y_stride_t & 3) || grad_y_stride_t < heads * head_dim)
         return bad_arg("asac_attention_mh_block_backward");
     Args a{};
     a.q = q, a.k = k, a.v = v, a.mask = mask, a.m_sb = mask_stride_b, a.m_si = mask_stride_q, a.m_sj = mask_stride_k;
     a.B = B, a.Lq = Lq, a.Lk = Lk, a.H = heads, a.d = head_dim;
     a.p_heads = const_cast<float*>(p_heads), a.g_w = grad_weights, a.g_q = grad_q, a.g_k = grad_k, a.g_v = grad_v;
-    a.gy = grad_y, a.pre = const_cast<float*>(pre), a.scale_in = row_scale, a.ow = out_weight, a.gpre = grad_pre, a.gx = grad_x;
+    a.gy = grad_y, a.gy_sb = grad_y_stride_b, a.gy_st = grad_y_stride_t, a.pre = const_cast<float*>(pre), a.scale_in = row_scale, a.ow = out_weight, a.gpre = grad_pre, a.gx = grad_x;
     for (int j = 0; j < 3; ++j) {
         if (!proj_weights[j]) return bad_arg("asac_attention_mh_block_backward: weights");
         a.pw[j] = proj_weights[j];

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 74
+ABI_VERSION = 75
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -386,9 +386,9 @@ _SIGNATURES = {
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_attention_mh_block_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                                   C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'asac_attention_mh_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -1982,11 +1982,12 @@ def attention_mh_block_backward(q, k, v, mask, heads, p_heads, grad_y, pre, row_
     B, Lq, E = q.shape
     Lk = k.shape[1]
     _last_work = 10.0 * B * Lq * Lk * E + 2.0 * B * (2 * Lq + 2 * Lk) * E * E
-    _dense_f32(q, k, v, p_heads, grad_y, pre, row_scale, out_weight, grad_weights, *proj_weights, grad_q, grad_k, grad_v, grad_pre,
-               grad_x)
+    _dense_f32(q, k, v, p_heads, pre, row_scale, out_weight, grad_weights, *proj_weights, grad_q, grad_k, grad_v, grad_pre, grad_x)
+    assert grad_y.shape == q.shape and grad_y.stride(2) == 1 and grad_y.dtype == torch.float32 and grad_y.is_cuda
     pm, sb, si, sj = _mask3(mask, B)
     _check(load().asac_attention_mh_block_backward(_p(q), _p(k), _p(v), pm, sb, si, sj, B, Lq, Lk, heads, E // heads, _p(p_heads),
-                                                   _p(grad_y), _p(pre), _p(row_scale), _p(out_weight), _p(grad_weights),
+                                                   _p(grad_y), grad_y.stride(0), grad_y.stride(1), _p(pre), _p(row_scale),
+                                                   _p(out_weight), _p(grad_weights),
                                                    _ptr_array(proj_weights), _p(grad_q), _p(grad_k), _p(grad_v), _p(grad_pre),
                                                    _p(grad_x), _stream()), 'asac_attention_mh_block_backward')
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 74
+#define ASAC_ABI_VERSION 75
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -931,15 +931,16 @@ int asac_attention_mh_proj_forward(const float* x, int64_t x_stride_b, int64_t x
                                    const float* out_bias, float* y, float* pre, void* stream);
 
 /* The backward of asac_attention_mh_proj_forward WITH its output block as one launch: asac_rows_resblock_backward in front of the
- * core's backward (grad_y, pre, row_scale = the forward's keep_rows or NULL, out_weight -> grad_pre [B][Lq][E], and the gradient
+ * core's backward (grad_y [B][Lq][E] with strides in floats — multiples of 4, feature stride 1 —, pre, row_scale = the forward's keep_rows or NULL, out_weight -> grad_pre [B][Lq][E], and the gradient
  * of the core's output, which stays on chip), asac_attention_mh_backward (-> grad_q / grad_k / grad_v, written for the parameter
  * gradient products), asac_rows_proj_backward behind it (proj_weights = HOST array of the three [E][E] device pointers ->
  * grad_x [B][Lk][E]).  Same values as the three launches. */
 int asac_attention_mh_block_backward(const float* q, const float* k, const float* v, const uint8_t* mask, int64_t mask_stride_b,
                                      int64_t mask_stride_q, int64_t mask_stride_k, int B, int Lq, int Lk, int heads, int head_dim,
-                                     const float* p_heads, const float* grad_y, const float* pre, const float* row_scale,
-                                     const float* out_weight, const float* grad_weights, const float* const* proj_weights,
-                                     float* grad_q, float* grad_k, float* grad_v, float* grad_pre, float* grad_x, void* stream);
+                                     const float* p_heads, const float* grad_y, int64_t grad_y_stride_b, int64_t grad_y_stride_t,
+                                     const float* pre, const float* row_scale, const float* out_weight, const float* grad_weights,
+                                     const float* const* proj_weights, float* grad_q, float* grad_k, float* grad_v, float* grad_pre,
+                                     float* grad_x, void* stream);
 
 /* The Linear layers around that core over the rows of a batch of windows, one launch each (csrc/rows_proj.hip) — replaces, in
  * `MultiheadAttention.forward` (nn_models/layers/seq_layers.py:239-333): `self.q_proj(query), self.k_proj(key),
