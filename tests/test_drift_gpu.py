@@ -1,6 +1,6 @@
 """GPU: how far product and oracle drift apart when NOTHING re-aligns them.
 
-260 (cfg2) / 130 (cfg4) consecutive train steps of a BASELINE configuration at its real size: the product draws on the device, the draws of
+220 (cfg2) / 110 (cfg4) consecutive train steps of a BASELINE configuration at its real size: the product draws on the device, the draws of
 every step are read back and replayed on the CPU oracle (`oracle.sac_ref.SacRef`), and the oracle's replay state (tree,
 written-back probabilities / hidden states, weights) is NEVER set to the product's after step 0's common start.  PER
 index selection is a discontinuous function of priorities that differ at rounding level, so at some step a stratum
@@ -23,7 +23,7 @@ from oracle import sac_ref  # noqa: E402
 from tests import parity_utils as pu  # noqa: E402
 from tests.test_full_size_gpu import SUBSET_ROWS, _episode, _full_perm  # noqa: E402
 
-STEPS = {'cfg2': 260, 'cfg4': 130}      # (round 4: 500 / 300; shortened to keep the GPU suite inside its time budget)
+STEPS = {'cfg2': 220, 'cfg4': 110}      # (round 4: 500 / 300; shortened to keep the GPU suite inside its time budget)
 FILL = {'cfg2': 2 ** 15, 'cfg4': 4096}
 # (relative difference of the means over the last 100 steps): loss_q, mean |td|, log alpha
 BOUNDS = {'cfg2': (0.25, 0.25, 0.05), 'cfg4': (0.25, 0.25, 0.05)}
