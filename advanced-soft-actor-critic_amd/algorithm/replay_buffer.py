@@ -33,6 +33,11 @@ import torch
 
 from asac_amd import native
 
+# ring column dtype -> the NumPy dtype an incoming episode's key is converted to before its bytes are scattered
+_NP_DTYPES = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64), torch.float16: np.dtype(np.float16),
+              torch.int64: np.dtype(np.int64), torch.int32: np.dtype(np.int32), torch.int16: np.dtype(np.int16),
+              torch.int8: np.dtype(np.int8), torch.uint8: np.dtype(np.uint8), torch.bool: np.dtype(np.bool_)}
+
 __all__ = ['PrioritizedReplayBuffer']
 
 
@@ -184,13 +189,29 @@ class PrioritizedReplayBuffer:
             self._columns = {k: torch.zeros((C, *v.shape[1:]), dtype=torch.from_numpy(v[:0]).dtype, device=self.device)
                              for k, v in arrs.items()}
             self._batch, self._gather_keys = None, None
+        # the scatter moves raw bytes: every key must arrive in its ring's own dtype and row shape (the per-key path's
+        # `copy_` converted and raised; a later episode with float64 rewards after a float32 first one would otherwise
+        # write rows of another width into the ring)
+        for k, v in arrs.items():
+            col = self._columns.get(k)
+            if col is None:
+                raise KeyError(f'transition key {k!r} is not a column of this replay buffer ({list(self._columns)})')
+            if tuple(v.shape[1:]) != tuple(col.shape[1:]):
+                raise ValueError(f'transition key {k!r}: row shape {tuple(v.shape[1:])} does not match the ring\'s '
+                                 f'{tuple(col.shape[1:])}')
+            if v.shape[0] != count:
+                raise ValueError(f'transition key {k!r}: {v.shape[0]} rows, the episode has {count}')
+            want = _NP_DTYPES.get(col.dtype)
+            if want is not None and v.dtype != want:
+                arrs[k] = np.ascontiguousarray(v.astype(want))
         first_id = self._next_id
         skip = max(0, count - C)             # only the last C rows of an over-long episode survive
         live = count - skip
         if live > 0:
             offs, total = {}, 0
             for k, v in arrs.items():
-                rb_ = v.dtype.itemsize * int(np.prod(v.shape[1:], dtype=np.int64))
+                col = self._columns[k]
+                rb_ = col.element_size() * int(np.prod(col.shape[1:], dtype=np.int64))      # the RING's row bytes
                 offs[k] = (total, rb_)
                 total += (live * rb_ + 15) & ~15
             slot_off = total

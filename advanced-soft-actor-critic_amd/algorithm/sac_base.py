@@ -2198,7 +2198,6 @@ class SAC_Base(AuxHeadsMixin):
             self._dist_ready, _ = self._dist.all_ready(rb.is_lg_batch_size, rb.size, self.device)
         return self._dist_ready
 
-    @unified_elapsed_timer('train a step', 10)
     def _optimizer_hp(self) -> tuple:
         """(lr, betas, eps) of every optimizer of the learner: host floats that a captured step holds as kernel arguments"""
         opts = self._all_optimizers
@@ -2219,6 +2218,7 @@ class SAC_Base(AuxHeadsMixin):
                 self._graph_runs.clear()
             self._graph_hp = hp
 
+    @unified_elapsed_timer('train a step', 10)
     def train(self) -> int:
         step = self.get_global_step()
         rb = self.replay_buffer

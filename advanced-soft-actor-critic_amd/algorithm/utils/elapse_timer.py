@@ -63,5 +63,7 @@ def unified_elapsed_timer(log, repeat=1, force_report=True, profiler='_profiler'
                 return fn(self, *a, **k)
         wrapped.__name__ = getattr(fn, '__name__', 'wrapped')
         wrapped.__doc__ = fn.__doc__
+        wrapped.__wrapped__ = fn
+        wrapped.elapsed_log = log      # (which log line this method reports under: tests/test_host_logic.py)
         return wrapped
     return deco

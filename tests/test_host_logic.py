@@ -156,3 +156,13 @@ def test_deferred_cat_behaves_like_the_concatenation_for_every_other_consumer():
     assert b.grad is not None and torch.equal(out, lin(want))
     assert not deferrable([a, b], -1, 64)                      # host tensors are never deferred
     assert not deferrable([a], -1, 64) and not deferrable([a, b, a], -1, 64)
+
+
+def test_train_is_the_method_timed_as_train_a_step():
+    """Reference `sac_base.py:2496`: `@unified_elapsed_timer('train a step', 10)` sits on `train` — the log hook the
+    reference's users read; helpers next to it must not take the decorator."""
+    from algorithm.sac_base import SAC_Base
+    assert getattr(SAC_Base.train, 'elapsed_log', None) == 'train a step'
+    assert SAC_Base.train.__wrapped__.__name__ == 'train'
+    for helper in ('_optimizer_hp', '_drop_graphs_if_hp_changed', '_ready_to_train'):
+        assert not hasattr(getattr(SAC_Base, helper), 'elapsed_log'), helper

@@ -58,6 +58,10 @@ def test_sharded_plan_kernels_equal_single_tree(G):
     rng = np.random.default_rng(17 + G)
     Cs, B = 1024, 96 * G if G < 8 else 1024
     leaves = (rng.random(G * Cs) * (rng.random(G * Cs) < 0.7)).astype(np.float32)
+    # the boundary values u = 0 and u -> 1 must land on leaves WITH priority, so that the weights below are real numbers
+    # for every G (a zero-priority first leaf made min(ratio) 0 and the comparison vacuous at G = 1); the degenerate
+    # draw is asserted on its own at the end
+    leaves[0], leaves[-1] = max(leaves[0], 0.25), max(leaves[-1], 0.5)
     union = SumTreeRef(G * Cs)
     union.update(np.arange(G * Cs), leaves)
     shards = []
@@ -92,16 +96,28 @@ def test_sharded_plan_kernels_equal_single_tree(G):
         assert (leaf[~mine] == -1).all() and (p[~mine] == 0).all() and (ids[~mine] == -1).all()
         p_sum += torch.from_numpy(p).cuda()
     assert np.array_equal(p_sum.cpu().numpy().view(np.uint32), p_ref.view(np.uint32)), 'the all-reduce\'s sum'
+    assert (p_ref > 0).all(), 'every drawn leaf carries priority: the weights below are finite and non-trivial'
     ratio = p_ref / union.total
     w_ref = np.power(ratio / np.min(ratio), -np.float64(0.401)).astype(np.float32)
+    assert np.isfinite(w_ref).all() and w_ref.max() == 1.0 and np.unique(w_ref).size > B // 2
     total_d = torch.tensor([float(union.total)], **f)
     for g in range(G):
         beta = torch.tensor([0.4], dtype=torch.float64, **f)
         w = torch.zeros(per, **f)
         native.per_is_weights_slice(p_sum, g * per, per, total_d, beta, 0.001, w)
         assert float(beta) == 0.401
-        ok = np.isfinite(w_ref[g * per:(g + 1) * per])
-        np.testing.assert_allclose(w.cpu().numpy()[ok], w_ref[g * per:(g + 1) * per][ok], rtol=2e-6)
+        np.testing.assert_allclose(w.cpu().numpy(), w_ref[g * per:(g + 1) * per], rtol=2e-6, atol=0)
+    # a zero-priority leaf among the draws (the reference divides by a minimum ratio of 0, replay_buffer.py:352-354):
+    # weight 0 where p > 0 (inf ** -beta), NaN where p == 0 (0 / 0) — asserted as that pattern, not through NaN == NaN
+    p_deg = p_ref.copy()
+    p_deg[1] = 0.0
+    p_deg_d = torch.from_numpy(p_deg).cuda()
+    for g in range(G):
+        beta = torch.tensor([0.4], dtype=torch.float64, **f)
+        w = torch.zeros(per, **f)
+        native.per_is_weights_slice(p_deg_d, g * per, per, total_d, beta, 0.001, w)
+        got, mine = w.cpu().numpy(), p_deg[g * per:(g + 1) * per]
+        assert np.array_equal(np.isnan(got), mine == 0) and (got[mine > 0] == 0).all()
 
 
 def _agent(dist_ctx=None, sampling='throughput', device='cuda:0', graph=False, seed=3):

@@ -216,6 +216,43 @@ def test_packed_ingress_equals_per_key_copies_and_the_oracle():
     plain.close()
 
 
+def test_packed_ingress_converts_dtypes_and_rejects_other_row_shapes():
+    """A later episode whose key arrives in another dtype (float64 rewards after a float32 first episode: `put_episode`
+    does no casting) is converted to the ring's dtype like the per-key `copy_` did — not scattered as rows of another
+    width — and a different row shape / an unknown key raises instead of writing out of bounds."""
+    import asac_amd  # noqa: F401
+    from algorithm.replay_buffer import PrioritizedReplayBuffer
+    C, B = 32, 4
+    packed = PrioritizedReplayBuffer(B, 1, 2, torch.device('cuda:0'), capacity=C)
+    plain = PrioritizedReplayBuffer(B, 1, 2, torch.device('cuda:0'), capacity=C)
+    plain.packed_ingress = False
+    rng = np.random.default_rng(11)
+
+    def episode(T, reward_dtype=np.float32, mu_dtype=np.float32, width=3):
+        return {'index': np.arange(T, dtype=np.int32), 'obs_vec': rng.standard_normal((T, width)).astype(np.float32),
+                'reward': rng.standard_normal(T).astype(reward_dtype), 'mu_prob': rng.random((T, 2)).astype(mu_dtype),
+                'done': np.zeros(T, bool)}
+    for ep in (episode(7), episode(9, np.float64, np.float64), episode(30, np.float16), episode(5, np.float64)):
+        packed.add(ep, ignore_size=1)
+        plain.add(ep, ignore_size=1)
+        for k in ep:
+            assert packed._columns[k].dtype == plain._columns[k].dtype
+            assert torch.equal(packed._columns[k], plain._columns[k]), k
+    with pytest.raises(ValueError):
+        packed.add(episode(4, width=5))
+    bad = episode(4)
+    bad['extra'] = np.zeros(4, np.float32)
+    with pytest.raises(KeyError):
+        packed.add(bad)
+    ragged = episode(4)
+    ragged['reward'] = ragged['reward'][:3]
+    with pytest.raises(ValueError):
+        packed.add(ragged)
+    assert packed.check_tree_invariant() == 0
+    packed.close()
+    plain.close()
+
+
 def test_option_critic_replay_fields_and_random_reads():
     """the option-critic variant's storage dict (reference oc/option_selector_base.py:2029-2086:
     `option_index` int8, `option_changed_index` int32, `pre_low_seq_hidden_state` beside the usual keys) through
