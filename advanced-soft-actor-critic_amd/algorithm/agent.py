@@ -392,38 +392,46 @@ class AgentManager:
         self._tmp_episode_trans_list = []
         self._data = {}
 
-    def __getitem__(self, k: str):
-        return self._data[k]
+    # -- per-manager scratch the environment loops hang on the manager (`mgr['key']`), and views over its agents
+    #    (reference agent.py:372-400: same names, same meaning)
+    def __getitem__(self, key: str):
+        return self._data[key]
 
-    def __setitem__(self, k: str, v):
-        self._data[k] = v
+    def __setitem__(self, key: str, value):
+        self._data[key] = value
 
-    @property
-    def agents(self) -> list[Agent]:
-        return list(self.agents_dict.values())
+    def _agents_where(self, empty: bool | None = None) -> list[Agent]:
+        members = self.agents_dict.values()
+        if empty is None:
+            return [*members]
+        return [ag for ag in members if bool(ag.is_empty) == empty]
 
-    @property
-    def non_empty_agents(self) -> list[Agent]:
-        return [a for a in self.agents if not a.is_empty]
-
-    @property
-    def empty_agents(self) -> list[Agent]:
-        return [a for a in self.agents if a.is_empty]
+    agents = property(lambda self: self._agents_where())
+    non_empty_agents = property(lambda self: self._agents_where(empty=False))
+    empty_agents = property(lambda self: self._agents_where(empty=True))
 
     @property
     def done(self) -> bool:
-        return all([a.done for a in self.agents])
+        """every agent of the manager has finished its episode"""
+        for ag in self.agents_dict.values():
+            if not ag.done:
+                return False
+        return True
 
     @property
     def max_reached(self) -> bool:
-        return any([a.max_reached for a in self.non_empty_agents])
+        """some running (non-empty) agent has hit its step limit"""
+        for ag in self._agents_where(empty=False):
+            if ag.max_reached:
+                return True
+        return False
 
     def set_config(self, config) -> None:
         self.config = deepcopy(config)
 
     def set_model_abs_dir(self, model_abs_dir: Path) -> None:
-        model_abs_dir.mkdir(parents=True, exist_ok=True)
         self.model_abs_dir = model_abs_dir
+        self.model_abs_dir.mkdir(parents=True, exist_ok=True)
 
     def set_rl(self, rl: SAC_Base) -> None:
         self.rl = rl

@@ -325,12 +325,16 @@ def fused_mse_loss(workspace: torch.Tensor, grad_scale: float = 1.0):
     backwards a fill and another elementwise pass).  Every other call goes to the original function.  `workspace`: the
     caller's zeroed `native.mse_mean_grad_workspace()` floats; `grad_scale`: the constant the caller will multiply the
     loss with (`sac_aux._DivConstFn`), folded into the stored gradient."""
+    import threading
     from asac_amd import native
     F = torch.nn.functional
     orig = F.mse_loss
+    owner = threading.get_ident()      # the module attribute is process-global: only the learner's own thread is rerouted —
+    #                                    an agent / evaluation thread calling `F.mse_loss` meanwhile gets the original (it must
+    #                                    not touch the learner's workspace or inherit its grad_scale)
 
     def mse_loss(input, target, *args, **kwargs):
-        if (not args and not kwargs and isinstance(input, torch.Tensor) and isinstance(target, torch.Tensor)
+        if (threading.get_ident() == owner and not args and not kwargs and isinstance(input, torch.Tensor) and isinstance(target, torch.Tensor)
                 and input.dim() >= 3 and input.shape == target.shape and input.numel() >= MSE_INTERCEPT_MIN
                 and input.requires_grad and not target.requires_grad and torch.is_grad_enabled() and input.is_contiguous()):
             B, T = input.shape[:2]
@@ -388,41 +392,31 @@ class DeviceNoise:
                            for t in (u, flat, subsets) if t is not None]
 
     def begin_step_with_sample(self, step_counter, rb, flat, subsets=None, ensemble: int = 0, polyak=None,
-                               zero=None, gather: bool = False, defer_weights: bool = False) -> int:
+                               zero=None, defer_weights: bool = False) -> int:
         """`begin_step` and the replay buffer's stratified sample (`rb.sample_into_static`'s tree walk) as ONE launch
         when that form applies (this source feeds the sampler, batch <= 1024); with a sharded replay
         (`rb.min_ratio_reducer`) the launch leaves the IS weights to `rb.sample_into_static`, which needs the MIN over
         ranks first;  -> 0 (not applicable), 1 (sampled: the caller runs only the buffer's weights / gather) or, with
-        `gather`, 2: the window gather of the drawn batch was part of the same launch too
-        (`asac_step_prologue_sample_gather`); with `defer_weights` and a batch of 257 .. 1 024 on one GPU, 3: sampled, and
-        the IS weights are left to the gather's launch (`rb.sample_into_static(sampled=3)`: `asac_window_gather_pad_w`)."""
+        `defer_weights` and a batch of 257 .. 1 024 on one GPU, 3: sampled, and the IS weights are left to the gather's
+        launch (`rb.sample_into_static(sampled=3)`: `asac_window_gather_pad_w`)."""
         if (rb.uniform_source is not self or rb.sharded is not None
                 or rb.batch_size > native.PROLOGUE_SAMPLE_MAX_BATCH):
             return 0
         if subsets is not None and subsets.shape[1] == ensemble:
             subsets = None
-        gather = gather and rb._gather_keys is not None
-        if (defer_weights and not gather and rb.min_ratio_reducer is None and rb.batch_size > 256
-                and rb._gather_keys is not None):
+        if defer_weights and rb.min_ratio_reducer is None and rb.batch_size > 256 and rb._gather_keys is not None:
             native.step_prologue_sample_partial(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
                                                 rb.capacity, rb.batch_size, rb._slot_ids, rb._leaf, rb._p, rb._ids, rb._min_p)
             self._prefilled = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
                                for t in (rb._u, flat, subsets) if t is not None]
             return 3
-        if gather:
-            native.step_prologue_sample_gather(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
-                                               rb.capacity, rb.batch_size, rb._slot_ids, rb._beta,
-                                               rb.beta_increment_per_sampling, rb._leaf, rb._p, rb._ids,
-                                               rb._w if rb.min_ratio_reducer is None else None, rb._min_p,
-                                               rb._gather_keys, rb.prev_n, rb.post_n, rb._index_ring())
-        else:
-            native.step_prologue_sample(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
-                                        rb.capacity, rb.batch_size, rb._slot_ids, rb._beta, rb.beta_increment_per_sampling,
-                                        rb._leaf, rb._p, rb._ids, rb._w if rb.min_ratio_reducer is None else None,
-                                        rb._min_p)
+        native.step_prologue_sample(polyak, zero, self.seed, step_counter, rb._u, flat, subsets, ensemble, rb._tree,
+                                    rb.capacity, rb.batch_size, rb._slot_ids, rb._beta, rb.beta_increment_per_sampling,
+                                    rb._leaf, rb._p, rb._ids, rb._w if rb.min_ratio_reducer is None else None,
+                                    rb._min_p)
         self._prefilled = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size())
                            for t in (rb._u, flat, subsets) if t is not None]
-        return 2 if gather else 1
+        return 1
 
     def uniform_(self, buf: torch.Tensor) -> None:
         if not self._covered(buf):

@@ -155,7 +155,8 @@ def rows_resblock(block, x):
     lin = block.linear
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and type(block.act) is nn.GELU
             and getattr(block.act, 'approximate', 'none') == 'none' and lin.bias is not None and x.dim() >= 2
-            and x.shape[-1] == lin.in_features and x.numel() // lin.in_features >= MIN_ROWS and x.stride(-1) == 1):
+            and x.shape[-1] == lin.in_features and x.numel() // lin.in_features >= MIN_ROWS and x.stride(-1) == 1
+            and lin.weight.data_ptr() % 16 == 0 and lin.bias.data_ptr() % 16 == 0):      # (16-byte vector reads of the parameters)
         return None
     from asac_amd import native
     if not block.residual:

@@ -602,15 +602,25 @@ def _plain_resblock(ll, width):
         return None
     rb = mods[0]
     if not (rb.residual and type(rb.act) is nn.GELU and getattr(rb.act, 'approximate', 'none') == 'none'
-            and rb.linear.bias is not None and rb.linear.in_features == rb.linear.out_features == width):
+            and rb.linear.bias is not None and rb.linear.in_features == rb.linear.out_features == width
+            and _params_aligned16(rb.linear)):
         return None
     return rb.linear
+
+
+def _params_aligned16(linear) -> bool:
+    """The MFMA row kernels read weights and biases as 16-byte vectors and reject anything else (`bad_arg` -> AsacNativeError).
+    Parameters are views packed back to back in the learner's flat buffer: only SEGMENT starts are aligned, so a plugin
+    whose model holds an earlier parameter of numel % 4 != 0 (a scalar gate, an odd-width Linear) shifts everything behind
+    it — such layers take the nn.Linear path instead of crashing in forward."""
+    return (linear.weight.data_ptr() % 16 == 0 and linear.weight.is_contiguous()
+            and (linear.bias is None or (linear.bias.data_ptr() % 16 == 0 and linear.bias.is_contiguous())))
 
 
 def _plain_linear(ll):
     """the single nn.Linear (with bias) of a `LinearLayers` stack that is nothing else, or None"""
     mods = [m for m in ll.dense if not (isinstance(m, nn.Dropout) and m.p == 0)]
-    if len(mods) == 1 and type(mods[0]) is nn.Linear and mods[0].bias is not None:
+    if len(mods) == 1 and type(mods[0]) is nn.Linear and mods[0].bias is not None and _params_aligned16(mods[0]):
         return mods[0]
     return None
 

@@ -237,10 +237,6 @@ class SAC_Base(AuxHeadsMixin):
         self._twin_rep = bool(hip_config.get('twin_rep', True))
         self._fuse_linear_tanh = bool(hip_config.get('fused_linear_tanh', True))
         self._use_sidecars = bool(hip_config.get('sidecars', True))
-        # asac_step_prologue_sample_gather (sampler + window gather in one launch).  Off: A/B on one box (cfg2, 3 x 20 000
-        # steps each) 11 567 steps/s with it against 11 664 without, although the merged launch is 1.8 us shorter than the two
-        # under rocprofv3 — the gather's workgroups sleep and poll for the ids ~2.5 us, about what a launch boundary costs
-        self._prologue_gather = bool(hip_config.get('prologue_gather', False))
         # batches of 257 .. 1 024: the IS weights in an extra workgroup of the gather's launch instead of behind an exchange
         # between the sampler's workgroups (asac_step_prologue_sample_partial + asac_window_gather_pad_w)
         self._defer_is_weights = bool(hip_config.get('defer_is_weights', True))
@@ -267,13 +263,9 @@ class SAC_Base(AuxHeadsMixin):
         # one sampled batch in flight, the reference's schedule (replay_buffer.py:275, 339-396): see `_step_sample`
         self._lookahead = int(hip_config.get('lookahead', 0))
         assert self._lookahead in (0, 1), 'hip_config lookahead: 0 (synchronous sampling) or 1 (one batch in flight)'
-        self._la_branch = bool(hip_config.get('lookahead_branch', False))   # a graph branch for the draw: measured slower
-        # the target representation's pass over the window beside the online one: a second stream (a branch of the captured
-        # graph) — the passes share nothing but their inputs; for representations without a twin launch (GRU layers have one).
-        # Measured SLOWER (cfg4 3 015 -> 2 461, cfg5 444 -> 434, cfg4_84 900 -> 883 steps/s: a fork / join inside a replayed
-        # graph costs more than the small launches it hides) — off, as `lookahead_branch`
-        self._rep_branch = bool(hip_config.get('rep_branch', False))
-        self._rep_stream = None
+        # (graph branches — the next batch's draw, the target representation's pass — on a second stream were measured
+        # slower than the launches in line and are gone: a fork / join inside a replayed hipGraph costs more than the small
+        # launches it hides, NOTES.md section 1 rounds 4 / 5)
         self._la_gather_sidecar = bool(hip_config.get('lookahead_gather_sidecar', True)) and self._use_sidecars
         self._la_gather = None
         self._fuse_prediction_dense = bool(hip_config.get('fuse_prediction_dense', True))
@@ -326,7 +318,7 @@ class SAC_Base(AuxHeadsMixin):
         self._graph = None
         self._graph_hp, self._all_optimizers = None, None     # `_optimizer_hp()` the captured graphs were made with
         self._graph_runs = {}           # run length -> (the step graph it was captured beside, graph, exec handle)
-        self._la_graphs, self._la_stream, self._la_pending = {}, None, False      # hip_config['lookahead']
+        self._la_graphs = {}      # hip_config['lookahead']
         self._graph_failed = False
         self._eager_steps = 0
 
@@ -1747,9 +1739,6 @@ class SAC_Base(AuxHeadsMixin):
             self._opt_steps.add_(1)
 
     def _join_lookahead(self) -> None:
-        if self._la_pending:
-            torch.cuda.current_stream().wait_stream(self._la_stream)
-            self._la_pending = False
         if self._la_gather is not None:      # no launch hosted the next batch's gather: on its own, before any write-back
             self._la_gather = None
             self.replay_buffer.gather_next_now()
@@ -1770,10 +1759,10 @@ class SAC_Base(AuxHeadsMixin):
         zero = None if self._grads_overwrite else self._params.grad
         if self._lookahead:
             # the batch this step trains on was drawn during the previous step (`train` swapped the sets); the NEXT one
-            # is drawn now, from the tree and the rows as the previous step left them, beside this step's launches: a
-            # second stream (a branch of the captured graph) that joins before this step's first write to the replay
+            # is drawn now, from the tree and the rows as the previous step left them, before this step's first write to
+            # the replay
             sampled = False
-            if self._use_sidecars and not self._la_branch:
+            if self._use_sidecars:
                 # the prologue launch hosts the NEXT batch's tree walk (its sampler workgroup), as in the plain schedule
                 rb.swap_sets()
                 try:
@@ -1784,25 +1773,17 @@ class SAC_Base(AuxHeadsMixin):
             if not sampled:
                 self.noise.begin_step(self._opt_steps, rb.next_uniforms() if rb.uniform_source is self.noise else None,
                                       self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
-            if self._la_branch:
-                if self._la_stream is None:
-                    self._la_stream = torch.cuda.Stream(device=self.device)
-                self._la_stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._la_stream):
-                    rb.sample_next_into_static()
-                self._la_pending = True
+            if sampled and self._la_gather_sidecar:
+                # ... and its window gather rides as extra workgroups of the step's first policy / critic launch
+                # (`_take_la_gather`; `_join_lookahead` runs it on its own if no launch took it)
+                self._la_gather = rb.next_gather_sidecar()
             else:
-                if sampled and self._la_gather_sidecar:
-                    # ... and its window gather rides as extra workgroups of the step's first policy / critic launch
-                    # (`_take_la_gather`; `_join_lookahead` runs it on its own if no launch took it)
-                    self._la_gather = rb.next_gather_sidecar()
-                else:
-                    rb.sample_next_into_static(sampled=sampled)      # same launches, in line (no graph branch)
+                rb.sample_next_into_static(sampled=sampled)      # same launches, in line
         else:
-            # ... and the sampler and the window gather of the batch it draws (`prologue_gather`): one launch for K1-K3 + K5
+            # ... and the sampler of the batch it draws: one launch for K1 + K2 + K5
             sampled = self._use_sidecars and self.noise.begin_step_with_sample(
                 self._opt_steps, rb, self._eps_all, self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero,
-                gather=self._prologue_gather, defer_weights=self._defer_is_weights)
+                defer_weights=self._defer_is_weights)
             if not sampled:
                 self.noise.begin_step(self._opt_steps, rb._u if rb.uniform_source is self.noise else None, self._eps_all,
                                       self._subsets_all, self.ensemble_q_num, polyak=polyak, zero=zero)
@@ -1862,22 +1843,11 @@ class SAC_Base(AuxHeadsMixin):
             tail = lambda x: None if x is None else x[:, b:]  # noqa: E731
             idx, pad, obs, pre, hidden = w.rep_in
             rep_in, pb = (tail(idx), tail(pad), [o[:, b:] for o in obs], tail(pre), tail(hidden)), 0
-        branch = self._rep_branch and not self._rep_twin and w.rep_trainable
         with (self._rep_twin if self._rep_twin else contextlib.nullcontext()), cat_mode():
-            if branch:
-                if self._rep_stream is None:
-                    self._rep_stream = torch.cuda.Stream(device=self.device)
-                main = torch.cuda.current_stream()
-                self._rep_stream.wait_stream(main)
-                with torch.cuda.stream(self._rep_stream), torch.no_grad():
-                    w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
             with torch.no_grad() if one_position else contextlib.nullcontext():
                 bnx_states, next_hidden = self.get_l_states(*rep_in, is_target=False)
-            if branch:
-                main.wait_stream(self._rep_stream)
-            else:
-                with torch.no_grad():
-                    w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
+            with torch.no_grad():
+                w.bnx_target_states, _ = self.get_l_states(*rep_in, is_target=True)
         w.nx_target_states = w.bnx_target_states[:, pb:]
         state_base = (bnx_states, pb)
         if one_position:

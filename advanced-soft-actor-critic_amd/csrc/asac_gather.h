@@ -49,13 +49,7 @@ struct GatherLaunch {
     GatherArgs c;
 };
 
-// `COH`: the ids are written by OTHER workgroups of the same launch (the merged prologue / sampler / gather launch): read
-// them past the non-coherent caches (agent-scope atomic load), never through the scalar cache
-template <bool COH>
-__device__ __forceinline__ int64_t load_id(const int64_t* ids, int s) {
-    if (COH) return __hip_atomic_load(const_cast<int64_t*>(ids) + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ids[s];
-}
+__device__ __forceinline__ int64_t load_id(const int64_t* ids, int s) { return ids[s]; }
 
 __device__ __forceinline__ bool row_valid(const GatherArgs& a, int64_t id, int j) {
     if (j == a.prev_n) return true;
@@ -101,7 +95,7 @@ template <> __device__ __forceinline__ uint4 zero_unit<uint4>() { return make_ui
 template <typename Unit> __device__ __forceinline__ Unit next_index(Unit v) { return v; }
 template <> __device__ __forceinline__ uint32_t next_index<uint32_t>(uint32_t v) { return v + (v != 0xffffffffu ? 1u : 0u); }
 
-template <typename Unit, int kUnroll, bool COH>
+template <typename Unit, int kUnroll>
 __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                            int64_t total_units) {
     // g indexes units of the dense destination [B, L, units_per_row]
@@ -118,7 +112,7 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
         at[r] = row * k.dst_pitch + (int64_t)w * (int)sizeof(Unit);
         const int sample = (int)(row / a.L);
         const int j = (int)(row - (int64_t)sample * a.L);
-        const int64_t id = load_id<COH>(a.ids, sample);
+        const int64_t id = load_id(a.ids, sample);
         // the row is read whether or not it turns out to belong to the centre row's episode (the slot is always a
         // valid address): the validity test's own loads — random reads of the index ring — travel WITH the data
         // instead of in front of it
@@ -136,7 +130,7 @@ __device__ __forceinline__ void copy_units(const GatherArgs& a, const GatherKeyD
 }
 
 // conversion path: 4 source bytes -> 4 floats (uint8/255 or bool)
-template <int kUnroll, bool COH>
+template <int kUnroll>
 __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherKeyDev& k, int64_t g0,
                                               int64_t total_units) {
 #pragma unroll
@@ -147,7 +141,7 @@ __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherK
         const int w = (int)(g - row * k.units_per_row);
         const int sample = (int)(row / a.L);
         const int j = (int)(row - (int64_t)sample * a.L);
-        const int64_t id = load_id<COH>(a.ids, sample);
+        const int64_t id = load_id(a.ids, sample);
         const int slot = ring_slot(id + (j - a.prev_n), a.capacity);
         const uint8_t* srow = k.src + (int64_t)slot * k.row_bytes;
         float* drow = reinterpret_cast<float*>(k.dst + row * k.dst_pitch);
@@ -170,7 +164,7 @@ __device__ __forceinline__ void convert_units(const GatherArgs& a, const GatherK
 }
 
 // workgroup `block` of a gather launch: its key `k` and the shared arguments `a`
-template <int kUnroll, bool COH = false>
+template <int kUnroll>
 __device__ __forceinline__ void gather_work(const GatherArgs& a, const GatherKeyDev& k, unsigned block) {
     const int64_t rows = (int64_t)a.batch * a.L;
     const int64_t total_units = rows * k.units_per_row;
@@ -183,28 +177,28 @@ __device__ __forceinline__ void gather_work(const GatherArgs& a, const GatherKey
             if (g >= rows) continue;
             const int sample = (int)(g / a.L);
             const int j = (int)(g - (int64_t)sample * a.L);
-            k.dst[g] = row_valid(a, load_id<COH>(a.ids, sample), derived_row(k.derive, j, a.L)) ? 0 : 1;
+            k.dst[g] = row_valid(a, load_id(a.ids, sample), derived_row(k.derive, j, a.L)) ? 0 : 1;
         }
         return;
     }
     if (k.convert != ASAC_CVT_NONE) {
-        convert_units<kUnroll, COH>(a, k, g0, total_units);
+        convert_units<kUnroll>(a, k, g0, total_units);
         return;
     }
-    if (k.unit_log2 == 4) copy_units<uint4, kUnroll, COH>(a, k, g0, total_units);
-    else if (k.unit_log2 == 2) copy_units<uint32_t, kUnroll, COH>(a, k, g0, total_units);
-    else copy_units<uint8_t, kUnroll, COH>(a, k, g0, total_units);
+    if (k.unit_log2 == 4) copy_units<uint4, kUnroll>(a, k, g0, total_units);
+    else if (k.unit_log2 == 2) copy_units<uint32_t, kUnroll>(a, k, g0, total_units);
+    else copy_units<uint8_t, kUnroll>(a, k, g0, total_units);
 }
 
 // workgroup `block` of a gather launch described by `m` (read from the kernel arguments or from device memory)
-template <int NK, int kUnroll, bool COH = false>
+template <int NK, int kUnroll>
 __device__ __forceinline__ void gather_block(const GatherLaunch<NK>& m, unsigned block) {
     // which key does this block belong to?  (<= 16 entries, wave-uniform scan)
     int ki = 0;
 #pragma unroll 1
     for (int q = 1; q < m.c.n_keys; ++q)
         if (block >= m.key[q].first_block) ki = q;
-    gather_work<kUnroll, COH>(m.c, m.key[ki], block);
+    gather_work<kUnroll>(m.c, m.key[ki], block);
 }
 
 // host: the launch description of a window gather (key table, shared arguments, workgroups per key); force_unroll 0:

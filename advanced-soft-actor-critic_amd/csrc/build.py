@@ -41,6 +41,14 @@ def _headers():
     return sorted(CSRC.glob('*.h')) + [REPO / 'include' / 'asac_hip.h']
 
 
+def source_hash() -> str:
+    """Content hash of everything libasac_hip.so is built from (every source, every header, the flags), 16 hex digits.
+    Stamped into the committed profile summaries (`profiles/*_kernel_stats.json`, `*_pmc_traffic.json`: key `_meta`) by
+    tools/summarize_rocprof.py / summarize_pmc.py; bench.py quotes a committed duration only when its stamp equals the
+    hash of the tree it runs from."""
+    return _digest([CSRC / s for s in SOURCES], [_digest(_headers(), FLAGS)])[:16]
+
+
 def _stale_sources(obj_dir: Path):
     """Sources whose object is missing or was built from other text: the decision is by CONTENT (source + every header +
     flags, recorded beside the object), not by mtime — a checkout whose library happens to be newer than its sources is

@@ -58,14 +58,9 @@ struct SampleDraw {
 // have arrived (they are the first workgroups of the grid: resident before anything else of the launch is, and what
 // they wait for is finite work of each other); the last one to LEAVE clears the counters for the next launch and
 // publishes beta (nobody reads the old value after that).  Per sample: the same comparisons in the same order.
-constexpr int kFlagLines = 32;       // the gather workgroups' "ids are stored" flags: word 16 * (1 + f) of min_p_out,
-constexpr int kFlagStride = 16;      // i.e. one per 64-byte line behind the line that holds the counters
-constexpr unsigned kGatherWgsMax = 2048;   // persistent gather workgroups of the merged launch (8 per CU)
-constexpr uint64_t kMergedGatherMaxBlocks = 1024;   // larger gathers: two launches (asac_step_prologue_sample_gather)
-struct SampleSync {            // min_p_out[2..]: floats [2..5] partial minima, [6] arrivals, [7] departures,
-    float part[4];             // [8] sampler workgroups whose ids are stored, [9] gather workgroups that have read them
-    unsigned int arrived, left;    // (the merged prologue / sampler / gather launch); all counters 0 between launches
-    unsigned int ids_ready, gather_done;
+struct SampleSync {            // min_p_out[2..]: floats [2..5] partial minima, [6] arrivals, [7] departures;
+    float part[4];             // all counters 0 between launches
+    unsigned int arrived, left;
 };
 // The exchange uses RELAXED agent-scope atomics only (sc1: performed at the device's coherence point, past the XCD's L2)
 // and orders them by waiting for their completion (`s_waitcnt 0`).  An agent-scope RELEASE would do it too, but on this
@@ -77,7 +72,7 @@ __device__ __forceinline__ void sync_store(float* p, float v) { __hip_atomic_sto
 __device__ __forceinline__ float sync_load(float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <bool FUSE_WEIGHTS, bool STAGE_TOP, bool DRAW = false, bool EXPLICIT = false, int TRIPS = kFusedSampleMax / kSampleBlock,
-          bool MULTI = false, bool PUBLISH = false, int LDS_LEVELS = kLdsLevels, bool PARTIAL = false>
+          bool MULTI = false, int LDS_LEVELS = kLdsLevels, bool PARTIAL = false>
 __device__ __forceinline__ void sumtree_sample_body(
     const float* __restrict__ tree, int capacity, int levels, int batch,
     double* __restrict__ u, const int64_t* __restrict__ slot_ids, double* beta_state,
@@ -253,29 +248,10 @@ __device__ __forceinline__ void sumtree_sample_body(
         p_reg[trip] = p;
     }
 
-    // `PUBLISH`: window-gather workgroups of the SAME launch wait for the ids (k_prologue_sample_gather): stored first,
-    // made visible, counted — the minimum, the weights and beta follow while the gather is already running
-    if (PUBLISH) {
-#pragma unroll
-        for (int trip = 0; trip < kTrips; ++trip) {
-            const int i = first + trip * kSampleBlock;
-            if (live_[trip]) __hip_atomic_store(ids_out + i, id_reg[trip], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        sync_complete();
-    }
     // batch minimum of p (per block -> global)
     float m = wave_min(pmin);
     if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
     __syncthreads();
-    if (PUBLISH && threadIdx.x == 0) {
-        const unsigned n_pub = (unsigned)((batch + kSampleBlock - 1) / kSampleBlock);
-        const unsigned before = __hip_atomic_fetch_add(&reinterpret_cast<SampleSync*>(min_p_out + 2)->ids_ready, 1u,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (before == n_pub - 1)        // all ids are stored: raise the gather's flags (one word per cache line)
-            for (int f = 0; f < kFlagLines; ++f)
-                __hip_atomic_store(reinterpret_cast<unsigned*>(min_p_out) + kFlagStride * (1 + f), 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-    }
     SampleSync* const sync = MULTI ? reinterpret_cast<SampleSync*>(min_p_out + 2) : nullptr;
     const unsigned n_wg = MULTI ? (unsigned)((batch + kSampleBlock - 1) / kSampleBlock) : 1u;
     if (PARTIAL) {
@@ -352,12 +328,10 @@ __device__ __forceinline__ void sumtree_sample_body(
             if (i < batch) w_out[i] = is_weight(p_reg[trip], root, min_ratio, b);
         }
     }
-    if (!PUBLISH) {
 #pragma unroll
-        for (int trip = 0; trip < kTrips; ++trip) {
-            const int i = first + trip * kSampleBlock;
-            if (live_[trip]) ids_out[i] = id_reg[trip];
-        }
+    for (int trip = 0; trip < kTrips; ++trip) {
+        const int i = first + trip * kSampleBlock;
+        if (live_[trip]) ids_out[i] = id_reg[trip];
     }
 }
 
@@ -387,118 +361,15 @@ __global__ __launch_bounds__(kSampleBlock) void k_prologue_sample(
         // (thirteen staged levels, 32 KB: trees of 2^16 / 2^19 leaves keep 3 / 6 levels for memory — one / two round trips
         // of three levels each, one less than with twelve; the launch has a handful of other workgroups, LDS is free)
         if (n_s == 1)
-            sumtree_sample_body<true, true, true, false, 1, false, false, 13>(
+            sumtree_sample_body<true, true, true, false, 1, false, 13>(
                 tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment, leaf_out, p_out, ids_out, w_out,
                 min_p_out, dr);
         else
-            sumtree_sample_body<true, true, true, false, 1, true, false, 13, PARTIAL>(
+            sumtree_sample_body<true, true, true, false, 1, true, 13, PARTIAL>(
                 tree, capacity, levels, batch, pa.u, slot_ids, beta_state, beta_increment, leaf_out, p_out, ids_out, w_out,
                 min_p_out, dr);
     } else {
         prologue_block(pa, (int)blockIdx.x - n_s, true);
-    }
-}
-
-// The step prologue, the sampler AND the window gather (K1 + K2 + K3 + K5) as one launch: workgroups [0, n_s) sample,
-// [n_s, n_s + gather_blocks) are the gather's — each waits (one lane polling, the rest at the barrier) until all n_s
-// sampler workgroups have stored their ids, which happens before the sampler turns to the minimum and the weights —,
-// the rest are the prologue's workers.  The sampler workgroups come first in the grid: they are resident before any
-// gather workgroup is, so what the gather waits for always makes progress.  The last gather workgroup to have read its
-// ids clears the two counters for the next launch.  Saves one dependent launch (~4.4 us inside a replayed graph) and
-// hides the sampler's tail (minimum exchange, f64 powers) and the gather's ramp-up behind each other.
-// Every workgroup of a launch is given the kernel's LDS, used or not: with the 16 KB tree top of the stand-alone sampler
-// the gather's workgroups were held to 3-4 per CU (1 024 persistent workgroups were the optimum and the gather ran at
-// half its stand-alone rate).  Eleven staged levels (8 KB) cost no extra round trip for trees of 2^16 (5 levels left:
-// 3 + 2) or 2^19 leaves (8 left: 3 + 3 + 2) against twelve (4: 3 + 1; 7: 3 + 3 + 1).
-constexpr int kMergedLdsLevels = 11;
-struct SamplerArgs {
-    const float* tree;
-    int capacity, levels, batch;
-    const int64_t* slot_ids;
-    double* beta_state;
-    double beta_increment;
-    int32_t* leaf_out;
-    float* p_out;
-    int64_t* ids_out;
-    float* w_out;
-    float* min_p_out;
-};
-
-template <int NK>
-struct MergedArgs {
-    PrologueArgs pa;
-    SamplerArgs sa;
-    GatherLaunch<NK> m;
-    unsigned gather_blocks, gather_wgs;
-};
-
-// (the ~0.8 KB of arguments are read from the kernarg segment BY ROLE, asac_common.h ASAC_KARG: as by-value parameters
-// they were loaded whole at entry by every workgroup — 106 SGPRs, spills into scratch)
-template <int NK, int kUnroll>
-__global__ __launch_bounds__(kSampleBlock) void k_prologue_sample_gather(const MergedArgs<NK> by_value) {
-    static_assert(kGatherBlock == kSampleBlock, "one block size for the three roles");
-    const ASAC_KARG MergedArgs<NK>& A = *static_cast<const ASAC_KARG MergedArgs<NK>*>(kernarg_base());
-    const unsigned n_s = (unsigned)((A.sa.batch + kSampleBlock - 1) / kSampleBlock);
-    const unsigned gather_blocks = A.gather_blocks, gather_wgs = A.gather_wgs;
-    if (blockIdx.x < n_s) {
-        const PrologueArgs pa = karg_copy(&A.pa);
-        const SamplerArgs sa = karg_copy(&A.sa);
-        const SampleDraw dr{pa.seed, pa.step, pa.n_normal};
-        if (n_s == 1)
-            sumtree_sample_body<true, true, true, false, 1, false, true, kMergedLdsLevels>(
-                sa.tree, sa.capacity, sa.levels, sa.batch, pa.u, sa.slot_ids, sa.beta_state, sa.beta_increment, sa.leaf_out,
-                sa.p_out, sa.ids_out, sa.w_out, sa.min_p_out, dr);
-        else
-            sumtree_sample_body<true, true, true, false, 1, true, true, kMergedLdsLevels>(
-                sa.tree, sa.capacity, sa.levels, sa.batch, pa.u, sa.slot_ids, sa.beta_state, sa.beta_increment, sa.leaf_out,
-                sa.p_out, sa.ids_out, sa.w_out, sa.min_p_out, dr);
-    } else if (blockIdx.x < n_s + gather_wgs) {
-        float* const min_p_out = A.sa.min_p_out;
-        // (round 5, first form: every one of ~3 000 gather workgroups polling ONE word every ~100 cycles: the sampler's own
-        // atomics on that cache line queued behind the flood — 256 us instead of 30.  Hence: a bounded number of
-        // persistent gather workgroups, sixteen flag words in sixteen cache lines, a first sleep of about the time the
-        // sampler needs anyway, and polls that are plain relaxed loads)
-        SampleSync* const sync = reinterpret_cast<SampleSync*>(min_p_out + 2);
-        const unsigned g = blockIdx.x - n_s;
-        if (threadIdx.x == 0) {
-            unsigned* const flag = reinterpret_cast<unsigned*>(min_p_out) + kFlagStride * (1 + (g & (kFlagLines - 1)));
-            __builtin_amdgcn_s_sleep(80);                  // ~5 000 clocks: the descent takes longer than that
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-        // (plain loads of the ids: nothing of this launch has read them before the flag — no cache holds an older copy —
-        // and the barrier keeps the loads behind the poll)
-        const GatherArgs ga = karg_copy(&A.m.c);
-        for (unsigned blk = g; blk < gather_blocks; blk += gather_wgs) {
-            int ki = 0;
-#pragma unroll 1
-            for (int q = 1; q < ga.n_keys; ++q)
-                if (blk >= A.m.key[q].first_block) ki = q;
-            const GatherKeyDev key = karg_copy(&A.m.key[ki]);
-            gather_work<kUnroll, false>(ga, key, blk);
-        }
-        // every workgroup counts itself out on ITS flag line (word 1 of the line); the last of a line counts the line out,
-        // the last line clears the flags.  (One counter for all: the persistent workgroups finish together, and ~1 000
-        // returning atomics on one word are ~10 us of serial work at the device's coherence point.)
-        if (threadIdx.x == 0) {
-            const unsigned f = g & (kFlagLines - 1);
-            unsigned* const line = reinterpret_cast<unsigned*>(min_p_out) + kFlagStride * (1 + f);
-            const unsigned on_line = (gather_wgs - f + kFlagLines - 1) / kFlagLines;
-            if (__hip_atomic_fetch_add(line + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == on_line - 1) {
-                __hip_atomic_store(line + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned lines = gather_wgs < (unsigned)kFlagLines ? gather_wgs : (unsigned)kFlagLines;
-                if (__hip_atomic_fetch_add(&sync->gather_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lines - 1) {
-                    for (int q = 0; q < kFlagLines; ++q)
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(min_p_out) + kFlagStride * (1 + q), 0u,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&sync->ids_ready, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&sync->gather_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    } else {
-        const PrologueArgs pa = karg_copy(&A.pa);
-        prologue_block(pa, (int)(blockIdx.x - n_s - gather_wgs), true);
     }
 }
 
@@ -885,75 +756,6 @@ int asac_step_prologue_sample_partial(float* target, const float* source, int64_
     return prologue_sample_launch(target, source, n_polyak, tau, zero_out, n_zero, seed, step_counter, uniform_out, normal_out,
                                   n_normal, subsets_out, n_subsets, E_sample, E, tree, capacity, batch, slot_ids, &unused_beta,
                                   0.0, leaf_out, p_out, ids_out, nullptr, min_p_out, true, stream);
-}
-
-int asac_step_prologue_sample_gather(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
-                                     int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
-                                     float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets,
-                                     int E_sample, int E, const float* tree, int capacity, int batch,
-                                     const int64_t* slot_ids, double* beta_state, double beta_increment, int32_t* leaf_out,
-                                     float* p_out, int64_t* ids_out, float* is_weights_out, float* min_p_out,
-                                     const asac_gather_key_t* keys_host, int n_keys, int prev_n, int post_n,
-                                     const int32_t* index_ring, void* stream) {
-    if (!step_counter || n_normal < 0 || n_subsets < 0 || n_polyak < 0 || n_zero < 0 || !uniform_out ||
-        (n_polyak > 0 && (!target || !source)) || (n_zero > 0 && !zero_out) || (n_normal > 0 && !normal_out))
-        return bad_arg("asac_step_prologue_sample_gather");
-    if (n_subsets > 0 && (!subsets_out || E_sample < 1 || E_sample > E || E > ASAC_MAX_ENSEMBLE))
-        return bad_arg("asac_step_prologue_sample_gather: subsets");
-    if (capacity <= 0 || (capacity & (capacity - 1)) || batch <= 0 || batch > kFusedSampleMax ||
-        !min_p_out || !tree || !slot_ids || !beta_state || !ids_out)
-        return bad_arg("asac_step_prologue_sample_gather: sampler");
-    GatherLaunch<ASAC_MAX_GATHER_KEYS> m{};
-    uint64_t gblocks = 0;
-    int unroll = 0;
-    if (const int rc = gather_fill(keys_host, n_keys, ids_out, batch, prev_n, post_n, capacity, index_ring, 0, m, &gblocks, &unroll))
-        return rc;
-    // A gather of megabytes is better off as its own launch: measured inside the replayed step (round 5, cfg4 / cfg5:
-    // 100 / 200 MB) the merged form took 35 / 58 us against 10 + 24 / 11 + 42 us for the two launches — thousands of
-    // workgroups start by polling and end by counting themselves out, and what the merge saves (one launch boundary,
-    // ~4.4 us) is small beside a 25-40 us gather.  At the BASELINE batch (a gather of tens of workgroups) it is the
-    // other way round: 9.3 us against 6.3 + 4.9.
-    if (gblocks > kMergedGatherMaxBlocks) {
-        if (const int rc = asac_step_prologue_sample(target, source, n_polyak, tau, zero_out, n_zero, seed, step_counter,
-                                                     uniform_out, normal_out, n_normal, subsets_out, n_subsets, E_sample, E,
-                                                     tree, capacity, batch, slot_ids, beta_state, beta_increment, leaf_out,
-                                                     p_out, ids_out, is_weights_out, min_p_out, stream))
-            return rc;
-        return asac_window_gather_pad(keys_host, n_keys, ids_out, batch, prev_n, post_n, capacity, index_ring, stream);
-    }
-    const int64_t lanes = (n_normal + 3) / 4 + (batch + 1) / 2 + n_subsets;
-    const int64_t pb = prologue_span_blocks(n_polyak), zb = prologue_span_blocks(n_zero);
-    const float one_m_tau = (float)(1.0 - (double)tau);
-    const SamplerArgs sa0{tree, capacity, ilog2(capacity), batch, slot_ids, beta_state, beta_increment,
-                          leaf_out, p_out, ids_out, is_weights_out, min_p_out};
-    const unsigned n_s = (unsigned)((batch + kSampleBlock - 1) / kSampleBlock);
-    for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: Polyak and the beta advance in the first only)
-        const int blocks_p = rep == 0 ? (int)pb : 0;
-        const PrologueArgs a{seed, step_counter, uniform_out, batch, normal_out, n_normal, subsets_out, n_subsets, E_sample,
-                             E, blocks_p, target, source, n_polyak, one_m_tau, tau, (int)zb, zero_out, n_zero};
-        SamplerArgs sa = sa0;
-        if (rep > 0) sa.beta_increment = 0.0;
-        const unsigned gwgs = gblocks < kGatherWgsMax ? (unsigned)gblocks : kGatherWgsMax;
-        const dim3 grid((unsigned)(n_s + gwgs + blocks_p + zb + (lanes + 255) / 256));
-        if (n_keys <= 8) {
-            MergedArgs<8> A8{a, sa, {}, (unsigned)gblocks, gwgs};
-            for (int q = 0; q < n_keys; ++q) A8.m.key[q] = m.key[q];
-            A8.m.c = m.c;
-            if (unroll == 1)
-                hipLaunchKernelGGL((k_prologue_sample_gather<8, 1>), grid, dim3(kSampleBlock), 0, as_stream(stream), A8);
-            else
-                hipLaunchKernelGGL((k_prologue_sample_gather<8, kUnrollLarge>), grid, dim3(kSampleBlock), 0, as_stream(stream), A8);
-        } else {
-            const MergedArgs<ASAC_MAX_GATHER_KEYS> A16{a, sa, m, (unsigned)gblocks, gwgs};
-            if (unroll == 1)
-                hipLaunchKernelGGL((k_prologue_sample_gather<ASAC_MAX_GATHER_KEYS, 1>), grid, dim3(kSampleBlock), 0,
-                                   as_stream(stream), A16);
-            else
-                hipLaunchKernelGGL((k_prologue_sample_gather<ASAC_MAX_GATHER_KEYS, kUnrollLarge>), grid, dim3(kSampleBlock), 0,
-                                   as_stream(stream), A16);
-        }
-    }
-    return finish_launch("asac_step_prologue_sample_gather");
 }
 
 int asac_per_is_weights(const float* p, int batch, const float* total, const float* min_ratio,

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 75
+ABI_VERSION = 76
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -363,11 +363,6 @@ _SIGNATURES = {
     'asac_window_gather_pad_w': (C.c_int, [C.POINTER(GatherKey), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                            C.c_void_p]),
-    'asac_step_prologue_sample_gather': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_uint64,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
-                                                   C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double,
-                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                   C.POINTER(GatherKey), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_graph_launch': (C.c_int, [C.c_void_p, C.c_void_p]),
     'asac_alpha_adam_step': (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -1719,29 +1714,6 @@ def window_gather_pad_w(keys, ids, batch, prev_n, post_n, capacity, index_ring, 
     _check(load().asac_window_gather_pad_w(keys, len(keys), _p(ids), batch, prev_n, post_n, capacity, _p(index_ring), _p(p),
                                            _p(tree), _p(beta_state), float(beta_increment), _p(is_weights_out),
                                            _p(min_p_out), _stream()), 'asac_window_gather_pad_w')
-
-
-@_profiled
-def step_prologue_sample_gather(polyak, zero, seed, step_counter, uniform_out, normal_out, subsets_out, ensemble, tree,
-                                capacity, batch, slot_ids, beta_state, beta_increment, leaf_out, p_out, ids_out,
-                                is_weights_out, min_p_out, keys, prev_n, post_n, index_ring):
-    """`step_prologue_sample` + `window_gather_pad(keys, ids_out, batch, ...)` in one launch (the gather's workgroups wait
-    for the ids inside the launch)."""
-    target_flat, source_flat, tau = polyak if polyak is not None else (None, None, 0.0)
-    assert uniform_out.numel() == batch and uniform_out.dtype == torch.float64 and batch <= PROLOGUE_SAMPLE_MAX_BATCH
-    assert min_p_out.numel() >= 528 and min_p_out.dtype == torch.float32
-    assert zero is None or (zero.is_contiguous() and zero.dtype == torch.float32)
-    nn_ = 0 if normal_out is None else normal_out.numel()
-    ns = es = 0
-    if subsets_out is not None:
-        assert subsets_out.dtype == torch.int32 and subsets_out.is_contiguous() and subsets_out.dim() == 2
-        ns, es = subsets_out.shape
-    _check(load().asac_step_prologue_sample_gather(
-        _p(target_flat), _p(source_flat), 0 if polyak is None else target_flat.numel(), float(tau), _p(zero),
-        0 if zero is None else zero.numel(), C.c_uint64(int(seed) & (2 ** 64 - 1)), _p(step_counter), _p(uniform_out),
-        _p(normal_out), nn_, _p(subsets_out), ns, es, int(ensemble), _p(tree), capacity, batch, _p(slot_ids),
-        _p(beta_state), float(beta_increment), _p(leaf_out), _p(p_out), _p(ids_out), _p(is_weights_out), _p(min_p_out),
-        keys, len(keys), prev_n, post_n, _p(index_ring), _stream()), 'asac_step_prologue_sample_gather')
 
 
 def graph_launch(graph_exec: int):

@@ -133,7 +133,6 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_window_gather_pad': 'asac::k_window_gather_pad', 'asac_vtrace_return_min': 'asac::k_vtrace_return_min',
               'asac_sumtree_sample': 'asac::k_sumtree_sample', 'asac_step_prologue_sample': 'asac::k_prologue_sample',
               'asac_step_prologue_sample_partial': 'asac::k_prologue_sample', 'asac_window_gather_pad_w': 'asac::k_window_gather_pad_w',
-              'asac_step_prologue_sample_gather': 'asac::k_prologue_sample_gather',
               'asac_sumtree_update': 'asac::k_sumtree_update', 'asac_squash_multi': 'asac::k_squash_multi',
               'asac_squash_sample_fwd': 'asac::k_squash_sample_fwd', 'asac_gru_forward': 'asac::k_gru_fwd',
               'asac_gru_backward': 'asac::k_gru_bwd', 'asac_scatter_rows_if_id_match': 'asac::k_scatter_write',
@@ -160,50 +159,86 @@ _KERNEL_OF = {'asac_mlp_forward': 'asac::k_mlp_fwd', 'asac_mlp_forward_multi': '
               'asac_gru_wide_forward': 'asac::gruw::k_gruw_fwd', 'asac_gru_wide_backward': 'asac::gruw::k_gruw_bwd',
               'asac_normal_nll_kl': 'asac::k_normal_nll_kl', 'asac_normal_nll_kl_logstd': 'asac::k_normal_nll_kl',
               'asac_masked_mse': 'asac::k_masked_mse'}
-SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_step_prologue_sample_partial', 'asac_step_prologue_sample_gather',
+SAMPLE_RETURN = ('asac_step_prologue_sample', 'asac_step_prologue_sample_partial',
                  'asac_sumtree_sample', 'asac_window_gather_pad', 'asac_window_gather_pad_w', 'asac_vtrace_return_min',
                  'asac_td_update')      # (the TD error's return, formed inside the priority update's launch: K4 + K6)
-ROUND = 'r05'
-_ROUNDS = ('r05', 'r04')      # newest committed summary wins; the source file is named in the line
+ROUND = 'r06'
 
 
-def pmc_traffic(config: str, kernel: str):
-    """(HBM bytes per launch, source) of a kernel (all template instances, launch-weighted), or (None, None): the PMC
+def library_hash() -> str:
+    """content hash of the library this process runs (sources + headers + flags: csrc/build.py `source_hash`)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('asac_build', ROOT / 'advanced-soft-actor-critic_amd' / 'csrc' / 'build.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
+def _committed(config: str, kind: str, profiles_dir=None, lib_hash=None):
+    """(document, 'profiles/<file>') of this round's committed summary `profiles/<ROUND>_<config>_<kind>.json` — ONLY when
+    it was recorded with the very library that is running (its `_meta.lib_hash` stamp, tools/summarize_rocprof.py /
+    summarize_pmc.py, equals `library_hash()`); (None, reason) otherwise.  No fallback to older rounds: a kernel change
+    without a profile refresh must not print a stale duration beside live work counts."""
+    path = Path(profiles_dir or ROOT / 'profiles') / f'{ROUND}_{config}_{kind}.json'
+    if not path.exists():
+        return None, 'no committed profile'
+    d = json.loads(path.read_text())
+    stamp = (d.get('_meta') or {}).get('lib_hash')
+    if stamp != (lib_hash or library_hash()):
+        return None, 'profile stale'
+    return d, f'profiles/{path.name}'
+
+
+def pmc_traffic(config: str, kernel: str, profiles_dir=None, lib_hash=None):
+    """(HBM bytes per launch, source) of a kernel (all template instances, launch-weighted), or (None, reason): the PMC
     passes run under rocprofv3, not inside this process, so the committed summary of the same command is read
     (profiles/<round>_<config>_pmc_traffic.json, tools/summarize_pmc.py: FETCH_SIZE x2 (gfx950) + WRITE_SIZE)."""
-    for rnd in (*_ROUNDS, 'r02', 'r01'):
-        path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_pmc_traffic.json'
-        if not path.exists():
-            continue
-        recs = [v for k, v in json.loads(path.read_text()).items()
-                if (k == kernel or k.startswith(kernel + '<') or k.startswith(kernel + '_sc<'))     # (_sc: with sidecars)
-                and v.get('fetch_bytes_corrected') is not None]
-        if not recs:
-            continue
-        calls = sum(r.get('launches', 1) for r in recs) or 1
-        tot = sum((r['fetch_bytes_corrected'] + (r.get('write_bytes_raw') or 0.0)) * r.get('launches', 1) for r in recs)
-        return round(tot / calls), f'profiles/{path.name}'
-    return None, None
+    d, src = _committed(config, 'pmc_traffic', profiles_dir, lib_hash)
+    if d is None:
+        return None, src
+    recs = [v for k, v in d.items()
+            if (k == kernel or k.startswith(kernel + '<') or k.startswith(kernel + '_sc<'))     # (_sc: with sidecars)
+            and isinstance(v, dict) and v.get('fetch_bytes_corrected') is not None]
+    if not recs:
+        return None, 'kernel not in the committed profile'
+    calls = sum(r.get('launches', 1) for r in recs) or 1
+    tot = sum((r['fetch_bytes_corrected'] + (r.get('write_bytes_raw') or 0.0)) * r.get('launches', 1) for r in recs)
+    return round(tot / calls), src
 
 
-def in_situ(config: str, kernel: str):
+def in_situ(config: str, kernel: str, profiles_dir=None, lib_hash=None):
     """(mean launch duration in us, launches per step, source) of a kernel INSIDE the replayed hipGraph step, from the
     committed rocprofv3 --kernel-trace --stats summary of `bench.py --config <config>` (profiles/<round>_<config>_
-    kernel_stats.json, tools/summarize_rocprof.py); `a+b`: a launch group, durations added.  (None, None, None) without it."""
-    for rnd in _ROUNDS:
-        path = Path(__file__).resolve().parent / 'profiles' / f'{rnd}_{config}_kernel_stats.json'
-        if path.exists():
-            break
-    else:
-        return None, None, None
-    d = json.loads(path.read_text())
+    kernel_stats.json, tools/summarize_rocprof.py); `a+b`: a launch group, durations added.  (None, None, reason) when
+    there is none for the running library."""
+    d, src = _committed(config, 'kernel_stats', profiles_dir, lib_hash)
+    if d is None:
+        return None, None, src
     us, per_step = 0.0, None
     for k in kernel.split('+'):
         if k not in d:
-            return None, None, None
+            return None, None, 'kernel not in the committed profile'
         us += d[k]['avg_us']
         per_step = d[k]['launches_per_step'] if per_step is None else per_step
-    return us, per_step, f'profiles/{path.name}'
+    return us, per_step, src
+
+
+def roofline_with_profile(roofline: dict, config: str, kernel: str, profiles_dir=None, lib_hash=None) -> dict:
+    """`roofline` as measured LIVE in this run (HIP events on the launch stream) -> the record that is printed: the live
+    figures stay as `*_hip_events`; when this round's committed rocprofv3 summary was recorded with the running library
+    its in-situ duration (inside the replayed step) becomes `frac` / `achieved` / `avg_launch_us` and is named in
+    `frac_source`, otherwise the live figures are THE figures and `frac_source` says why ("live (profile stale)")."""
+    r = dict(roofline)
+    r['traffic'], r['traffic_source'] = pmc_traffic(config, kernel, profiles_dir, lib_hash)
+    r.update({'achieved_hip_events': r['achieved'], 'frac_hip_events': r['frac'], 'avg_launch_us_hip_events': r['avg_launch_us']})
+    us_situ, _, src = in_situ(config, kernel, profiles_dir, lib_hash)
+    if us_situ is None:
+        r['frac_source'] = f'live ({src})'
+        return r
+    work = r.get('alg_flops_per_launch') or r.get('alg_bytes_per_launch')
+    ach = work / (us_situ * 1e-6) / (1e12 if r['bound'] == 'mfma' else 1e9)
+    r.update({'achieved': round(ach, 4), 'frac': round(ach / r['peak'], 6), 'avg_launch_us': round(us_situ, 3), 'frac_source': src})
+    return r
 
 
 def _gru_bytes(B, L):
@@ -334,11 +369,13 @@ def cpu_baseline(budget_s=24.0, fill=None):
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
     return {'value': round(k / dt, 3), 'unit': 'train_steps/s', 'cores': best, 'kind': 'port',
-            'sample': f'{k} steps in {dt:.1f}s, {best} torch thread(s) (sweep { {t: round(v, 1) for t, v in sweep.items()} } steps/s), '
-                      f'host cpu_count={os.cpu_count()}; same workload: {CFG["desc"]}, B={CFG["batch_size"]}, {fill} rows resident'}
+            'threads': best, 'host_cores': os.cpu_count(), 'rows_resident': int(fill), 'sample_steps': k,
+            'sample_seconds': round(dt, 1), 'thread_sweep_steps_per_s': {str(t): round(v, 1) for t, v in sweep.items()},
+            'sample': f'{k} steps of the same workload in {dt:.1f}s, oracle/sac_ref.SacRef, best of a thread sweep'}
 
 
 # ---- the line the driver parses ---------------------------------------------------------------------------------------------
+PROSE_LIMIT = 100      # free-text fields of the line (sizes and counts travel as numbers, never inside prose)
 LINE_LIMIT = 4096      # the driver keeps a tail of stdout: the LAST line must fit in it whole (round 4's 21 KB line did not)
 _ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernels', 'avg_launch_us', 'us_per_step',
               'launches_per_step', 'alg_flops_per_launch', 'alg_bytes_per_launch', 'alg_bytes_per_step',
@@ -361,16 +398,19 @@ def compact_line(full: dict, details_path: str = 'bench_details.json') -> str:
         if k.startswith('value_') and v is not None:
             out[k] = v
     cfg = dict(full.get('config') or {})
-    cfg['workload'] = _clip(cfg.get('workload', ''), 160)
-    out['config'] = {k: cfg[k] for k in ('workload', 'per_gpu_batch', 'global_batch', 'replay_shard_capacity', 'parallelism',
+    cfg['workload'] = _clip(cfg.get('workload', ''), PROSE_LIMIT)
+    out['config'] = {k: cfg[k] for k in ('workload', 'per_gpu_batch', 'global_batch', 'rows_resident', 'replay_capacity',
+                                         'replay_shard_capacity', 'n_step', 'burn_in_step', 'parallelism',
                                          'ranks', 'collectives', 'hipgraph') if k in cfg}
     for name in ('roofline', 'roofline_hbm'):
         r = full.get(name)
         out[name] = None if r is None else {k: (_clip(r[k], 80) if isinstance(r[k], str) else r[k])
                                             for k in _ROOF_KEYS if k in r and r[k] is not None or k == 'traffic' and k in r}
     c = full.get('cpu_baseline')
-    out['cpu_baseline'] = None if c is None else {**{k: c.get(k) for k in ('value', 'unit', 'cores', 'kind')},
-                                                  'sample': _clip(c.get('sample', ''), 140)}
+    out['cpu_baseline'] = None if c is None else {**{k: c.get(k) for k in ('value', 'unit', 'cores', 'kind', 'threads', 'host_cores',
+                                                                            'rows_resident', 'sample_steps', 'sample_seconds')
+                                                     if c.get(k) is not None},
+                                                  'sample': _clip(c.get('sample', ''), PROSE_LIMIT)}
     side = {}
     for name, d in (full.get('configs') or {}).items():
         if 'error' in d:
@@ -598,7 +638,6 @@ def main():
         # batches of 257 .. 1 024: K2 (IS weights, 8 B bytes) is formed by an extra workgroup of the gather's launch
         alg['asac_step_prologue_sample_partial'] = alg['asac_step_prologue_sample'] - 8 * B
         alg['asac_window_gather_pad_w'] = alg['asac_window_gather_pad'] + 8 * B
-        alg['asac_step_prologue_sample_gather'] = alg['asac_step_prologue_sample'] + alg['asac_window_gather_pad']
         for name, st in sorted(summ.items(), key=lambda kv: -kv[1]['avg_us'] * kv[1]['calls']):
             by = alg.get(name)
             calls_per_step = st['calls'] / args.profile_steps
@@ -641,21 +680,7 @@ def main():
                         'frac': round(ach / HBM_PEAK_GBS, 6), 'traffic': None,
                         'alg_bytes_per_launch': round(d['bytes_per_step'] / d['launches_per_step']), **common}
         if roofline is not None:
-            roofline['traffic'], roofline['traffic_source'] = pmc_traffic(args.config, dom)
-            # the same kernel's duration INSIDE the replayed step (committed rocprofv3 summary of this command): what the
-            # profile readers recompute `frac` from
-            us_situ, per_step, src = in_situ(args.config, dom)
-            if us_situ is not None:
-                work = roofline.get('alg_flops_per_launch') or roofline.get('alg_bytes_per_launch')
-                scale = 1e12 if roofline['bound'] == 'mfma' else 1e9
-                ach_situ = work / (us_situ * 1e-6) / scale
-                # THE figure is the in-situ one; the back-to-back HIP-event one (warm caches) stays beside it
-                roofline.update({'achieved_hip_events': roofline['achieved'], 'frac_hip_events': roofline['frac'],
-                                 'avg_launch_us_hip_events': roofline['avg_launch_us'],
-                                 'achieved': round(ach_situ, 4), 'frac': round(ach_situ / roofline['peak'], 6),
-                                 'avg_launch_us': round(us_situ, 3), 'frac_source': src})
-            else:
-                roofline['frac_source'] = 'hip_events (no committed rocprofv3 summary for this config)'
+            roofline = roofline_with_profile(roofline, args.config, dom)
 
         # the north-star's "sample + return kernels" (K1-K4) as ONE group at this batch size
         members = [n_ for n_ in SAMPLE_RETURN if n_ in kernels]
@@ -685,7 +710,7 @@ def main():
                             'traffic_source': sorted(srcs) if traffic is not None else None,
                             'achieved_hip_events': round(ach, 3), 'frac_hip_events': round(ach / HBM_PEAK_GBS, 6),
                             'us_per_step_hip_events': round(us_step, 2),
-                            'frac_source': situ[0][2] if us_situ is not None else 'hip_events (no committed rocprofv3 summary for this config)',
+                            'frac_source': situ[0][2] if us_situ is not None else f'live ({next(x[2] for x in situ if x[0] is None)})',
                             'note': 'K1+K2 sample / IS weights (with the step prologue), K3 window gather, K4 return + min; '
                                     'in situ = inside the replayed hipGraph step'}
 
@@ -711,8 +736,9 @@ def main():
             'value_lookahead': (configs or {}).get('cfg2_lookahead', {}).get('value') if args.config == 'cfg2' else None,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': f'{CFG["desc"]}, batch {CFG["batch_size"]} per GPU, {args.fill} transitions resident',
-                       'per_gpu_batch': CFG['batch_size'],
+            'config': {'workload': CFG.get('short') or CFG['desc'], 'workload_long': CFG['desc'],
+                       'per_gpu_batch': CFG['batch_size'], 'rows_resident': int(args.fill), 'replay_capacity': CFG['capacity'],
+                       'n_step': CFG['n_step'], 'burn_in_step': CFG['burn_in_step'],
                        'global_batch': CFG['batch_size'] * world,
                        'replay_shard_capacity': CFG['capacity'] // world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',

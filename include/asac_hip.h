@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 75
+#define ASAC_ABI_VERSION 76
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -1082,10 +1082,8 @@ int asac_step_prologue(float* target, const float* source, int64_t n_polyak, flo
  * launch, the first of a captured train step: the first ceil(batch / 256) workgroups sample 256 rows each, drawing their
  * stratified uniforms themselves (the very numbers asac_step_prologue would have stored in uniform_out, which they
  * also fill), the other workgroups are the prologue's.  replay_buffer.py:185-205, 347-354 + sac_base.py:745-764.
- * min_p_out is f32[528], 64-byte aligned, HERE: [0] min p, [1] min ratio, [2..9] the workgroups' exchange (partial minima,
- * four counters), [16 * (1 + f)], [16 * (1 + f) + 1], f < 32: flag and count words of asac_step_prologue_sample_gather,
- * one pair per cache line — all of
- * which must be ZERO before the first launch and are left zero by every launch.
+ * min_p_out is f32[528], 64-byte aligned, HERE: [0] min p, [1] min ratio, [2..7] the workgroups' exchange (partial minima,
+ * two counters) — which must be ZERO before the first launch and are left zero by every launch.
  * is_weights_out == NULL defers the weights (sharded replay: they are normalised by the minimum sampling ratio over
  * all ranks' shards): min_p_out[0] = min p, min_p_out[1] = min p / total, beta untouched; after the MIN all-reduce of
  * min_p_out[1], asac_per_is_weights advances beta and writes the weights. */
@@ -1110,20 +1108,6 @@ int asac_window_gather_pad_w(const asac_gather_key_t* keys_host, int n_keys, con
                              int post_n, int capacity, const int32_t* index_ring, const float* p, const float* tree,
                              double* beta_state, double beta_increment, float* is_weights_out, float* min_p_out,
                              void* stream);
-
-/* asac_step_prologue_sample and asac_window_gather_pad of the batch it draws (ids = ids_out, same batch / capacity) as
- * ONE launch: the gather's workgroups wait inside the launch until the sampler workgroups — first in the grid — have
- * stored their ids; minimum, IS weights and beta follow beside the running gather.  One dependent launch less per train
- * step; gathers of more than 1 024 workgroups (megabytes) are issued as the two launches instead, which is faster there.
- * replay_buffer.py:185-205, 345-364 + sac_base.py:745-764, 2435-2453.  min_p_out: f32[528] as above. */
-int asac_step_prologue_sample_gather(float* target, const float* source, int64_t n_polyak, float tau, float* zero_out,
-                                     int64_t n_zero, uint64_t seed, const int64_t* step_counter, double* uniform_out,
-                                     float* normal_out, int64_t n_normal, int32_t* subsets_out, int n_subsets,
-                                     int E_sample, int E, const float* tree, int capacity, int batch,
-                                     const int64_t* slot_ids, double* beta_state, double beta_increment, int32_t* leaf_out,
-                                     float* p_out, int64_t* ids_out, float* is_weights_out, float* min_p_out,
-                                     const asac_gather_key_t* keys_host, int n_keys, int prev_n, int post_n,
-                                     const int32_t* index_ring, void* stream);
 
 /* hipGraphLaunch of an instantiated graph (the captured train step) on `stream`. */
 int asac_graph_launch(void* graph_exec, void* stream);

@@ -15,6 +15,7 @@ GOLDEN = ROOT / 'tests' / 'golden'
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: long-running variant, additionally gated by an environment variable')
 
 
 @pytest.fixture(scope='session')

@@ -281,7 +281,10 @@ def _tolerance_scale(key: str, rtol: float) -> float:
         _TOL_TABLE = json.loads(path.read_text()) if path.exists() else {}
     rec = _TOL_TABLE.get(key)
     if rec is None:
-        return 1.
+        # a comparison without an entry would silently run at the call site's (loose) default: refuse it.  New keys are
+        # recorded first (ASAC_PARITY_RECORD=1 on the GPU box, then tools/set_tolerances.py --merge)
+        raise AssertionError(f'parity key {key!r} has no entry in tests/parity_tolerances.json: record it '
+                             f'(ASAC_PARITY_RECORD=1 python -m pytest tests -m gpu; python tools/set_tolerances.py --merge)')
     return min(1., max(4. * rec['used_of_default'], ULP2 / max(rtol, 1e-300)))
 
 

@@ -10,6 +10,7 @@ differing ids per step afterwards, and how far the losses / TD errors / temperat
 distributions over the last 100 steps.  Asserted: ids agree for the first steps; both runs stay finite; the
 distribution distances stay within bounds set from the recorded run (4x observed)."""
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -24,13 +25,21 @@ from tests import parity_utils as pu  # noqa: E402
 from tests.test_full_size_gpu import SUBSET_ROWS, _episode, _full_perm  # noqa: E402
 
 STEPS = {'cfg2': 220, 'cfg4': 110}      # (round 4: 500 / 300; shortened to keep the GPU suite inside its time budget)
+LONG_STEPS = {'cfg2': 500, 'cfg4': 300}  # the long variant: ASAC_LONG_DRIFT=1 (run once per round, record under profiles/)
 FILL = {'cfg2': 2 ** 15, 'cfg4': 4096}
 # (relative difference of the means over the last 100 steps): loss_q, mean |td|, log alpha
 BOUNDS = {'cfg2': (0.25, 0.25, 0.05), 'cfg4': (0.25, 0.25, 0.05)}
 
 
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get('ASAC_LONG_DRIFT'), reason='long drift run: set ASAC_LONG_DRIFT=1')
 @pytest.mark.parametrize('name', ['cfg2', 'cfg4'])
-def test_unaligned_drift_at_full_size(name):
+def test_unaligned_drift_at_full_size_long(name):
+    test_unaligned_drift_at_full_size(name, LONG_STEPS[name], '_long')
+
+
+@pytest.mark.parametrize('name', ['cfg2', 'cfg4'])
+def test_unaligned_drift_at_full_size(name, n_steps=None, tag=''):
     import asac_amd  # noqa: F401
     from algorithm.sac_base import SAC_Base
     cfg = bench.CONFIGS[name]
@@ -58,7 +67,7 @@ def test_unaligned_drift_at_full_size(name):
     rb._update_ids(last, torch.zeros(last.numel(), device=rb.device), stale_check=False, mode=1)
     orb.tree.tree[:] = rb._tree.cpu().numpy()          # the common start; nothing is copied after this line
 
-    n_steps = STEPS[name]
+    n_steps = STEPS[name] if n_steps is None else n_steps
     first_mismatch, differing = None, []
     series = {k: ([], []) for k in ('loss_q', 'td_abs_mean', 'log_alpha')}
     for step in range(n_steps):
@@ -104,7 +113,7 @@ def test_unaligned_drift_at_full_size(name):
               'observables': dist}
     out_dir = Path(__file__).resolve().parents[1] / 'gpurun_out'
     out_dir.mkdir(exist_ok=True)
-    (out_dir / f'drift_{name}.json').write_text(json.dumps(record, indent=1))
+    (out_dir / f'drift_{name}{tag}.json').write_text(json.dumps(record, indent=1))
     print(json.dumps(record))
     assert first_mismatch is None or first_mismatch >= 3, f'ids differ already at step {first_mismatch}'
     b_loss, b_td, b_alpha = BOUNDS[name]

@@ -169,16 +169,3 @@ def test_baseline_config_full_size_vs_oracle(name):
     rb.check_health()
     assert rb.check_tree_invariant() == 0
     agent.close()
-
-
-def test_sampler_and_gather_in_one_launch_full_size(monkeypatch):
-    """`hip_config['prologue_gather']` (off by default: measured slower end to end): the headline
-    configuration with `asac_step_prologue_sample_gather` as the step's first launch, eager / capture / replay against
-    the oracle like every other form."""
-    monkeypatch.setenv('ASAC_TEST_HIP_CONFIG', json.dumps({'prologue_gather': True}))
-    from asac_amd import native
-    seen = []
-    real = native.step_prologue_sample_gather
-    monkeypatch.setattr(native, 'step_prologue_sample_gather', lambda *a, **k: (seen.append(1), real(*a, **k))[1])
-    test_baseline_config_full_size_vs_oracle('cfg2')
-    assert seen, 'the merged launch was not taken'

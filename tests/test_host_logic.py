@@ -166,3 +166,45 @@ def test_train_is_the_method_timed_as_train_a_step():
     assert SAC_Base.train.__wrapped__.__name__ == 'train'
     for helper in ('_optimizer_hp', '_drop_graphs_if_hp_changed', '_ready_to_train'):
         assert not hasattr(getattr(SAC_Base, helper), 'elapsed_log'), helper
+
+
+def test_fused_row_routes_are_refused_for_unaligned_parameters():
+    """Parameters are views packed back to back in the learner's flat buffer; only segment starts are 16-byte aligned.  A
+    model with an earlier parameter of numel % 4 != 0 shifts the Linears behind it off the 16-byte grid the MFMA row
+    kernels read on: the gating predicates must send such layers to nn.Linear instead of into a `bad_arg`."""
+    from algorithm.nn_models.layers import seq_layers as sl
+    lin = torch.nn.Linear(64, 64)
+    stack = torch.nn.Module()
+    stack.dense = torch.nn.Sequential(lin)
+    assert sl._plain_linear(stack) is lin
+    flat = torch.zeros(64 * 64 + 64 + 8)
+    for off, ok in ((4, True), (1, False), (2, False)):        # element offsets into an aligned buffer
+        base = (-flat.data_ptr() // 4) % 4                     # first element on a 16-byte boundary
+        w = flat[base + off:base + off + 64 * 64].view(64, 64)
+        b = flat[base + off + 64 * 64:base + off + 64 * 64 + 64]
+        lin.weight.data, lin.bias.data = w, b
+        assert sl._params_aligned16(lin) == ok
+        assert (sl._plain_linear(stack) is lin) == ok
+
+
+def test_mse_intercept_only_reroutes_the_thread_that_installed_it():
+    """`fused.fused_mse_loss` patches the process-global `torch.nn.functional.mse_loss` while the learner's `get_loss`
+    runs: a call from any OTHER thread in that window must reach the original function (never the learner's workspace)."""
+    import threading
+    import torch.nn.functional as F
+    from algorithm import fused
+    seen = {}
+    orig = F.mse_loss
+    with fused.fused_mse_loss(torch.zeros(8), grad_scale=0.25):
+        patched = F.mse_loss
+        assert patched is not orig
+
+        def other():
+            a = torch.ones(2, 2, 3, requires_grad=True)
+            seen['value'] = float(F.mse_loss(a, torch.zeros(2, 2, 3)))
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        # (small CPU tensors take the original path on the owner thread too: the route itself is GPU-tested)
+        assert float(F.mse_loss(torch.ones(2, 2, 3, requires_grad=True), torch.zeros(2, 2, 3))) == 1.0
+    assert F.mse_loss is orig and seen['value'] == 1.0

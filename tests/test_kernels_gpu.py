@@ -687,77 +687,6 @@ def test_step_prologue_with_sampler_is_prologue_then_sampler(nat, B):
             assert not b['minp'][6:8].view(torch.int32).any()
 
 
-@pytest.mark.parametrize('B,row', [(256, 24), (512, 2000), (1000, 10800)])
-def test_step_prologue_sample_gather_is_the_two_launches(nat, B, row):
-    """`asac_step_prologue_sample_gather` == `asac_step_prologue_sample` followed by `asac_window_gather_pad` on the ids it
-    drew, bit for bit (the gather's workgroups wait inside the launch for the sampler workgroups' ids), launch after
-    launch on a tree that changes in between, eagerly and as hipGraph replays; the exchange words are left zero."""
-    C, prev_n, post_n = 8192, 2, 3
-    L = prev_n + 1 + post_n
-    rng = np.random.default_rng(B)
-    t = DevTree(nat, C, extra=2 * C)
-    t.set_priorities(np.arange(C), (rng.random(C) + 0.01).astype(np.float32))
-    slot_ids = torch.arange(C, dtype=torch.int64, device='cuda') + 7 * C        # ids whose slot is id % C
-    step = torch.full((1,), 3, dtype=torch.int64, device='cuda')
-    g = torch.Generator().manual_seed(2)
-    wide = torch.randn(C, row // 4, generator=g).cuda()
-    vec = torch.randn(C, 3, generator=g).cuda()
-    index = (torch.arange(C, dtype=torch.int32) % 37).cuda()
-    source, target0 = torch.randn(30_000, generator=g).cuda(), torch.randn(30_000, generator=g).cuda()
-
-    def outs():
-        o = dict(leaf=torch.zeros(B, dtype=torch.int32, device='cuda'), p=torch.zeros(B, device='cuda'),
-                 ids=torch.zeros(B, dtype=torch.int64, device='cuda'), w=torch.zeros(B, device='cuda'),
-                 beta=torch.tensor([0.4], dtype=torch.float64, device='cuda'), minp=torch.zeros(528, device='cuda'),
-                 u=torch.zeros(B, dtype=torch.float64, device='cuda'), z=torch.zeros(999, device='cuda'),
-                 target=target0.clone(), grad=torch.ones(555, device='cuda'),
-                 wide=torch.zeros(B, L, row // 4, device='cuda'), vec=torch.zeros(B, L, 3, device='cuda'),
-                 index=torch.zeros(B, L, dtype=torch.int32, device='cuda'), mask=torch.zeros(B, L, dtype=torch.bool, device='cuda'))
-        o['keys'] = nat.make_gather_keys([
-            dict(src=wide, dst=o['wide'], row_bytes=row, pad_mode=nat.PAD_KEEP),
-            dict(src=vec, dst=o['vec'], row_bytes=12, pad_mode=nat.PAD_WORD, pad_word=0),
-            dict(src=index, dst=o['index'], row_bytes=4, pad_mode=nat.PAD_WORD, pad_word=0xffffffff),
-            dict(src=None, dst=o['mask'], pad_mode=nat.PAD_EMIT_MASK)])
-        return o
-
-    def two(o):
-        nat.step_prologue_sample((o['target'], source, 0.005), o['grad'], 99, step, o['u'], o['z'], None, 0, t.tree, C, B,
-                                 slot_ids, o['beta'], 0.001, o['leaf'], o['p'], o['ids'], o['w'], o['minp'])
-        nat.window_gather_pad(o['keys'], o['ids'], B, prev_n, post_n, C, index)
-
-    def one(o):
-        nat.step_prologue_sample_gather((o['target'], source, 0.005), o['grad'], 99, step, o['u'], o['z'], None, 0, t.tree, C,
-                                        B, slot_ids, o['beta'], 0.001, o['leaf'], o['p'], o['ids'], o['w'], o['minp'],
-                                        o['keys'], prev_n, post_n, index)
-
-    names = ('u', 'z', 'target', 'grad', 'leaf', 'p', 'ids', 'w', 'beta', 'wide', 'vec', 'index', 'mask')
-    a, b = outs(), outs()
-    stream = torch.cuda.Stream()
-    graph = None
-    for it in range(6):
-        if it == 3:      # from here on: replays of the captured launch
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=stream):
-                    one(b)
-            torch.cuda.synchronize()
-        two(a)
-        if graph is None:
-            one(b)
-        else:
-            graph.replay()
-        torch.cuda.synchronize()
-        for k in names:
-            assert torch.equal(a[k], b[k]), (it, k)
-        assert not b['minp'][6:].view(torch.int32).any()
-        assert a['mask'].any() and not a['mask'].all()
-        # another tree and another step counter for the next launch
-        idx = rng.permutation(C)[:500]
-        t.set_priorities(idx, (rng.random(500) * 3).astype(np.float32))
-        step += 1
-
-
 @pytest.mark.parametrize('B', [257, 512, 1000, 1024])
 def test_partial_sampler_plus_weights_in_the_gather_launch(nat, B):
     """`asac_step_prologue_sample_partial` + `asac_window_gather_pad_w` == `asac_step_prologue_sample` +

@@ -212,16 +212,6 @@ def test_step_parity_with_each_switch_off(golden_dir, case, switch):
     agent.close()
 
 
-def test_step_parity_with_the_target_representation_on_a_second_stream(golden_dir):
-    """`hip_config['rep_branch']` (off by default: measured slower): the target representation's pass over the window as a
-    branch of the step beside the online one — the same recorded reference steps under the same bounds"""
-    agent, g, mods, n_steps, _, _ = run_golden_case(golden_dir, 'conv', align=True, tag='switch_on/rep_branch', hip={'rep_branch': True})
-    assert agent._rep_stream is not None, 'the branch was not taken'
-    pu.assert_weights_close(mods, g, n_steps, LR, *tol('conv', 'weights'), log_key='switch_on/rep_branch/conv/weights')
-    agent.replay_buffer.check_health()
-    agent.close()
-
-
 def test_attn_policy_gradient_against_float64(golden_dir):
     """The arbiter for REFERENCE_ILL_CONDITIONED: the policy step of the golden `attn` step 0, from the very weights
     and state the product's policy step sees, evaluated on the host in float64 with the reference's formulas

@@ -5,7 +5,7 @@ import shutil
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r05'
+R, P, TAG = ROOT / 'gpurun_out' / 'refresh', ROOT / 'profiles', 'r06'
 
 CFGS = ('cfg2', 'cfg3', 'cfg4', 'cfg4_84', 'cfg5')
 for c in CFGS:
@@ -30,8 +30,9 @@ for src, dst, title in (('kernel_sweep_pmc.json', f'{TAG}_kernel_sweep_pmc',
                         *[(f'{c}_pmc_traffic.json', f'{TAG}_{c}_pmc_traffic',
                            f'bench.py --config {c} (--steps 60 --warmup 10 --fill 20000, hipgraph replay) under rocprofv3 --pmc (two passes); per-launch averages')
                           for c in ('cfg3', 'cfg3_h64', 'cfg4', 'cfg4_84', 'cfg5', 'cfg_attn_h64') if (R / f'{c}_pmc_traffic.json').exists()]):
-    d = {k: v for k, v in json.load(open(R / src)).items() if k.startswith('asac::')}
-    json.dump(d, open(P / f'{dst}.json', 'w'), indent=1, sort_keys=True)
+    raw = json.load(open(R / src))
+    d = {k: v for k, v in raw.items() if k.startswith('asac::')}
+    json.dump({**d, **({'_meta': raw['_meta']} if '_meta' in raw else {})}, open(P / f'{dst}.json', 'w'), indent=1, sort_keys=True)
     lines = [f'# {title}', '# fetch x2 = gfx950 correction for wide coalesced reads (MI355X_MICROARCH.md "HBM"); write is raw',
              f'{"kernel":52s} {"launches":>8s} {"fetch raw B":>13s} {"fetch x2 B":>13s} {"write raw B":>13s}']
     fmt = lambda x: f'{x:13.0f}' if x is not None else f'{"-":>13s}'

@@ -37,13 +37,13 @@ for c in ${PMC_CFGS:-cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg_attn_h64}; do
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w_$c -- python $R/bench.py --no-extras --config $c --no-cpu-baseline $st --fill $( [ $c = cfg4_84 ] && echo 8000 || echo 20000 ) --profile-steps 0 --run-length 0 > /tmp/w_$c.log 2>&1
   python $R/tools/summarize_pmc.py $(find /tmp/pmc_r_$c -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_w_$c -name "*counter_collection.csv" | head -1) $O/${c}_pmc_traffic.json > $O/${c}_pmc_traffic_all.txt
 done
-# the bench lines last: their `*_in_situ` fields read the kernel-trace summaries just made (profiles/r05_*_kernel_stats.json)
+# the bench lines last: their `*_in_situ` fields read the kernel-trace summaries just made (profiles/r06_*_kernel_stats.json)
 # the headline workload with one batch in flight (hip_config['lookahead'] = 1): its two alternating graphs
 rm -rf /tmp/prof_la
 ASAC_BENCH_HIP_CONFIG='{"lookahead": 1}' timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_la -- python $R/bench.py --no-extras --no-cpu-baseline --profile-steps 0 --steps 400 --warmup 40 --run-length 0 > /tmp/prof_la.log 2>&1
 python $R/tools/step_sequence.py $(find /tmp/prof_la -name "*kernel_trace.csv" | head -1) > $O/cfg2_lookahead_step_sequence.txt
 python $R/tools/summarize_rocprof.py $(find /tmp/prof_la -name "*kernel_stats.csv" | head -1) 440 40 $O/cfg2_lookahead_kernel_stats.json > $O/cfg2_lookahead_kernel_stats_summary.txt
-for c in cfg2 cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg5_without_prediction cfg_attn_h64; do cp $O/${c}_kernel_stats.json $R/profiles/r05_${c}_kernel_stats.json; done
+for c in cfg2 cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg5_without_prediction cfg_attn_h64; do cp $O/${c}_kernel_stats.json $R/profiles/r06_${c}_kernel_stats.json; done
 cd $R
 timeout 1200 python bench.py > $O/cfg2_bench_line.json 2> $O/cfg2_bench.err
 cp $R/bench_details.json $O/cfg2_bench.json      # (the full record; cfg2_bench_line.json: the < 4 KB line the driver parses)

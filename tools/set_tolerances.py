@@ -3,7 +3,10 @@ default bounds) -> tests/parity_tolerances.json (what the tests enforce: default
 tests/parity_utils.py) and profiles/<round>_parity_errors.json (the observed errors, for DESIGN.md section 5).
 
     ASAC_PARITY_RECORD=1 python -m pytest tests -m gpu -q        (on the GPU box)
-    python tools/set_tolerances.py [round]"""
+    python tools/set_tolerances.py [round] [--merge]
+
+`--merge`: keep the table's other keys and, per key, the WORSE of the table's and the log's observed error (a partial run —
+new tests only — extends the table instead of replacing it)."""
 import json
 import sys
 from pathlib import Path
@@ -12,7 +15,9 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+    argv = [a for a in sys.argv[1:] if a != '--merge']
+    merge = '--merge' in sys.argv[1:]
+    rnd = argv[0] if argv else 'r06'
     log = json.loads((ROOT / 'gpurun_out' / 'parity_errors.json').read_text())
     table, report = {}, {}
     for key, rec in sorted(log.items()):
@@ -29,8 +34,18 @@ def main():
         slim.update(default_rtol=rt, **{atol_key: rec[atol_key]}, used_of_default=used,
                     enforced_rtol=rt * scale, **{'enforced_' + atol_key[8:]: rec[atol_key] * scale})
         report[key] = slim
-    (ROOT / 'tests' / 'parity_tolerances.json').write_text(json.dumps(table, indent=0, sort_keys=True))
-    (ROOT / 'profiles' / f'{rnd}_parity_errors.json').write_text(json.dumps(report, indent=1, sort_keys=True))
+    tol_path, rep_path = ROOT / 'tests' / 'parity_tolerances.json', ROOT / 'profiles' / f'{rnd}_parity_errors.json'
+    if merge:
+        old = json.loads(tol_path.read_text()) if tol_path.exists() else {}
+        for key, rec in old.items():
+            if key not in table or rec['used_of_default'] > table[key]['used_of_default']:
+                table[key] = rec
+        old_rep = json.loads(rep_path.read_text()) if rep_path.exists() else {}
+        for key, rec in old_rep.items():
+            if key not in report or rec.get('used_of_default', 0) > report[key].get('used_of_default', 0):
+                report[key] = rec
+    tol_path.write_text(json.dumps(table, indent=0, sort_keys=True))
+    rep_path.write_text(json.dumps(report, indent=1, sort_keys=True))
     print(f'{len(table)} keys -> tests/parity_tolerances.json, profiles/{rnd}_parity_errors.json')
     worst = sorted(((v.get('enforced_rtol', 0), k) for k, v in report.items() if isinstance(v, dict) and 'enforced_rtol' in v), reverse=True)
     for rt, k in worst[:25]:

@@ -61,6 +61,8 @@ def main():
         print(f'{k:48s} {v["launches"]:8d} {fmt(v["fetch_bytes_raw"])} {fmt(v["fetch_bytes_corrected"])} '
               f'{fmt(v["write_bytes_raw"])}')
     if len(sys.argv) > 3:
+        from summarize_rocprof import _lib_hash
+        out['_meta'] = {'lib_hash': _lib_hash()}       # (bench.py quotes this traffic only for this very library)
         json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
 
 

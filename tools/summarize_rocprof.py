@@ -19,6 +19,16 @@ def short(name: str) -> str:
     return (base + ('<' + tag + '>' if tag else ''))[:72]
 
 
+def _lib_hash() -> str:
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location(
+        'asac_build', Path(__file__).resolve().parent.parent / 'advanced-soft-actor-critic_amd' / 'csrc' / 'build.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
 def main():
     path = sys.argv[1]
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
@@ -44,6 +54,7 @@ def main():
         out = {k: {'avg_us': round(t / c / 1e3, 3), 'launches_per_step': round(c / steps, 3)} for k, (c, t) in merged.items()}
         out['_all'] = {'us_per_step': round(tot / 1e3 / steps, 1), 'launches_per_step': round(calls / steps, 1),
                        'asac_share': round(sum(float(r['TotalDurationNs']) for r in asac) / tot, 4), 'steps': steps}
+        out['_meta'] = {'lib_hash': _lib_hash()}       # (bench.py quotes these durations only for this very library)
         json.dump(out, open(sys.argv[4], 'w'), indent=1, sort_keys=True)
     print(f'# asac kernels: {sum(float(r["TotalDurationNs"]) for r in asac) / tot * 100:.1f}% of device time, '
           f'{sum(int(r["Calls"]) for r in asac) / steps:.1f} launches/step')
