@@ -947,6 +947,35 @@ class SAC_Base(AuxHeadsMixin):
                     c_policy, torch.atanh(torch.clamp(c_act, -0.999, 0.999)))
         return probs
 
+    def _return_sample_epilogue(self, jobs, k, ls, nx_actions, eps_buf, policy_sample):
+        """What `_get_y` does with the policy's output over `nx_states` right after the forward — rsample / tanh / log-prob,
+        pi(stored actions) under `use_n_step_is`, with `policy_sample` the policy step's draw at t = 0 (reference
+        sac_base.py:1346-1351, 1430, 1452) — as the EPILOGUE of that forward's launch (`jobs[k]` of
+        `native.mlp_forward_multi_sampled`: no elementwise launch behind it).  Where the form applies the step's noise is
+        drawn as `_get_y` would have and the launch is issued;  -> ((a_tanh, logp), c_pi) to hand to
+        `_get_y(sample=, stored_pi=)`, or None: nothing drawn, nothing launched."""
+        A = self.c_action_size
+        if not (native.SAMPLE_EPILOGUE and A and 2 * A <= 16 and ls.dim() == 3 and nx_actions.stride(-1) == 1):
+            return None
+        f32 = dict(dtype=torch.float32, device=self.device)
+        a_tanh, logp = torch.empty((*ls.shape[:2], A), **f32), torch.empty(ls.shape[:2], **f32)
+        c_pi = torch.empty((*ls.shape[:2], A), **f32) if self.use_n_step_is else None
+        epis = [native.sample_epilogue() for _ in jobs]
+        epis[k] = native.sample_epilogue(jobs[k], eps_buf, a_tanh, logp, ls.shape[1],
+                                         action=nx_actions if self.use_n_step_is else None,
+                                         action_offset=self.d_action_summed_size, prob_out=c_pi,
+                                         eps2=self._eps_pi if policy_sample else None, t2=0,
+                                         a2_out=self._pi_a if policy_sample else None,
+                                         logp2_out=self._pi_logp if policy_sample else None)
+        if not native.mlp_forward_multi_sampled_ok(jobs, epis):
+            return None
+        self.noise.normal_(eps_buf)
+        if policy_sample:
+            self.noise.normal_(self._eps_pi)
+            self._pi_sampled = True
+        native.mlp_forward_multi_sampled(jobs, epis)
+        return (a_tanh, logp), c_pi
+
     # ==========================================================================================
     # target value (reference _get_y 1297-1466 + _v_trace 1244-1295)
     # ==========================================================================================
@@ -982,6 +1011,13 @@ class SAC_Base(AuxHeadsMixin):
         """
         dsum = self.d_action_summed_size
         n_actions = nx_actions[:, :-1]
+        if ls is None and sample is None and self._fpi is not None and self.c_action_size and nx_states.dim() == 3:
+            # the stock policy over the window and the window's sample as ONE launch (`_return_sample_epilogue`)
+            job_pi, ls_out = self._fpi.job(StockMLP._rows_in_place(nx_states, self.state_size), None)
+            ls_try = ls_out[0].view(*nx_states.shape[:2], 2 * self.c_action_size)
+            pre = self._return_sample_epilogue([job_pi], 0, ls_try, nx_actions, eps_buf, policy_sample)
+            if pre is not None:
+                ls, (sample, stored_pi) = ls_try, pre
         if ls is not None:
             d_policy = c_policy = None
             loc, scale, plain = ls[..., :self.c_action_size], ls[..., self.c_action_size:], True
@@ -1167,12 +1203,19 @@ class SAC_Base(AuxHeadsMixin):
                                  q_table=q_tab.view(E, B, T))
             self._defer_return = False
         else:
-            # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window
-            native.mlp_forward_multi([job_tq, job_pi])
+            # one launch: target Q of the stored pair (for the clipped loss) beside the policy over the window — whose
+            # lanes also draw the window's sample (`_return_sample_epilogue`; otherwise an elementwise launch in `_get_y`)
             ls = ls[0].view(*nx_states.shape[:2], 2 * self.c_action_size)
-            _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
-                                 n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
-                                 subset_prefix='y', y_out=self._y_buf, policy_sample=policy_sample, ls=ls)
+            pre = self._return_sample_epilogue([job_tq, job_pi], 1, ls, nx_actions, self._eps_y, policy_sample)
+            if pre is not None:
+                _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
+                                     n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
+                                     subset_prefix='y', y_out=self._y_buf, ls=ls, sample=pre[0], stored_pi=pre[1])
+            else:
+                native.mlp_forward_multi([job_tq, job_pi])
+                _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, nx_states, nx_actions, n_rewards,
+                                     n_dones, n_mu_probs if self.use_n_step_is else None, eps_buf=self._eps_y,
+                                     subset_prefix='y', y_out=self._y_buf, policy_sample=policy_sample, ls=ls)
         w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
         # loss + backward in one launch (the backward recomputes the forward on chip anyway); on a single
         # GPU the tile reduction of the parameter gradients is folded into the Adam launch
@@ -1223,13 +1266,18 @@ class SAC_Base(AuxHeadsMixin):
                 states_y = nx_states.detach()
                 job_tq, t_q = self._ftq.job(x0, a0, out=self._tq_buf)
                 job_pi, ls_y = self._fpi.job(StockMLP._rows_in_place(states_y, self.state_size), None)
-                native.mlp_forward_multi([job_tq, job_pi])
+                ls_y = ls_y[0].view(*states_y.shape[:2], 2 * self.c_action_size)
+                # ... whose lanes also draw the window's sample (`_return_sample_epilogue`): no elementwise launch behind it
+                pre = self._return_sample_epilogue([job_tq, job_pi], 1, ls_y, nx_actions, self._eps_y, policy_sample)
+                sampled = pre is not None
+                if not sampled:
+                    native.mlp_forward_multi([job_tq, job_pi])
                 self._defer_return, self._deferred_return = self._fused_q_return, None
                 _, c_y = self._get_y(n_last_masks, n_padding_masks, nx_obses_list, states_y, nx_actions,
                                      n_rewards, n_dones, n_mu_probs if self.use_n_step_is else None,
                                      eps_buf=self._eps_y, subset_prefix='y', y_out=self._y_buf,
-                                     policy_sample=policy_sample,
-                                     ls=ls_y[0].view(*states_y.shape[:2], 2 * self.c_action_size))
+                                     policy_sample=policy_sample and not sampled, ls=ls_y,
+                                     sample=pre[0] if sampled else None, stored_pi=pre[1] if sampled else None)
                 self._defer_return = False
                 w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                 ret, self._deferred_return = self._deferred_return, None
@@ -1951,37 +1999,60 @@ class SAC_Base(AuxHeadsMixin):
         rows_win = StockMLP._rows(w.bnx_states, self.state_size)
         td_own = self.use_priority and not same_states
         td_rows = sc_elect = None
-        if td_own:
-            td_rows = StockMLP._rows_in_place(w.nx_target_states, self.state_size)
-            job_win, ls_out = self._fpi.job(rows_win, None)
-            job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
-            native.mlp_forward_multi([job_win, job_pi_td])
-            ls_win = ls_out[0].view(B_, L_, 2 * A)
-            post.ls_td = ls_td_out[0].view(B_, n + 1, 2 * A)
-        else:
-            ls_win = self._fpi._launch_forward(rows_win, None)[0].view(B_, L_, 2 * A)
         probs_win = torch.empty((B_, L_, A), **f32)
-        jobs = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=w.bnx_actions, prob_out=probs_win)]
-        if auto_alpha:
-            self.noise.normal_(self._eps_alpha)
-            post.alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
-            jobs.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, post.alpha_logp))
-        if self.use_priority and same_states:
-            self.noise.normal_(self._eps_td)
-            post.td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
-            jobs.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *post.td_sample))
-        elif td_own:
-            self.noise.normal_(self._eps_td)
-            post.td_sample = (torch.empty((B_, n + 1, A), **f32), torch.empty((B_, n + 1), **f32))
-            post.td_pi = torch.empty((B_, n + 1, A), **f32)
-            jobs.append(native.squash_job(post.ls_td[..., :A], post.ls_td[..., A:], self._eps_td, *post.td_sample,
-                                          action=w.bnx_actions[:, b:], prob_out=post.td_pi))
         # (with priorities the TD error's online-Q launch follows and hosts the second pass + the temperature step)
         if self.use_priority and self._use_sidecars and rb.sharded is None:
             sc_elect, post.sc_write = rb.window_scatter_sidecars(w.ids, -b, b + n, w.bnx_pad, 'mu_prob', probs_win[:, :-1])
+        # the policy forward(s) WITH the elementwise work on their outputs as the forward launch's epilogue
+        # (`native.mlp_forward_multi_sampled`: temperature sample at position b, pi(stored actions), the TD target's sample);
+        # the chain form below is what it replaces, bit for bit
+        if auto_alpha:
+            post.alpha_logp, scratch = torch.empty(B_, **f32), torch.empty((B_, A), **f32)
+        if self.use_priority and same_states:
+            post.td_sample = (torch.empty((B_, L_, A), **f32), torch.empty((B_, L_), **f32))
+        elif td_own:
+            post.td_sample = (torch.empty((B_, n + 1, A), **f32), torch.empty((B_, n + 1), **f32))
+            post.td_pi = torch.empty((B_, n + 1, A), **f32)
+        job_win, ls_out = self._fpi.job(rows_win, None)
+        jobs = [job_win]
+        epis = None
+        if native.SAMPLE_EPILOGUE and 2 * A <= 16 and w.bnx_actions.stride(-1) == 1:
+            epis = [native.sample_epilogue(job_win, *((self._eps_td, *post.td_sample) if self.use_priority and same_states
+                                                      else (None, None, None)), L_,
+                                           action=w.bnx_actions, prob_out=probs_win,
+                                           eps2=self._eps_alpha if auto_alpha else None, t2=b,
+                                           a2_out=scratch if auto_alpha else None,
+                                           logp2_out=post.alpha_logp if auto_alpha else None)]
+        if td_own:
+            td_rows = StockMLP._rows_in_place(w.nx_target_states, self.state_size)
+            job_pi_td, ls_td_out = self._fpi.job(td_rows, None)
+            jobs.append(job_pi_td)
+            post.ls_td = ls_td_out[0].view(B_, n + 1, 2 * A)
+            if epis is not None:
+                epis.append(native.sample_epilogue(job_pi_td, self._eps_td, *post.td_sample, n + 1,
+                                                   action=w.bnx_actions[:, b:], prob_out=post.td_pi))
+        ls_win = ls_out[0].view(B_, L_, 2 * A)
+        if epis is not None and not native.mlp_forward_multi_sampled_ok(jobs, epis):
+            epis = None
+        if auto_alpha:
+            self.noise.normal_(self._eps_alpha)
+        if self.use_priority:
+            self.noise.normal_(self._eps_td)
+        if auto_alpha and self.use_priority and self._use_sidecars and rb.sharded is None:
+            post.sc_alpha = self._alpha_sidecar(post.alpha_logp)
+        if epis is not None:
+            native.mlp_forward_multi_sampled(jobs, epis, sidecars=[sc_elect] if sc_elect is not None else None)
+        else:
+            native.mlp_forward_multi(jobs)
+            sq = [native.squash_job(ls_win[..., :A], ls_win[..., A:], action=w.bnx_actions, prob_out=probs_win)]
             if auto_alpha:
-                post.sc_alpha = self._alpha_sidecar(post.alpha_logp)
-        native.squash_multi(jobs, sidecars=[sc_elect] if sc_elect is not None else None)
+                sq.append(native.squash_job(ls_win[:, b, :A], ls_win[:, b, A:], self._eps_alpha, scratch, post.alpha_logp))
+            if self.use_priority and same_states:
+                sq.append(native.squash_job(ls_win[..., :A], ls_win[..., A:], self._eps_td, *post.td_sample))
+            elif td_own:
+                sq.append(native.squash_job(post.ls_td[..., :A], post.ls_td[..., A:], self._eps_td, *post.td_sample,
+                                            action=w.bnx_actions[:, b:], prob_out=post.td_pi))
+            native.squash_multi(sq, sidecars=[sc_elect] if sc_elect is not None else None)
         if post.sc_alpha is not None:
             self._alpha_logp_over_ranks(post.alpha_logp)
         post.ls_win, post.probs_win = ls_win, probs_win

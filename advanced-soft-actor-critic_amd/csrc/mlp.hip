@@ -577,9 +577,11 @@ inline size_t mlp_fwd_lds_bytes(int n_blocks, bool wide = false, int TM = 32) {
 // One workgroup evaluates member e on the row tiles tile0, tile0 + tile_stride, ...: every layer's weights
 // are staged into LDS ONCE and reused by all of them (for window-sized inputs — tens of thousands of rows —
 // re-staging 36 KB of weights per tile would be most of the traffic).
-template <int TM, bool WINDOW, bool WIDE = false, int NB = 0>
+// EPI: a Gaussian-head policy job whose rows are sampled from (and whose stored actions are scored) by the lanes that form
+// the head (asac_squash.h `sample_epilogue`: asac_squash_multi's jobs without a launch of their own)
+template <int TM, bool WINDOW, bool WIDE = false, int NB = 0, bool EPI = false>
 __device__ __forceinline__ void mlp_fwd_tiles(const MlpFwdArgs& a, const int e, const int tile0, const int tile_stride,
-                                              MlpLds<TM>& L) {
+                                              MlpLds<TM>& L, const SampleEpi* epi = nullptr) {
     constexpr int THREADS = threads_of<TM>();
     constexpr int RT = TM / 16;                               // row tiles of a workgroup tile
     constexpr bool fixed = NB > 0;                            // NB blocks of 64 (see net_fetch_fixed)
@@ -633,6 +635,14 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpFwdArgs& a, const int e, 
             else fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)(tile + tile_stride) * TM, nxt);
         }
         if (more && wide) fetch_input_tile<THREADS, WINDOW>(a, e, (int64_t)(tile + tile_stride) * TM, nxt_hi, kMaxW);
+        // the sampling epilogue's operands of this lane's head row travel under the layers (asac_squash.h)
+        SampleEpiIn epi_in{};
+        bool epi_on = false;
+        if constexpr (EPI) {
+            epi_on = epi->on != 0;                            // (uniform)
+            if (epi_on)
+                epi_in = sample_epilogue_fetch(*epi, row0 + (wave % RT) * 16 + 4 * (lane >> 4) + wave / RT, a.N, lane & 15);
+        }
         int K = K0;
 #pragma unroll
         for (int l = 0; l < (fixed ? NB : kMaxB); ++l) {
@@ -666,14 +676,18 @@ __device__ __forceinline__ void mlp_fwd_tiles(const MlpFwdArgs& a, const int e, 
         // heads: one padded column tile per row tile.  Transformed heads (tanh / exp per element, both branches taken by
         // every wave) of short launches: all 4 RT waves form their row tile's head (the same MFMA chain: the same values)
         // and each finishes ONE of the four rows a lane holds; otherwise the first wave of every row tile
-        if (a.d.head_transform == 1 && n_tiles <= 256) {      // (launches of at most a tile per CU: latency is what counts)
+        // (with an epilogue every wave takes the all-waves form: the rows' transcendental chains are what the head phase costs)
+        if (a.d.head_transform == 1 && (n_tiles <= 256 || epi_on)) {      // (launches of at most a tile per CU: latency is what counts)
             const int hrt = wave % RT, hr = wave / RT;
             const f32x4 acc = gemm_tile(L.xs[cur], L.head, round4(K_last), hrt, 0);
             const int col = lane & 15;
             const float mine = hr == 0 ? acc[0] : hr == 1 ? acc[1] : hr == 2 ? acc[2] : acc[3];
             const int64_t row = row0 + hrt * 16 + 4 * (lane >> 4) + hr;
-            if (row < a.N && col < O)
-                a.out[((int64_t)e * a.N + row) * O + col] = head_value(a.d, col, mine + L.head_bias[col]);
+            const float hv = head_value(a.d, col, mine + L.head_bias[col]);
+            if (row < a.N && col < O) a.out[((int64_t)e * a.N + row) * O + col] = hv;
+            if constexpr (EPI) {
+                if (epi_on) sample_epilogue(*epi, epi_in, col, hv, lane);
+            }
         } else if (wave < RT) {
             const f32x4 acc = gemm_tile(L.xs[cur], L.head, round4(K_last), wave, 0);
             const int col = lane & 15;
@@ -729,6 +743,30 @@ __global__ __launch_bounds__(TM * 16) void k_mlp_fwd_multi(const MlpMultiArgs m,
         mlp_fwd_tiles<TM, true, false, NB>(m.job[k], local % E, local / E, m.tile_stride[k], L);
     else
         mlp_fwd_tiles<TM, false, false, NB>(m.job[k], local % E, local / E, m.tile_stride[k], L);
+}
+
+// ... with a sampling epilogue per job (asac_mlp_forward_multi_sampled)
+struct SampleEpis {
+    SampleEpi e[ASAC_MLP_MAX_JOBS];
+};
+template <int TM, int NB>
+__global__ __launch_bounds__(TM * 16) void k_mlp_fwd_multi_sampled(const MlpMultiArgs m, const SampleEpis epis, const SidecarsDev sc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= m.blocks) {          // sidecar workgroups (asac_sidecar.h)
+        sidecar_run(sc, (int)blockIdx.x - m.blocks, reinterpret_cast<float*>(smem_raw));
+        return;
+    }
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < ASAC_MLP_MAX_JOBS; ++q)
+        if (q < m.n && (int)blockIdx.x >= m.first_block[q]) k = q;
+    const int local = (int)blockIdx.x - m.first_block[k];
+    const int E = m.E[k];
+    MlpLds<TM>& L = *reinterpret_cast<MlpLds<TM>*>(smem_raw);
+    if (m.job[k].x0_T > 0)
+        mlp_fwd_tiles<TM, true, false, NB, true>(m.job[k], local % E, local / E, m.tile_stride[k], L, &epis.e[k]);
+    else
+        mlp_fwd_tiles<TM, false, false, NB, true>(m.job[k], local % E, local / E, m.tile_stride[k], L, &epis.e[k]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2110,10 +2148,13 @@ static int launch_forward(const asac_mlp_desc_t* desc, const MlpFwdArgs& a, int 
 }
 
 template <int TM, int NB>
-static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const SidecarsDev& sc, hipStream_t s) {
-    static bool attr_done = false;
-    if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi<TM, NB>), sizeof(MlpLds<TM>), attr_done,
-                               "asac_mlp_forward_multi: hipFuncSetAttribute"))
+static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const SidecarsDev& sc, hipStream_t s,
+                                const SampleEpis* epis = nullptr) {
+    static bool attr_done = false, attr_done_epi = false;
+    if (int rc = epis ? set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi_sampled<TM, NB>), sizeof(MlpLds<TM>),
+                                      attr_done_epi, "asac_mlp_forward_multi_sampled: hipFuncSetAttribute")
+                      : set_lds_limit(reinterpret_cast<const void*>(k_mlp_fwd_multi<TM, NB>), sizeof(MlpLds<TM>), attr_done,
+                                      "asac_mlp_forward_multi: hipFuncSetAttribute"))
         return rc;
     MlpMultiArgs m{};
     m.n = n_jobs;
@@ -2140,10 +2181,14 @@ static int launch_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const Si
     const SidecarsDev none{};
     for (int rep = 0; rep < g_launch_repeat; ++rep) {      // (repeat knob: only the last repetition carries the sidecars)
         const bool last = rep == g_launch_repeat - 1;
-        hipLaunchKernelGGL((k_mlp_fwd_multi<TM, NB>), dim3((unsigned)(blocks + (last ? sc.blocks : 0))),
-                           dim3(threads_of<TM>()), lds, s, m, last ? sc : none);
+        if (epis)
+            hipLaunchKernelGGL((k_mlp_fwd_multi_sampled<TM, NB>), dim3((unsigned)(blocks + (last ? sc.blocks : 0))),
+                               dim3(threads_of<TM>()), lds, s, m, *epis, last ? sc : none);
+        else
+            hipLaunchKernelGGL((k_mlp_fwd_multi<TM, NB>), dim3((unsigned)(blocks + (last ? sc.blocks : 0))),
+                               dim3(threads_of<TM>()), lds, s, m, last ? sc : none);
     }
-    return finish_launch("asac_mlp_forward_multi");
+    return finish_launch(epis ? "asac_mlp_forward_multi_sampled" : "asac_mlp_forward_multi");
 }
 
 // waves of k_mlp_bwd on the stock networks' 16-row tiles (A/B builds: -DASAC_BWD_WAVES=8; measured on cfg2, same box,
@@ -2159,8 +2204,9 @@ static int launch_backward(const char* where, const asac_mlp_desc_t* desc, MlpAr
     const bool stock = !wide && stock3(*desc, a.params, a.member_stride) && offsets32(a);
     if (ret) {             // (asac_mlp_backward_qloss_return_ok has said yes: stock network, the tile's steps fit)
         const size_t lds = sizeof(MlpBwdLds<TM>) + (size_t)(2 * ((ret->v.n + 1) | 1) + 2) * TM * sizeof(float);
-        if (!stock || TM * ret->v.n > threads_of<TM>() || lds > 128 * 1024) return bad_arg(where);
         constexpr int w8 = TM == 16 ? ASAC_BWD_WAVES : 0;            // (16-row tiles of the stock networks: see k_mlp_bwd)
+        // one thread per (row, step) of the tile: the launch's own thread count bounds n (16 waves: n <= 64)
+        if (!stock || TM * ret->v.n > (w8 ? 64 * w8 : threads_of<TM>()) || lds > 128 * 1024) return bad_arg(where);
         if (int rc = set_lds_limit(reinterpret_cast<const void*>(k_mlp_bwd<TM, false, 3, true, w8>), 128 * 1024, attr_ret, where))
             return rc;
         ASAC_LAUNCH((k_mlp_bwd<TM, false, 3, true, w8>), dim3(tiles, E), dim3(w8 ? 64 * w8 : threads_of<TM>()), lds, s, a, *ret);
@@ -2266,6 +2312,75 @@ int asac_mlp_forward_multi(const asac_mlp_job_t* jobs, int n_jobs, const asac_si
     if (groups16 <= 256)
         return all_stock ? launch_forward_multi<16, 3>(jobs, n_jobs, sc, s) : launch_forward_multi<16, 0>(jobs, n_jobs, sc, s);
     return all_stock ? launch_forward_multi<32, 3>(jobs, n_jobs, sc, s) : launch_forward_multi<32, 0>(jobs, n_jobs, sc, s);
+}
+
+static bool sample_epilogue_ok(const asac_mlp_job_t& j, const asac_mlp_sample_epilogue_t& h) {
+    const asac_squash_job_t& q = h.sample;
+    if (!j.desc || j.desc->head_transform != 1 || j.desc->head_cols[0] != j.desc->head_cols[1] || j.E != 1) return false;
+    const int A = j.desc->head_cols[0];
+    if (A < 1 || 2 * A > 16 || q.A != A || q.rows != j.N || j.N * (int64_t)A >= 0x7fffffffLL) return false;
+    if (!q.eps && !q.action && !h.eps2) return false;
+    if (q.eps && (!q.a_tanh_out || !q.logp_out)) return false;
+    if (q.x_out) return false;
+    if ((q.action || h.eps2) && (q.T <= 0 || j.N % q.T != 0)) return false;
+    if (q.action) {
+        const int64_t sb = j.N / q.T;
+        if (!q.prob_out || sb * q.action_stride_b + (int64_t)q.T * q.action_stride_t + q.action_offset + A >= 0x7fffffffLL ||
+            sb * q.prob_stride_b + (int64_t)q.T * q.prob_stride_t + q.prob_offset + A >= 0x7fffffffLL ||
+            q.action_stride_b < 0 || q.action_stride_t < 0 || q.prob_stride_b < 0 || q.prob_stride_t < 0)
+            return false;
+    }
+    if (h.eps2 && (!h.a2_out || !h.logp2_out || h.t2 < 0 || h.t2 >= q.T)) return false;
+    return true;
+}
+
+int asac_mlp_forward_multi_sampled_ok(const asac_mlp_job_t* jobs, int n_jobs, const asac_mlp_sample_epilogue_t* epilogues) {
+    if (!jobs || !epilogues || n_jobs < 1 || n_jobs > ASAC_MLP_MAX_JOBS) return 0;
+    bool any = false;
+    for (int k = 0; k < n_jobs; ++k) {
+        const asac_mlp_job_t& j = jobs[k];
+        if (!j.desc || !desc_ok(*j.desc) || j.desc->in0 + j.desc->in1 > kMaxW || j.E <= 0 || j.N <= 0) return 0;
+        const asac_mlp_sample_epilogue_t& h = epilogues[k];
+        const bool on = h.sample.eps || h.sample.action || h.eps2;
+        if (on && !sample_epilogue_ok(j, h)) return 0;
+        // a workgroup pays 2-3 us of transcendental chains per tile it finishes (2 A of a wave's 64 lanes hold a row's
+        // values): worth it while every tile has a workgroup of its own — the elementwise launch it replaces costs ~5 us —,
+        // not where workgroups loop over tiles (cfg3's 20 736-row window: 25.8 us against 19.8 + 5.0 for the two launches)
+        if (on && (j.N + 31) / 32 > 512) return 0;
+        any = any || on;
+    }
+    return any ? 1 : 0;
+}
+
+int asac_mlp_forward_multi_sampled(const asac_mlp_job_t* jobs, int n_jobs, const asac_mlp_sample_epilogue_t* epilogues,
+                                   const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream) {
+    if (!asac_mlp_forward_multi_sampled_ok(jobs, n_jobs, epilogues)) return bad_arg("asac_mlp_forward_multi_sampled");
+    SidecarsDev sc{};
+    if (sidecars_prepare(sidecars_host, n_sidecars, sc)) return bad_arg("asac_mlp_forward_multi_sampled: sidecar");
+    int64_t groups16 = 0;
+    bool all_stock = true;
+    SampleEpis epis{};
+    for (int k = 0; k < n_jobs; ++k) {
+        const asac_mlp_job_t& j = jobs[k];
+        if (!j.x0 || (j.desc->in1 > 0 && !j.x1) || !j.out || j.x0_window_T < 0) return bad_arg("asac_mlp_forward_multi_sampled: job");
+        groups16 += ((j.N + 15) / 16) * j.E;
+        all_stock = all_stock && stock3(*j.desc, j.params, j.member_stride) && j.N * (j.x0_row_stride + j.x1_row_stride + 1) < 0x1fffffffLL &&
+                    (j.x0_window_T == 0 || (j.N / j.x0_window_T + 1) * j.x0_sample_stride < 0x1fffffffLL);
+        const asac_mlp_sample_epilogue_t& h = epilogues[k];
+        const asac_squash_job_t& q = h.sample;
+        SampleEpi& d = epis.e[k];
+        d.on = (q.eps || q.action || h.eps2) ? 1 : 0;
+        if (!d.on) continue;
+        d.eps = q.eps, d.eps2 = h.eps2, d.a_out = q.a_tanh_out, d.logp_out = q.logp_out, d.a2_out = h.a2_out, d.logp2_out = h.logp2_out;
+        d.action = q.action, d.prob_out = q.prob_out;
+        d.a_sb = (int32_t)q.action_stride_b, d.a_st = (int32_t)q.action_stride_t, d.a_off = q.action_offset;
+        d.p_sb = (int32_t)q.prob_stride_b, d.p_st = (int32_t)q.prob_stride_t, d.p_off = q.prob_offset;
+        d.A = q.A, d.T = q.T > 0 ? q.T : 1, d.t2 = h.t2;
+    }
+    hipStream_t s = as_stream(stream);
+    if (groups16 <= 256)
+        return all_stock ? launch_forward_multi<16, 3>(jobs, n_jobs, sc, s, &epis) : launch_forward_multi<16, 0>(jobs, n_jobs, sc, s, &epis);
+    return all_stock ? launch_forward_multi<32, 3>(jobs, n_jobs, sc, s, &epis) : launch_forward_multi<32, 0>(jobs, n_jobs, sc, s, &epis);
 }
 
 /* row tiles (= workgroups along the row axis, = per-tile partial slabs) the backward of this shape uses */
@@ -2544,7 +2659,9 @@ int asac_mlp_backward_qloss_return_ok(const asac_mlp_desc_t* desc, const float* 
     const int tm = mlp_tile_rows(N, E);
     const size_t lds = (tm == 16 ? sizeof(MlpBwdLds<16>) : sizeof(MlpBwdLds<32>)) +
                        (size_t)(2 * ((ret->n + 1) | 1) + 2) * tm * sizeof(float);
-    return tm * ret->n <= tm * 16 && lds <= 128 * 1024;
+    // one thread per (row, step) of a tile: 16-row tiles run ASAC_BWD_WAVES waves (n <= 64 with 16), 32-row tiles 512 threads
+    const int threads = tm == 16 ? 64 * ASAC_BWD_WAVES : 32 * 16;
+    return tm * ret->n <= threads && lds <= 128 * 1024;
 }
 
 int asac_mlp_backward_qloss_return(const asac_mlp_desc_t* desc, const float* params, int64_t member_stride, int E,

@@ -599,6 +599,7 @@ int64_t asac_struct_size(const char* name) {
     ASAC_SZ(asac_mlp_desc_t);
     ASAC_SZ(asac_mlp_job_t);
     ASAC_SZ(asac_pi_q_job_t);
+    ASAC_SZ(asac_mlp_sample_epilogue_t);
     ASAC_SZ(asac_gru_desc_t);
     ASAC_SZ(asac_conv2_desc_t);
     ASAC_SZ(asac_obs_decoder_params_t);

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 76
+ABI_VERSION = 77
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -95,6 +95,9 @@ class MlpJob(C.Structure):
 
 
 MLP_MAX_JOBS = 2
+# the policy forward's sampling epilogue (`mlp_forward_multi_sampled`) instead of a `squash_multi` launch behind it;
+# ASAC_SAMPLE_EPILOGUE=0: the chain (A/B runs)
+SAMPLE_EPILOGUE = _os.environ.get('ASAC_SAMPLE_EPILOGUE', '1') != '0'
 
 
 class Sidecar(C.Structure):
@@ -130,6 +133,12 @@ class PiQJob(C.Structure):
     """asac_pi_q_job_t: policy forward -> sampling -> critics forward over the same rows"""
     _fields_ = [('pi', MlpJob), ('sample', SquashJob), ('eps2', C.c_void_p), ('t2', C.c_int32), ('reserved_', C.c_int32),
                 ('a2_out', C.c_void_p), ('logp2_out', C.c_void_p), ('q', MlpJob)]
+
+
+class SampleEpilogue(C.Structure):
+    """asac_mlp_sample_epilogue_t: asac_squash_multi's jobs as the epilogue of a policy job of `mlp_forward_multi_sampled`"""
+    _fields_ = [('sample', SquashJob), ('eps2', C.c_void_p), ('t2', C.c_int32), ('reserved_', C.c_int32),
+                ('a2_out', C.c_void_p), ('logp2_out', C.c_void_p)]
 
 
 class GruDesc(C.Structure):
@@ -214,6 +223,9 @@ _SIGNATURES = {
     'asac_mlp_forward': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'asac_mlp_forward_multi': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.POINTER(Sidecar), C.c_int, C.c_void_p]),
+    'asac_mlp_forward_multi_sampled_ok': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.POINTER(SampleEpilogue)]),
+    'asac_mlp_forward_multi_sampled': (C.c_int, [C.POINTER(MlpJob), C.c_int, C.POINTER(SampleEpilogue), C.POINTER(Sidecar),
+                                                 C.c_int, C.c_void_p]),
     'asac_mlp_backward_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int64]),
     'asac_mlp_backward_tiles': (C.c_int64, [C.c_int64, C.c_int]),
     'asac_mlp_backward': (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -931,6 +943,56 @@ def mlp_forward_multi(jobs, sidecars=None):
     arr = (MlpJob * len(jobs))(*jobs)
     sc, n_sc = _sidecar_array(sidecars)
     _check(load().asac_mlp_forward_multi(arr, len(jobs), sc, n_sc, _stream()), 'asac_mlp_forward_multi')
+
+
+def sample_epilogue(job: MlpJob | None = None, eps=None, a_out=None, logp_out=None, T=0, action=None, action_offset=0,
+                    prob_out=None, prob_offset=0, eps2=None, t2=0, a2_out=None, logp2_out=None) -> SampleEpilogue:
+    """The epilogue of a policy job of `mlp_forward_multi_sampled` (`job` from `mlp_job`; None / no arguments: the job has
+    none): the main sample over every row (eps -> a_out, logp_out), the stored actions' probabilities ([samples, T, >= A]
+    `action` -> `prob_out`), a second sample at window position `t2` of every sample.  Raw pointers: keep the tensors alive."""
+    e = SampleEpilogue()
+    if job is None:
+        return e
+    A, N = job.desc.contents.head_cols[0], job.N
+    s = e.sample
+    s.rows, s.A, s.T = N, A, T
+    if eps is not None:
+        assert eps.is_contiguous() and a_out.is_contiguous() and eps.numel() == N * A and logp_out.numel() == N
+        assert logp_out.is_contiguous()
+        s.eps, s.a_tanh_out, s.logp_out = eps.data_ptr(), a_out.data_ptr(), logp_out.data_ptr()
+    if action is not None:
+        assert action.dim() == 3 and prob_out.dim() == 3 and action.stride(-1) == 1 and prob_out.stride(-1) == 1
+        assert action.shape[0] * action.shape[1] == N and prob_out.shape[:2] == action.shape[:2]
+        s.T = action.shape[1]
+        assert T in (0, s.T)
+        s.action, s.action_stride_b, s.action_stride_t, s.action_offset = \
+            action.data_ptr(), action.stride(0), action.stride(1), action_offset
+        s.prob_out, s.prob_stride_b, s.prob_stride_t, s.prob_offset = \
+            prob_out.data_ptr(), prob_out.stride(0), prob_out.stride(1), prob_offset
+    if eps2 is not None:
+        assert s.T > 0 and eps2.is_contiguous() and a2_out.is_contiguous() and eps2.numel() == (N // s.T) * A
+        assert logp2_out.is_contiguous() and logp2_out.numel() == N // s.T
+        e.eps2, e.t2, e.a2_out, e.logp2_out = eps2.data_ptr(), t2, a2_out.data_ptr(), logp2_out.data_ptr()
+    return e
+
+
+def mlp_forward_multi_sampled_ok(jobs, epilogues) -> bool:
+    assert len(jobs) == len(epilogues) and 1 <= len(jobs) <= MLP_MAX_JOBS
+    return bool(load().asac_mlp_forward_multi_sampled_ok((MlpJob * len(jobs))(*jobs), len(jobs),
+                                                         (SampleEpilogue * len(jobs))(*epilogues)))
+
+
+@_profiled
+def mlp_forward_multi_sampled(jobs, epilogues, sidecars=None):
+    """`mlp_forward_multi` whose policy jobs sample from / score stored actions under the rows they form (`sample_epilogue`):
+    the policy forward and `squash_multi` as one launch"""
+    global _last_work
+    _last_work = sum(mlp_flops(j.desc.contents, j.E, j.N) for j in jobs)
+    assert len(jobs) == len(epilogues) and 1 <= len(jobs) <= MLP_MAX_JOBS
+    arr = (MlpJob * len(jobs))(*jobs)
+    epi = (SampleEpilogue * len(jobs))(*epilogues)
+    sc, n_sc = _sidecar_array(sidecars)
+    _check(load().asac_mlp_forward_multi_sampled(arr, len(jobs), epi, sc, n_sc, _stream()), 'asac_mlp_forward_multi_sampled')
 
 
 def pi_q_job(pi_job: MlpJob, q_job: MlpJob, eps, a_out, logp_out, T, action=None, action_offset=0, prob_out=None,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 76
+#define ASAC_ABI_VERSION 77
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -522,6 +522,26 @@ typedef struct {
 } asac_mlp_job_t;
 int asac_mlp_forward_multi(const asac_mlp_job_t* jobs_host, int n_jobs, const asac_sidecar_t* sidecars_host,
                            int n_sidecars, void* stream);
+
+/* asac_mlp_forward_multi whose Gaussian-head policy jobs also run asac_squash_multi's jobs on the rows they have just
+ * formed — the chain  policy forward -> [sample a ~ pi(s), log pi(a); pi(stored action); second sample at window position
+ * t2]  of sac_base.py:1346-1351, 1430, 1183-1187, 1452, 2182-2245 as ONE launch: the lanes that hold a row's
+ * (loc | scale) head values in MFMA layout do the elementwise work (csrc/asac_squash.h `sample_epilogue`), bit for bit
+ * what asac_squash_multi writes.  epilogues[k] belongs to jobs[k]; a job without one has sample.eps == sample.action ==
+ * eps2 == NULL.  In `sample`: eps / a_tanh_out / logp_out (main sample over every row), action / prob_out with their strides
+ * and T (stored actions), rows (= the job's N) and A; loc / scale / ls_row_stride / x_out are unused.  A job with an epilogue:
+ * E == 1, head_transform 1, 2 A <= 16.  _ok: 1 when the launch qualifies (at least one epilogue, all of them valid). */
+typedef struct {
+    asac_squash_job_t sample;
+    const float* eps2;          /* [samples][A] or NULL: second sample from row (sample, t2) of every window */
+    int32_t t2;
+    int32_t reserved_;
+    float* a2_out;              /* [samples][A] */
+    float* logp2_out;           /* [samples] */
+} asac_mlp_sample_epilogue_t;
+int asac_mlp_forward_multi_sampled_ok(const asac_mlp_job_t* jobs_host, int n_jobs, const asac_mlp_sample_epilogue_t* epilogues);
+int asac_mlp_forward_multi_sampled(const asac_mlp_job_t* jobs_host, int n_jobs, const asac_mlp_sample_epilogue_t* epilogues,
+                                   const asac_sidecar_t* sidecars_host, int n_sidecars, void* stream);
 
 /* Policy forward -> sampling -> critic ensemble forward over the same rows in ONE launch: the chain
  * asac_mlp_forward(_multi)[policy] -> asac_squash_multi -> asac_mlp_forward(_multi)[critics] of the return target

@@ -117,7 +117,9 @@ def test_q_loss_backward_and_adam_from_partials(N, weighted):
 
 
 @pytest.mark.parametrize('B,n,E,Es,use_is', [(256, 4, 2, 2, True), (100, 1, 3, 2, True), (33, 7, 2, 2, False),
-                                              (1024, 3, 4, 2, True), (256, 16, 2, 2, True)])
+                                              (1024, 3, 4, 2, True), (256, 16, 2, 2, True),
+                                              (256, 40, 2, 2, True),      # BASELINE configs[2]: n_step 40 on 16-wave tiles
+                                              (300, 64, 2, 2, False), (6000, 16, 2, 2, True)])
 def test_q_loss_backward_forming_its_own_return_is_the_chain_bit_for_bit(B, n, E, Es, use_is):
     """`asac_mlp_backward_qloss_return` == `asac_vtrace_return_min` followed by `asac_mlp_backward_qloss`: the return
     target y, the per-member losses and every parameter gradient, bit for bit (reduced in the launch and deferred)."""
@@ -175,8 +177,11 @@ def test_q_loss_backward_forming_its_own_return_is_the_chain_bit_for_bit(B, n, E
             if w_ is not None:
                 assert torch.equal(w_, g_), (name, defer)
     r = ret_args(torch.zeros(B, **f))
-    r.n = 17
+    r.n = 65            # (16-row tiles run 16 waves: one thread per (row, step) up to n = 64; 32-row tiles 512 threads: n <= 16)
     assert not mlp.backward_qloss_return_ok(B, r), 'more steps per tile than threads: the two launches'
+    if B == 6000:
+        r.n = 17
+        assert not mlp.backward_qloss_return_ok(B, r)
 
 
 @pytest.mark.parametrize('N', [256, 45])
@@ -328,6 +333,100 @@ def test_policy_sample_critics_forward_in_one_launch_is_the_chain_bit_for_bit(B,
     assert torch.equal(a_g, a_w) and torch.equal(lp_g, lp_w) and torch.equal(q_g, q_w)
     other = fq.job(torch.randn(N, S, device='cuda'), a_g.view(N, A))[0]
     assert not native.policy_sample_q_forward_ok(native.pi_q_job(job_pi, other, eps, a_g, lp_g, T))
+
+
+@pytest.mark.parametrize('B,T,S,A,E,window', [(256, 5, 6, 2, 2, False), (256, 5, 6, 2, 2, True), (37, 3, 8, 4, 3, True),
+                                               (1024, 9, 8, 4, 2, False), (6000, 2, 6, 2, 2, False), (256, 41, 8, 2, 2, True),
+                                               (19, 4, 6, 8, 1, False)])
+def test_policy_forward_with_sampling_epilogue_is_the_chain_bit_for_bit(B, T, S, A, E, window):
+    """`asac_mlp_forward_multi_sampled` against `asac_mlp_forward_multi` -> `asac_squash_multi`: the policy's (loc | scale),
+    the main sample and its log-probabilities, the stored actions' probabilities, the second sample at a window position —
+    and a critic job riding beside it — identical bit for bit; every subset of the epilogue's three parts; 16- and 32-row
+    tiles; window addressing; two policy jobs with an epilogue each."""
+    from asac_amd import native
+    _, _, fq = _setup(E, S, A)
+    _, _, fpi = _setup(1, S, A, policy=True)
+    N = B * T
+    f = dict(device='cuda')
+    torch.manual_seed(B * T + A)
+    if window:
+        base = torch.randn(B, T + 2, S, **f)
+        xs = native.WindowRows(base[:, 2:])
+    else:
+        xs = torch.randn(N, S, **f)
+    eps, eps2 = torch.randn(N, A, **f), torch.randn(B, A, **f)
+    stored = torch.rand(B, T, A + 1, **f) * 1.9 - 0.95       # stored actions behind one discrete column
+    x0, a0 = torch.randn(B, S, **f), torch.randn(B, A, **f).tanh()
+    t2 = T - 1
+
+    def outs():
+        return dict(a=torch.zeros(B, T, A, **f), lp=torch.zeros(B, T, **f), pr=torch.zeros(B, T, A + 2, **f),
+                    a2=torch.zeros(B, A, **f), lp2=torch.zeros(B, **f))
+
+    for main, prob, second in ((True, True, True), (True, False, False), (False, True, False), (False, False, True),
+                               (True, False, True), (False, True, True)):
+        # the chain
+        w = outs()
+        job_x, x_w = fq.job(x0, a0)
+        job_pi, ls_w = fpi.job(xs, None)
+        native.mlp_forward_multi([job_x, job_pi])
+        ls = ls_w[0].view(B, T, 2 * A)
+        jobs = []
+        if main or prob:
+            jobs.append(native.squash_job(ls[..., :A], ls[..., A:], eps if main else None, w['a'] if main else None,
+                                          w['lp'] if main else None, stored if prob else None, 1, w['pr'][..., 1:] if prob else None, 0))
+        if second:
+            jobs.append(native.squash_job(ls[:, t2, :A], ls[:, t2, A:], eps2, w['a2'], w['lp2']))
+        native.squash_multi(jobs)
+        # one launch
+        g = outs()
+        job_x2, x_g = fq.job(x0, a0)
+        job_pi2, ls_g = fpi.job(xs, None)
+        epi = native.sample_epilogue(job_pi2, eps if main else None, g['a'] if main else None, g['lp'] if main else None, T,
+                                     action=stored if prob else None, action_offset=1, prob_out=g['pr'][..., 1:] if prob else None,
+                                     eps2=eps2 if second else None, t2=t2, a2_out=g['a2'] if second else None,
+                                     logp2_out=g['lp2'] if second else None)
+        both = [job_x2, job_pi2], [native.sample_epilogue(), epi]
+        assert native.mlp_forward_multi_sampled_ok(*both)
+        with native.LaunchProfiler(repeat=1) as prof:
+            native.mlp_forward_multi_sampled(*both)
+        assert list(prof.summary()) == ['asac_mlp_forward_multi_sampled']
+        assert torch.equal(ls_g[0], ls_w[0]) and torch.equal(x_g, x_w), (main, prob, second)
+        for k in w:
+            assert torch.equal(g[k], w[k]), (k, main, prob, second)
+        if main:
+            assert g['lp'].abs().sum() > 0 and torch.isfinite(g['lp']).all()
+    # two policy jobs, an epilogue each (the TD target's own policy pass beside the window's)
+    xs_b = torch.randn(B * 2, S, **f)
+    eps_b = torch.randn(B * 2, A, **f)
+    job_a, ls_a = fpi.job(xs, None)
+    job_b, ls_b = fpi.job(xs_b, None)
+    native.mlp_forward_multi([job_a, job_b])
+    w, wb = outs(), (torch.zeros(B * 2, A, **f), torch.zeros(B * 2, **f))
+    la, lb = ls_a[0].view(B, T, 2 * A), ls_b[0].view(B * 2, 2 * A)
+    native.squash_multi([native.squash_job(la[..., :A], la[..., A:], action=stored, action_offset=1, prob_out=w['pr'][..., 1:]),
+                         native.squash_job(la[:, t2, :A], la[:, t2, A:], eps2, w['a2'], w['lp2']),
+                         native.squash_job(lb[..., :A], lb[..., A:], eps_b, *wb)])
+    g, gb = outs(), (torch.zeros(B * 2, A, **f), torch.zeros(B * 2, **f))
+    job_a, ls_a2 = fpi.job(xs, None)
+    job_b, ls_b2 = fpi.job(xs_b, None)
+    native.mlp_forward_multi_sampled(
+        [job_a, job_b],
+        [native.sample_epilogue(job_a, action=stored, action_offset=1, prob_out=g['pr'][..., 1:], eps2=eps2, t2=t2,
+                                a2_out=g['a2'], logp2_out=g['lp2']),
+         native.sample_epilogue(job_b, eps_b, *gb)])
+    assert torch.equal(ls_a2[0], ls_a[0]) and torch.equal(ls_b2[0], ls_b[0])
+    for k in w:
+        assert torch.equal(g[k], w[k]), k
+    assert torch.equal(gb[0], wb[0]) and torch.equal(gb[1], wb[1])
+    # what does not qualify: no epilogue at all, an epilogue on a critic job
+    assert not native.mlp_forward_multi_sampled_ok([job_a], [native.sample_epilogue()])
+    bad = native.sample_epilogue(job_a, eps, g['a'], g['lp'], T)
+    assert not native.mlp_forward_multi_sampled_ok([fq.job(x0, a0)[0]], [bad])
+    # ... and windows whose tiles outnumber the launch's workgroups (the epilogue would run several times per workgroup)
+    big = fpi.job(torch.randn(20000, S, **f), None)[0]
+    eb = native.sample_epilogue(big, torch.randn(20000, A, **f), torch.zeros(20000, A, **f), torch.zeros(20000, **f), 1)
+    assert not native.mlp_forward_multi_sampled_ok([big], [eb])
 
 
 @pytest.mark.parametrize('N', [256, 1280, 7])
