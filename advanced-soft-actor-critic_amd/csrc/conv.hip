@@ -341,6 +341,73 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         e_bias[q] = oc < d.O2 ? a.b2[oc] : 0.f;
     }
 
+    // DIRECT (16-byte aligned filters): every lane reads the weights of its MFMA B operands where they lie, 16 bytes at a
+    // time — the reduction index a (quad q, lane group lk, step u) of layer 1 stands for is 16 q + 4 lk + u, i.e. four
+    // CONSECUTIVE filter taps per lane (the order of a reduction is free as long as both operands agree on it), and
+    // likewise k = 128 kh + 16 j + 4 lk + t for layer 2 — so a wave's load covers 64-byte pieces of 16 filter rows, nothing
+    // passes through the frame buffer, and the first group's frames are requested at kernel entry: all of it travels under
+    // the index-table builds.  (Round 3 / 5 read single taps per lane, 768 bytes apart: the grid's waves queued on a
+    // handful of L2 channels, +3.5 us; staged through the frame buffer the set-up ended 10.3 us after entry at 4 608
+    // frames.)  Unaligned filters (a plugin with an odd parameter in front of them) take the staged path.
+    const bool direct = ((reinterpret_cast<uintptr_t>(a.w1) | reinterpret_cast<uintptr_t>(a.w2)) & 15) == 0;
+    const bool dma = TILED ||
+                     ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0);
+    const int Q1 = d.K1 / 16;
+    // layer-2 weights of this wave's (column tile, k half): B operand element (k = 4 step + lk, column lr)
+    const int ct = wave >> 1, kh = wave & 1;
+    constexpr int S2H = kConvMaxK / 8;           // steps per k half
+    float w2r[S2H];
+    const int oc2 = ct * 16 + lr;
+    constexpr int QR = Q1C > 0 ? Q1C : 1;
+    int4 ko_r[QR];
+    float4 w_r[QR];
+    if (direct) {
+        if (TILED) {
+            build_croptab(d, croptab);
+            __syncthreads();
+        }
+        if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
+        const float4* w2p = reinterpret_cast<const float4*>(a.w2 + (int64_t)min(oc2, d.O2 - 1) * d.K2);
+#pragma unroll
+        for (int j = 0; j < S2H / 4; ++j) {
+            const int k = kh * (4 * S2H) + 16 * j + 4 * lk;
+            const float4 v = w2p[min(k, d.K2 - 4) >> 2];
+            const bool on = k < d.K2 && oc2 < d.O2;
+            w2r[4 * j] = on ? v.x : 0.f, w2r[4 * j + 1] = on ? v.y : 0.f, w2r[4 * j + 2] = on ? v.z : 0.f, w2r[4 * j + 3] = on ? v.w : 0.f;
+        }
+        const float4* w1p = reinterpret_cast<const float4*>(a.w1 + (int64_t)min(lr, d.O1 - 1) * d.K1) + lk;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Q1C > 0) {
+#pragma unroll
+            for (int q = 0; q < QR; ++q) w_r[q] = lr < d.O1 ? w1p[q * 4] : zero4;
+        }
+        // (the LDS table of the tail tiles / of the quad counts without a register form: quad q by wave q % 4)
+        float4 w1t[kConvMaxK / 64];
+#pragma unroll
+        for (int i = 0; i < kConvMaxK / 64; ++i) {
+            const int q = wave + 4 * i;
+            w1t[i] = (q < Q1 && lr < d.O1) ? w1p[min(q, Q1 - 1) * 4] : zero4;
+        }
+        for (int k = threadIdx.x; k < kConvMaxK; k += kConvThreads) {
+            ktab[k] = k < d.K1 ? patch_offset(k, d.k1, d.H * d.W, d.W) : 0;
+            // (entry 4 (kh S2H + s) + lk, what layer 2 reads for step s, stands for k = 128 kh + 16 (s / 4) + 4 lk + s % 4)
+            const int s2 = (k >> 2) & (S2H - 1), k2 = (k >> 7) * (4 * S2H) + 16 * (s2 >> 2) + 4 * (k & 3) + (s2 & 3);
+            koff2[k] = k2 < d.K2 ? patch_offset(k2, d.k2, d.M1, d.W1) : 0;
+        }
+        for (int row = threadIdx.x; row < rows_pad; row += kConvThreads) {
+            const int rr = min(row, d.rows1 - 1);          // the tail tile re-reads a valid position
+            const int im = rr / d.M1, pos = rr - im * d.M1, oy = pos / d.W1, ox = pos - oy * d.W1;
+            rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
+            rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < kConvMaxK / 64; ++i) {
+            const int q = wave + 4 * i;
+            if (q < Q1) reinterpret_cast<float4*>(w1q)[q * 64 + lane] = w1t[i];
+        }
+        __syncthreads();           // ktab is complete
+        for (int i = threadIdx.x; i < Q1 * 16; i += kConvThreads) ktq[i] = ktab[i];     // (q, lk, u) <-> k = 16 q + 4 lk + u
+    } else {
     for (int k = threadIdx.x; k < kConvMaxK; k += kConvThreads) {
         ktab[k] = k < d.K1 ? patch_offset(k, d.k1, d.H * d.W, d.W) : 0;
         koff2[k] = k < d.K2 ? patch_offset(k, d.k2, d.M1, d.W1) : 0;
@@ -351,13 +418,6 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
-    const int Q1 = d.K1 / 16;
-    // layer-2 weights of this wave's (column tile, k half): B operand element (k = 4 step + lk, column lr)
-    const int ct = wave >> 1, kh = wave & 1;
-    constexpr int S2H = kConvMaxK / 8;           // steps per k half
-    float w2r[S2H];
-    const int oc2 = ct * 16 + lr;
-    {
     if (TILED) build_croptab(d, croptab);
     // parameters pass through the (still free) work area: W1 | W2
     coop_copy2(a.w1, d.O1 * d.K1, a.w2, d.O2 * d.K2, img);
@@ -407,24 +467,21 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < S2H; ++s) settle(w2r[s]);
     settle(e_bias[0]); settle(e_bias[1]); settle(b1e); settle(b1s);
-    // (Q1C > 0: the full tiles' operand constants, read from the tables once)
-    constexpr int QR = Q1C > 0 ? Q1C : 1;
-    int4 ko_r[QR];
-    float4 w_r[QR];
+    // (Q1C > 0: the full tiles' operand constants, read from the tables once; the weights came straight from memory where
+    // the filters are aligned)
     if (Q1C > 0) {
 #pragma unroll
         for (int q = 0; q < QR; ++q) {
             ko_r[q] = (reinterpret_cast<const int4*>(ktq) + lk)[q * 4];
-            w_r[q] = (reinterpret_cast<const float4*>(w1q) + lane)[q * 64];
+            if (!direct) w_r[q] = (reinterpret_cast<const float4*>(w1q) + lane)[q * 64];
+            settle(w_r[q].x); settle(w_r[q].y); settle(w_r[q].z); settle(w_r[q].w);
         }
     }
 
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
     // (tiled mode: the host has checked the 16-byte granularity the crops need)
-    const bool dma = TILED ||
-                     ((d.CHW & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (a.x_sample_stride & 3) == 0);
-    if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
+    if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         const int n_img = (int)min((int64_t)d.G, a.N - g * d.G);
         const TileAt at = tile_at<TILED>(d, g);
