@@ -16,7 +16,7 @@ from asac_amd import native
 
 from .fused_mlp import _flat_alias, direct_enabled
 
-__all__ = ['fused_conv_stack', 'conv_stack_desc']
+__all__ = ['fused_conv_stack', 'conv_stack_desc', 'DeferredConvBackward']
 
 # add the parameter gradients into existing consecutive `.grad` views from the reduction kernel itself
 DIRECT_PARAM_GRADS = True
@@ -43,6 +43,62 @@ def conv_stack_desc(conv_layers, x):
     desc = native.conv2_desc(x.shape[1], x.shape[2], x.shape[3], c1.out_channels, c1.kernel_size[0], c1.stride[0],
                              c2.out_channels, c2.kernel_size[0], c2.stride[0])
     return desc if native.conv2_supported(desc) else None
+
+
+class DeferredConvBackward:
+    """Several backward walks of ONE forward pass with the convolution stack's share of them as ONE launch.
+
+    The reference differentiates the representation's graph once per gated auxiliary loss (`calculate_adaptive_weights`,
+    sac_base.py:1607-1631); the convolution stack is the LEAF of each of these walks (frames are data), so its backward can
+    wait: inside `with DeferredConvBackward() as d:` a `_ConvStackFn.backward` only records its output gradient under the
+    current `d.walk` index and hands autograd no parameter gradients; `d.flush()` then runs `asac_conv2_backward_multi` once
+    per forward pass that was reached — frames, saved pre-activations and the gathered patch operands shared by the
+    cotangents — and returns, per walk, {parameter id: gradient}.  Bit-identical to the walks' own launches."""
+    _active = None
+
+    def __init__(self):
+        self.walk = 0
+        self._pending = {}       # id(ctx) -> (ctx, {walk: grad_y})
+
+    def __enter__(self):
+        assert DeferredConvBackward._active is None
+        DeferredConvBackward._active = self
+        return self
+
+    def __exit__(self, *exc):
+        DeferredConvBackward._active = None
+
+    def record(self, ctx, grad_y) -> bool:
+        entry = self._pending.setdefault(id(ctx), (ctx, {}))
+        if self.walk in entry[1]:          # (the same node twice in one walk: not a case this form handles)
+            return False
+        entry[1][self.walk] = grad_y.contiguous()
+        return True
+
+    def flush(self) -> dict:
+        """-> {walk: {id(param): gradient tensor}} (gradients of a parameter reached through several forward passes summed)"""
+        out = {}
+        for ctx, by_walk in self._pending.values():
+            desc = ctx.desc
+            x, z1, z2, w2 = ctx.saved_tensors
+            n_frames = x.shape[0] * x.shape[1] if ctx.windows else x.shape[0]
+            walks = sorted(by_walk)
+            for lo in range(0, len(walks), native.CONV2_MAX_COTANGENTS):
+                part = walks[lo:lo + native.CONV2_MAX_COTANGENTS]
+                n = native.conv2_param_count(desc)
+                g = torch.empty(len(part), n, dtype=x.dtype, device=x.device)
+                ws = torch.empty(len(part) * native.conv2_backward_workspace(desc, n_frames), dtype=x.dtype, device=x.device)
+                native.conv2_backward_multi(desc, x, w2.detach().contiguous(), z1, z2, [by_walk[k] for k in part], g, ws)
+                for row, k in enumerate(part):
+                    off, grads = 0, out.setdefault(k, {})
+                    for p_ in ctx.params:
+                        cnt = p_.numel()
+                        if p_.requires_grad:
+                            piece = g[row, off:off + cnt].view(p_.shape)
+                            grads[id(p_)] = piece if id(p_) not in grads else grads[id(p_)] + piece
+                        off += cnt
+        self._pending = {}
+        return out
 
 
 class _ConvStackFn(torch.autograd.Function):
@@ -88,6 +144,9 @@ class _ConvStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         desc = ctx.desc
+        deferred = DeferredConvBackward._active
+        if deferred is not None and deferred.record(ctx, grad_y):
+            return (None, None, None, None, None, None, None, None)
         x, z1, z2, w2 = ctx.saved_tensors
         n_frames = x.shape[0] * x.shape[1] if ctx.windows else x.shape[0]
         run = native.conv2_backward_windows if ctx.windows else native.conv2_backward

@@ -444,15 +444,30 @@ class AuxHeadsMixin:
             # the representation's graph is entered from there once per loss as in `calculate_adaptive_weights`.
             rep_params = list(self.model_rep.parameters())
             aux, gs = [], []
+            # the convolution stack is the leaf of each of the three walks through the representation: its backward waits
+            # until all three output gradients are known and runs as ONE launch (fused_conv.DeferredConvBackward)
+            from .fused_conv import DeferredConvBackward
+            conv_later = DeferredConvBackward() if self._rpm_conv_one_launch else None
             for loss_i, params_i in zip(losses, model_params):
                 got = autograd.grad(loss_i, [nx_states, *params_i], grad_outputs=unit_gradient(loss_i), allow_unused=True,
                                     retain_graph=True)
                 gs += got[1:]
                 if got[0] is None:
                     aux.append([None] * len(rep_params))
-                else:
+                elif conv_later is None:
                     aux.append(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
                                              retain_graph=True))
+                else:
+                    conv_later.walk = len(aux)
+                    with conv_later:
+                        aux.append(list(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
+                                                      retain_graph=True)))
+            if conv_later is not None:
+                for walk, grads in conv_later.flush().items():
+                    for j, p_ in enumerate(rep_params):
+                        g_conv = grads.get(id(p_))
+                        if g_conv is not None:
+                            aux[walk][j] = g_conv if aux[walk][j] is None else aux[walk][j] + g_conv
             self._add_gated_gradients(grads_rep_main, aux, rep_params)
         else:
             if grads_rep_main:

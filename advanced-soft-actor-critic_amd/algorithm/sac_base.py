@@ -260,6 +260,8 @@ class SAC_Base(AuxHeadsMixin):
         # one backward walk per prediction model (gates and model gradients from it): sac_aux._train_rpm
         self._rpm_single_backward = bool(hip_config.get('rpm_single_backward', True))
         self._fused_gating = bool(hip_config.get('fused_gating', True))          # asac_cosine_gate_add
+        # the convolution stack's share of the three per-loss walks of `_train_rpm` as one launch (asac_conv2_backward_multi)
+        self._rpm_conv_one_launch = bool(hip_config.get('rpm_conv_one_launch', True))
         # one sampled batch in flight, the reference's schedule (replay_buffer.py:275, 339-396): see `_step_sample`
         self._lookahead = int(hip_config.get('lookahead', 0))
         assert self._lookahead in (0, 1), 'hip_config lookahead: 0 (synchronous sampling) or 1 (one batch in flight)'

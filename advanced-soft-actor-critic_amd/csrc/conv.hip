@@ -33,9 +33,20 @@
 #include "asac_common.h"
 #include "asac_gelu.h"
 
+#include <type_traits>
+
 namespace asac {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// a pointer into device memory as such: a load through a pointer the compiler cannot place (one selected between an LDS
+// and a global address, or derived through clamps from a by-value argument struct) becomes a FLAT load — it counts
+// against both wait counters, so the LDS-only barriers of these kernels wait for it, and `s_waitcnt vmcnt(0)` in front of
+// its use also drains an LDS-DMA prefetch issued before it (k_conv2_bwd's first phase: a third of the launch, round 6)
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+    return (const __attribute__((address_space(1))) T*)p;
+}
 
 constexpr int kConvThreads = 256;              // 4 waves
 constexpr int kConvMaxK = ASAC_CONV2_MAX_K;     // patch length of either layer (C*k1*k1, O1*k2*k2)
@@ -67,6 +78,8 @@ struct ConvArgs {
     float* z1;                                  // [N][M1][O1] pre-activations (position-major) or NULL
     float* z2;                                  // [N][O2*M2] pre-activations or NULL
     const float* gy;                            // backward: gradient of y
+    const float* gy_more[3];                    // ... of cotangents 1 .. NC - 1 (k_conv2_bwd<., NC>: several backward walks of ONE
+                                                //     forward pass as one launch; slab c of a block's partials behind slab c - 1)
     float* partial;                             // backward: [blocks][param_count]
     int64_t N, n_groups;
     // forward over a SLICE of sampled windows (x[:, b:] of [B][L][C][H][W], read in place): a sample's frames are
@@ -367,26 +380,29 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             __syncthreads();
         }
         if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
-        const float4* w2p = reinterpret_cast<const float4*>(a.w2 + (int64_t)min(oc2, d.O2 - 1) * d.K2);
+        const auto* w2p = as_global(reinterpret_cast<const f32x4*>(a.w2 + (int64_t)min(oc2, d.O2 - 1) * d.K2));
 #pragma unroll
         for (int j = 0; j < S2H / 4; ++j) {
             const int k = kh * (4 * S2H) + 16 * j + 4 * lk;
-            const float4 v = w2p[min(k, d.K2 - 4) >> 2];
+            const f32x4 v = w2p[min(k, d.K2 - 4) >> 2];
             const bool on = k < d.K2 && oc2 < d.O2;
             w2r[4 * j] = on ? v.x : 0.f, w2r[4 * j + 1] = on ? v.y : 0.f, w2r[4 * j + 2] = on ? v.z : 0.f, w2r[4 * j + 3] = on ? v.w : 0.f;
         }
-        const float4* w1p = reinterpret_cast<const float4*>(a.w1 + (int64_t)min(lr, d.O1 - 1) * d.K1) + lk;
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const auto* w1p = as_global(reinterpret_cast<const f32x4*>(a.w1 + (int64_t)min(lr, d.O1 - 1) * d.K1) + lk);
+        auto load4 = [&](int i, bool on) {
+            const f32x4 v = w1p[i];
+            return on ? make_float4(v.x, v.y, v.z, v.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
         if (Q1C > 0) {
 #pragma unroll
-            for (int q = 0; q < QR; ++q) w_r[q] = lr < d.O1 ? w1p[q * 4] : zero4;
+            for (int q = 0; q < QR; ++q) w_r[q] = load4(q * 4, lr < d.O1);
         }
         // (the LDS table of the tail tiles / of the quad counts without a register form: quad q by wave q % 4)
         float4 w1t[kConvMaxK / 64];
 #pragma unroll
         for (int i = 0; i < kConvMaxK / 64; ++i) {
             const int q = wave + 4 * i;
-            w1t[i] = (q < Q1 && lr < d.O1) ? w1p[min(q, Q1 - 1) * 4] : zero4;
+            w1t[i] = load4(min(q, Q1 - 1) * 4, q < Q1 && lr < d.O1);
         }
         for (int k = threadIdx.x; k < kConvMaxK; k += kConvThreads) {
             ktab[k] = k < d.K1 ? patch_offset(k, d.k1, d.H * d.W, d.W) : 0;
@@ -566,8 +582,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 //      position offsets.  Per-lane constants (patch offsets of the lane's gradient columns, the W2 elements of its
 //      da1 column tiles) live in registers; 76 KB for 30x30 frames: two workgroups per CU
 // ------------------------------------------------------------------------------------------------
-struct ConvBwdPlan { int img, img_size, zraw, g1, a1, da1, dz2, rowoff1, rowa, ktab, red, croptab, total; };
-__host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d) {
+struct ConvBwdPlan { int img, img_size, zraw, g1, a1, da1, da1_size, dz2, rowoff1, rowa, ktab, red, croptab, total; };
+// nc cotangents (k_conv2_bwd<., NC>): one dz2 and one da1 buffer each.  dz1 = da1 * gelu'(z1): a single cotangent forms it
+// in place of gelu'(z1) (position-major: conflict-free A operand reads), several form it in place of their da1
+// (channel-major: 2-way conflicts on 4 NC of a step's 16 + 4 NC reads) — a third set of buffers would not fit the 160 KB
+// beside the double-buffered frames (30 x 30: 130 KB + 11.2 KB per further cotangent)
+__host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc = 1) {
     ConvBwdPlan p;
     int off = 0;
     auto take = [&](int n) { const int o = off; off += (n + 3) & ~3; return o; };
@@ -577,8 +597,9 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d) {
     p.zraw = take((d.rows1 * d.O1 + 255) & ~255);   // the group's saved z1 rows as they sit in HBM (LDS-DMA target)
     p.g1 = take(rows_pad * 16);                  // gelu'(z1), then dz1: [position row][16 channels]
     p.a1 = take(d.G * d.O1 * d.M1);
-    p.da1 = take(d.G * d.O1 * d.M1);
-    p.dz2 = take(16 * 32);
+    p.da1_size = (d.G * d.O1 * d.M1 + 3) & ~3;
+    p.da1 = take(nc * p.da1_size);
+    p.dz2 = take(nc * 16 * 32);
     p.rowoff1 = take(rows_pad);
     p.rowa = take(rows_pad);
     p.ktab = take(2 * kConvMaxK);
@@ -591,19 +612,42 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d) {
 // packed parameter gradients: w1 | b1 | w2 | b2
 __host__ __device__ inline int conv_param_count(const ConvDims& d) { return d.O1 * d.K1 + d.O1 + d.O2 * d.K2 + d.O2; }
 
+// phase clocks of workgroup 0 (thread 0) summed over its groups, for tools/debug/conv_bwd_phases.py; compiled out of the library
+#ifdef ASAC_CONV_STAMPS
+__device__ unsigned long long g_conv_stamps[16];
+#define CONV_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[10] = {}
+#define CONV_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#define CONV_STAMP_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 10; ++k_) g_conv_stamps[k_] = st_acc[k_]; } while (0)
+extern "C" int asac_debug_conv_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define CONV_STAMP_INIT
+#define CONV_STAMP(k)
+#define CONV_STAMP_FLUSH
+#endif
+
 constexpr int kNT1 = kConvMaxK / 16 / 4;        // layer-1 weight-gradient column tiles per wave (k1 index / 16)
 constexpr int kNT2 = kConvMaxK / 16 / 4;        // layer-2 weight-gradient column tiles per wave, per row tile
 
-template <bool TILED>
+// NC > 1: the backward walks of NC cotangents through ONE forward pass (the per-loss gradients of `calculate_adaptive_weights`,
+// reference sac_base.py:1607-1631: the representation's graph differentiated once per gated loss) as one launch.  Everything that
+// does not depend on the cotangent is done once per group of frames — the frames' and z1 rows' DMA, a1 and gelu'(z1), and
+// above all the B operands of the two weight-gradient products, the patch elements gathered from LDS (the launch is bound
+// by those gathers, not by its MFMAs) — and feeds NC MFMAs where it fed one.  Per cotangent the same operations in the same
+// order as the single form: bit-identical gradients.
+// KT1: layer-1 weight-gradient column tiles per wave — 3 for filters of <= 192 taps (8 x 8 over RGB frames: 12 tiles; a fourth
+// per wave ran on clamped operands and was never stored: a quarter of the phase's gathers and MFMAs), else 4
+template <bool TILED, int NC = 1, int KT1 = kNT1>
 __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvDims& d = a.d;
-    const ConvBwdPlan p = conv_bwd_plan(d);
+    const ConvBwdPlan p = conv_bwd_plan(d, NC);
     float* zraw = lds + p.zraw;
     float* g1 = lds + p.g1;
     float* a1 = lds + p.a1;
-    float* da1 = lds + p.da1;
-    float* dz2 = lds + p.dz2;
+    float* da1 = lds + p.da1;              // [NC][da1_size]
+    float* dz2 = lds + p.dz2;              // [NC][16 * 32]
     int* rowoff1 = reinterpret_cast<int*>(lds + p.rowoff1);
     int* rowa = reinterpret_cast<int*>(lds + p.rowa);
     int* ktab = reinterpret_cast<int*>(lds + p.ktab);
@@ -628,10 +672,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     }
     __syncthreads();
     // this lane's gradient columns: k index 16 c + lr of column tile c = wave + 4 i
-    int k1off[kNT1], k2off[kNT2];
+    int k1off[KT1], k2off[kNT2];
     float w2b[kNT2][8];             // W2[4 s + lk][16 c + lr]: B operand of the da1 GEMM (reduction over out2)
 #pragma unroll
-    for (int i = 0; i < kNT1; ++i) {
+    for (int i = 0; i < KT1; ++i) {
         const int c = wave + 4 * i;
         k1off[i] = c < NT1 ? ktab[c * 16 + lr] : 0;
     }
@@ -646,12 +690,16 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         }
     }
     // accumulators: dW1 [O1 <= 16][K1]: column tiles c = wave + 4 i;  dW2 [O2 <= 32][K2]: row tiles 0/1, same columns
-    f32x4 dw1[kNT1], dw2[2][kNT2];
+    f32x4 dw1[NC][KT1], dw2[NC][2][kNT2];
+    float db1[NC], db2[NC];                      // thread (channel = tid % 16 | tid % 32, row slice) partial bias sums
 #pragma unroll
-    for (int i = 0; i < kNT1; ++i) dw1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < NC; ++c) {
 #pragma unroll
-    for (int i = 0; i < kNT2; ++i) dw2[0][i] = dw2[1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float db1 = 0.f, db2 = 0.f;                  // thread (channel = tid % 16 | tid % 32, row slice) partial bias sums
+        for (int i = 0; i < KT1; ++i) dw1[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < kNT2; ++i) dw2[c][0][i] = dw2[c][1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db1[c] = db2[c] = 0.f;
+    }
     // layer-2 positions: row = frame*M2 + pos of the group's 16; this lane's B rows (4 step + lk) and accumulator
     // rows (4 lk + r), and the two dz2 elements (e / 32, e % 32) this thread forms
     // (rows beyond the group's G * M2 positions — 7 of the 16 with a 3 x 3 block — carry dz2 = 0: their operand
@@ -701,19 +749,25 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         async_copy_kib(a.z1 + first * d.M1 * d.O1, zraw, (n_img * d.M1 * d.O1) >> 2, (d.rows1 * d.O1 + 255) >> 8, wave,
                        lane);
     };
-    float gy_n[2] = {0.f, 0.f}, z2_n[2] = {0.f, 0.f};
+    float gy_n[NC][2], z2_n[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gy_n[c][0] = gy_n[c][1] = 0.f;
     auto fetch_out = [&](int64_t g) {
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
         const TileAt at = tile_at<TILED>(d, g);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            gy_n[q] = z2_n[q] = 0.f;
+            z2_n[q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) gy_n[c][q] = 0.f;
             if (e_out[q] >= 0 && e_im[q] < n_img && (!TILED || (e_py[q] >= at.skip_y && e_px[q] >= at.skip_x))) {
                 const int64_t o = TILED ? (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] +
                                               (at.r0 + e_py[q]) * d.FW2 + at.c0 + e_px[q]
                                         : (first + e_im[q]) * (d.O2 * d.M2) + e_out[q];
-                gy_n[q] = a.gy[o];
+                gy_n[0][q] = a.gy[o];
+#pragma unroll
+                for (int c = 1; c < NC; ++c) gy_n[c][q] = a.gy_more[c - 1][o];
                 z2_n[q] = a.z2[o];
             }
         }
@@ -726,74 +780,135 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         fetch_out(blockIdx.x);
     }
     int buf = 0;
+    CONV_STAMP_INIT;
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x, buf ^= 1) {
+        CONV_STAMP(9);
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
         float* img = lds + p.img + buf * p.img_size;
         const bool more = g + gridDim.x < a.n_groups;
-        const float gy_c[2] = {gy_n[0], gy_n[1]}, z2_c[2] = {z2_n[0], z2_n[1]};
+        float gy_c[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gy_c[c][0] = gy_n[c][0], gy_c[c][1] = gy_n[c][1];
+        const float z2_c[2] = {z2_n[0], z2_n[1]};
         if (dma) {
             dma_barrier();             // this group's frames and z1 rows have landed (all waves' pieces)
-            if (more) request(g + gridDim.x, buf ^ 1);
+            CONV_STAMP(0);
         } else {
             stage_frames(a, g, img);
         }
-        if (more) fetch_out(g + gridDim.x);
+        // (the next group's frames / z1 rows / output-side operands are requested BEHIND the first phase, not here: that
+        // phase reads LDS the DMA path writes (zraw) and registers earlier loads filled (gy, z2), and in front of such a
+        // use the compiler waits for EVERY outstanding memory operation — `s_waitcnt vmcnt(0)` — i.e. for the prefetch just
+        // issued: the launch had no overlap of a group's transfers with the previous group's arithmetic, round 6)
         // z1 (position-major rows, contiguous for the group) -> a1 (channel-major) and gelu'(z1); da1 <- 0
         {
             const float* src = a.z1 + first * d.M1 * d.O1;
             const int count = n_img * d.M1 * d.O1;
-            for (int i = threadIdx.x; i < rows_pad * 16; i += kConvThreads) {
-                const int row = i >> 4, oc = i & 15;
-                float dv = 0.f;
-                const int ab = rowa[row];
-                if (ab >= 0 && oc < d.O1) {
-                    const int j = row * d.O1 + oc;
-                    const float z = j < count ? (dma ? zraw[j] : src[j]) : 0.f;
-                    float v;
-                    gelu_parts(z, v, dv);
-                    a1[ab + oc * d.M1] = v;
-                    if (j >= count) dv = 0.f;
+            // (rows_pad * 16 = RT1 * 256 elements: thread (row slice tid / 16, channel tid % 16) takes RT1 of them, three at a
+            // time with every LDS read of the three issued before the first use — one by one each element waited for two
+            // dependent round trips (its row's offset, then its value): a third of the launch, NOTES round 6)
+            const int oc = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+            constexpr int UB = 3;
+            // (two instantiations: `dma ? zraw[j] : src[j]` selects between an LDS and a global POINTER — a flat load whose
+            // wait, `vmcnt(0)`, also drained the next group's frame DMA requested just above)
+            auto rows = [&](auto from_lds) {
+                constexpr bool LDS = decltype(from_lds)::value;
+                const auto* gsrc = as_global(src);
+                for (int it0 = 0; it0 < d.RT1; it0 += UB) {
+                    int ab[UB], jj[UB];
+                    float zz[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = r0 + 16 * min(it0 + u, d.RT1 - 1);
+                        ab[u] = rowa[row];
+                        jj[u] = row * d.O1 + oc;
+                        const int jc = min(jj[u], count - 1);
+                        if constexpr (LDS) zz[u] = zraw[jc];
+                        else zz[u] = gsrc[jc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        if (it0 + u < d.RT1) {
+                            const int row = r0 + 16 * (it0 + u);
+                            const bool on = ab[u] >= 0 && oc < d.O1, have = jj[u] < count;
+                            float v, dv;
+                            gelu_parts(have ? zz[u] : 0.f, v, dv);
+                            if (on) a1[ab[u] + oc * d.M1] = v;
+                            g1[row * 16 + oc] = (on && have) ? dv : 0.f;
+                        }
+                    }
                 }
-                g1[i] = dv;
-            }
-            for (int i = threadIdx.x; i < d.G * d.O1 * d.M1; i += kConvThreads) da1[i] = 0.f;
+            };
+            if (dma) rows(std::true_type{});
+            else rows(std::false_type{});
+            for (int i = threadIdx.x; i < NC * p.da1_size; i += kConvThreads) da1[i] = 0.f;
             // dz2 [row = frame*M2 + pos][32 channels] = gy * gelu'(z2)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                dz2[threadIdx.x + q * kConvThreads] = gy_c[q] * gelu_grad(z2_c[q]);
+            for (int q = 0; q < 2; ++q) {
+                const float gg = gelu_grad(z2_c[q]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) dz2[c * 512 + threadIdx.x + q * kConvThreads] = gy_c[c][q] * gg;
+            }
         }
         lds_barrier();
-        if (dma && more) request_z(g + gridDim.x);      // the raw rows are consumed
+        CONV_STAMP(1);
+        if (more) {
+            if (dma) {
+                request(g + gridDim.x, buf ^ 1);
+                request_z(g + gridDim.x);               // the raw rows are consumed
+            }
+            fetch_out(g + gridDim.x);
+        }
         // ---- bias 2, dW2 += dz2^T patches(a1), da1 patches = dz2 W2 --------------------------------------
         if (threadIdx.x < 32) {
-            float s = 0.f;
-            for (int row = 0; row < 16; ++row) s += dz2[row * 32 + threadIdx.x];
-            db2 += s;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float s = 0.f;
+                for (int row = 0; row < 16; ++row) s += dz2[c * 512 + row * 32 + threadIdx.x];
+                db2[c] += s;
+            }
         }
         {
             // (column tiles beyond K2 / 16 run on clamped operands and are never stored: a branch around an MFMA makes
             // the compiler shuttle its accumulator between register files on every step)
+            // (the A operands — dz2 of the lane's rows — do not depend on the column tile: read once, not once per tile)
+            float za[NC][4], zb[NC][4];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    za[c][s] = dz2[c * 512 + (4 * s + lk) * 32 + lr], zb[c][s] = dz2[c * 512 + (4 * s + lk) * 32 + 16 + lr];
 #pragma unroll
             for (int i = 0; i < kNT2; ++i) {               // column tile c = wave + 4 i: k2 = 16 c + lr
                 const int ko = k2off[i];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const float bv = a1[rowbase[s] + ko];
-                    const float a0 = dz2[(4 * s + lk) * 32 + lr], a1v = dz2[(4 * s + lk) * 32 + 16 + lr];
-                    dw2[0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, dw2[0][i], 0, 0, 0);
-                    dw2[1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bv, dw2[1][i], 0, 0, 0);
+                    const float bv = a1[rowbase[s] + ko];          // (the gathered patch element: once for all cotangents)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        dw2[c][0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[c][s], bv, dw2[c][0][i], 0, 0, 0);
+                        dw2[c][1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zb[c][s], bv, dw2[c][1][i], 0, 0, 0);
+                    }
                 }
             }
+            CONV_STAMP(2);
             // da1 patch tile [16 rows][16 k2 of column tile c] = dz2 [16][32] * W2[32][k2]
-            f32x4 dp[kNT2];
+            f32x4 dp[NC][kNT2];
 #pragma unroll
-            for (int i = 0; i < kNT2; ++i) {
-                dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NC; ++c) {
+                float zr[8];                               // dz2[row lr][channel 4 s + lk]: the same for every column tile
 #pragma unroll
-                for (int s = 0; s < 8; ++s)                // reduction over the 32 output channels
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dz2[lr * 32 + 4 * s + lk], w2b[i][s], dp[i], 0, 0, 0);
+                for (int s = 0; s < 8; ++s) zr[s] = dz2[c * 512 + lr * 32 + 4 * s + lk];
+#pragma unroll
+                for (int i = 0; i < kNT2; ++i) {
+                    dp[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)                // reduction over the 32 output channels
+                        dp[c][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[s], w2b[i][s], dp[c][i], 0, 0, 0);
+                }
             }
+            CONV_STAMP(3);
             // col2im: the M2 positions of a frame overlap, the k2 indices of one position do not: one pass per
             // position (element r of the accumulator: row 4 lk + r), a barrier between passes
             if (d.M2 <= 4) {
@@ -801,9 +916,19 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                 // a different frame than the other lanes' element r: pass = r, uniform across the wave
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // (a pass's addresses are pairwise distinct — other column tiles, other cotangents' buffers: all reads,
+                    // then all additions, then all writes; one after the other each waited for its own LDS round trip)
+                    float cur[NC][kNT2];
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i)
-                        if (wave + 4 * i < NT2 && (!TILED || acc_pos[r] >= 0)) da1[acc_base[r] + k2off[i]] += dp[i][r];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) cur[c][i] = da1[c * p.da1_size + acc_base[r] + k2off[i]];
+#pragma unroll
+                    for (int i = 0; i < kNT2; ++i)
+                        if (wave + 4 * i < NT2 && (!TILED || acc_pos[r] >= 0)) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + k2off[i]] = cur[c][i] + dp[c][i][r];
+                        }
                     lds_barrier();
                 }
             } else {
@@ -819,88 +944,169 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                             const int ko = k2off[i];
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if ((TILED ? acc_col[r] : acc_pos[r]) == col) da1[acc_base[r] + ko] += dp[i][r];
+                                if ((TILED ? acc_col[r] : acc_pos[r]) == col) {
+#pragma unroll
+                                    for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + ko] += dp[c][i][r];
+                                }
                         }
                     }
                     lds_barrier();
                 }
             }
         }
+        CONV_STAMP(4);
         // ---- dz1 = da1 * gelu'(z1) (position-major, in place of gelu'), bias 1 -------------------------------
         {
-            const int oc = threadIdx.x & 15;
-            float s = 0.f;
-            for (int row = threadIdx.x >> 4; row < rows_pad; row += kConvThreads / 16) {
-                float v = 0.f;
-                const int ab = rowa[row];
-                if (ab >= 0 && oc < d.O1) v = da1[ab + oc * d.M1] * g1[row * 16 + oc];
-                g1[row * 16 + oc] = v;
-                s += v;
+            const int oc = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+            float s[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) s[c] = 0.f;
+            constexpr int UB = 3;                   // (three rows' reads in flight, as in the first phase)
+            for (int it0 = 0; it0 < d.RT1; it0 += UB) {
+                int ab[UB], at[UB];
+                float gp[UB], dv[NC][UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int row = r0 + 16 * min(it0 + u, d.RT1 - 1);
+                    ab[u] = rowa[row];
+                    gp[u] = g1[row * 16 + oc];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    at[u] = (ab[u] >= 0 && oc < d.O1) ? ab[u] + oc * d.M1 : 0;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dv[c][u] = da1[c * p.da1_size + at[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (it0 + u < d.RT1) {
+                        const int row = r0 + 16 * (it0 + u);
+                        const bool on = ab[u] >= 0 && oc < d.O1;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            float v = 0.f;
+                            if (on) v = dv[c][u] * gp[u];
+                            if (NC == 1) g1[row * 16 + oc] = v;
+                            else if (on) da1[c * p.da1_size + at[u]] = v;
+                            s[c] += v;
+                        }
+                    }
+                }
             }
-            db1 += s;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) db1[c] += s[c];
         }
         lds_barrier();
+        CONV_STAMP(5);
         // ---- dW1 += dz1^T patches(x): reduction over the group's positions, 4 per step -------------------
-        for (int s0 = 0; s0 < rows_pad / 4; s0 += 4) {     // rows_pad / 4 = 4 RT1 steps; 4 steps' reads in flight
-            int ro[4];
-            float av[4], bv[4][kNT1];
+        // One iteration = 4 reduction steps (16 positions): row offsets -> gathered patch elements are two dependent LDS
+        // round trips in front of 16 NC MFMAs.  Pipelined by hand: the gathers of iteration k + 1 (and the row offsets of
+        // k + 2) are requested before the MFMAs of k are issued and wait behind them; the loop runs two iterations per trip
+        // so that the two operand sets alternate without register copies.
+        {
+            const int n_it = rows_pad / 16;                    // = RT1
+            auto offsets = [&](int it, int (&ro_)[4]) {
+                const int s0 = 4 * min(it, n_it - 1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int row = 4 * (s0 + u) + lk;
-                ro[u] = rowoff1[row];
-                av[u] = g1[row * 16 + lr];             // A[m = channel lr][k = row]
+                for (int u = 0; u < 4; ++u) ro_[u] = rowoff1[4 * (s0 + u) + lk];
+            };
+            auto operands = [&](int it, const int (&ro_)[4], float (&av_)[NC][4], float (&bv_)[4][KT1]) {
+                const int s0 = 4 * min(it, n_it - 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = 4 * (s0 + u) + lk;
+                    if (NC == 1) {
+                        av_[0][u] = g1[row * 16 + lr];             // A[m = channel lr][k = row]
+                    } else {
+                        const int ab = rowa[row];                  // (rows beyond the group's positions: zero)
+                        const bool on = ab >= 0 && lr < d.O1;
+                        const int at = on ? ab + lr * d.M1 : 0;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const float v = da1[c * p.da1_size + at];
+                            av_[c][u] = on ? v : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < KT1; ++i) bv_[u][i] = img[ro_[u] + k1off[i]];     // (gathered once for all cotangents)
+                }
+            };
+            auto products = [&](const float (&av_)[NC][4], const float (&bv_)[4][KT1]) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int i = 0; i < KT1; ++i)
+                            dw1[c][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[c][u], bv_[u][i], dw1[c][i], 0, 0, 0);
+            };
+            int roA[4], roB[4];
+            float avA[NC][4], bvA[4][KT1], avB[NC][4], bvB[4][KT1];
+            offsets(0, roA);
+            offsets(1, roB);
+            operands(0, roA, avA, bvA);
+            for (int it = 0; it < n_it; it += 2) {
+                operands(it + 1, roB, avB, bvB);               // (beyond the end: the last iteration's again, not used)
+                offsets(it + 2, roA);
+                __builtin_amdgcn_sched_barrier(0);             // (left alone the scheduler sinks every read to its use)
+                products(avA, bvA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < n_it) {
+                    operands(it + 2, roA, avA, bvA);
+                    offsets(it + 3, roB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    products(avB, bvB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < kNT1; ++i) bv[u][i] = img[ro[u] + k1off[i]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int i = 0; i < kNT1; ++i)
-                    dw1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][i], dw1[i], 0, 0, 0);
         }
         lds_barrier();             // everything of this group is consumed
+        CONV_STAMP(6);
     }
+    CONV_STAMP_FLUSH;
 
-    // ---- this workgroup's partial gradients -> its slab: w1 | b1 | w2 | b2 -------------------------------
-    float* out = a.partial + (int64_t)blockIdx.x * conv_param_count(d);
-    float* o_b1 = out + d.O1 * d.K1;
-    float* o_w2 = o_b1 + d.O1;
-    float* o_b2 = o_w2 + d.O2 * d.K2;
+    // ---- this workgroup's partial gradients -> its slabs (one per cotangent): w1 | b1 | w2 | b2 -----------------------
 #pragma unroll
-    for (int i = 0; i < kNT1; ++i) {
-        const int c = wave + 4 * i;
-        if (c < NT1) {
+    for (int c = 0; c < NC; ++c) {
+        float* out = a.partial + ((int64_t)blockIdx.x * NC + c) * conv_param_count(d);
+        float* o_b1 = out + d.O1 * d.K1;
+        float* o_w2 = o_b1 + d.O1;
+        float* o_b2 = o_w2 + d.O2 * d.K2;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oc = 4 * lk + r;
-                if (oc < d.O1) out[oc * d.K1 + c * 16 + lr] = dw1[i][r];
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < kNT2; ++i) {
-        const int c = wave + 4 * i;
-        if (c < NT2) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+        for (int i = 0; i < KT1; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct < NT1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int oc = rt * 16 + 4 * lk + r;
-                    if (oc < d.O2) o_w2[oc * d.K2 + c * 16 + lr] = dw2[rt][i][r];
+                    const int oc = 4 * lk + r;
+                    if (oc < d.O1) out[oc * d.K1 + ct * 16 + lr] = dw1[c][i][r];
                 }
+            }
         }
+#pragma unroll
+        for (int i = 0; i < kNT2; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct < NT2) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int oc = rt * 16 + 4 * lk + r;
+                        if (oc < d.O2) o_w2[oc * d.K2 + ct * 16 + lr] = dw2[c][rt][i][r];
+                    }
+            }
+        }
+        // bias sums: threads of the same channel (tid % 16) hold row slices
+        if (c > 0) __syncthreads();
+        red[threadIdx.x] = db1[c];
+        __syncthreads();
+        if (threadIdx.x < 16 && (int)threadIdx.x < d.O1) {
+            float sum = 0.f;
+            for (int q = 0; q < kConvThreads / 16; ++q) sum += red[q * 16 + threadIdx.x];
+            o_b1[threadIdx.x] = sum;
+        }
+        if (threadIdx.x < 32 && (int)threadIdx.x < d.O2) o_b2[threadIdx.x] = db2[c];
     }
-    // bias sums: threads of the same channel (tid % 16) hold row slices
-    red[threadIdx.x] = db1;
-    __syncthreads();
-    if (threadIdx.x < 16 && (int)threadIdx.x < d.O1) {
-        float s = 0.f;
-        for (int q = 0; q < kConvThreads / 16; ++q) s += red[q * 16 + threadIdx.x];
-        o_b1[threadIdx.x] = s;
-    }
-    if (threadIdx.x < 32 && (int)threadIdx.x < d.O2) o_b2[threadIdx.x] = db2;
 }
 
 // sum of the workgroups' slabs in fixed order (64 parameters per workgroup, 16 slices of slabs, then the slices)
@@ -1123,18 +1329,99 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
     const size_t lds = (size_t)conv_bwd_plan(a.d).total * sizeof(float);
     const unsigned blocks = (unsigned)(a.n_groups < kConvBwdGroupsCap ? a.n_groups : kConvBwdGroupsCap);
     hipStream_t s = as_stream(stream);
-    if (a.d.tiles > 1) {
-        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd<true>), attr_t, "asac_conv2_backward")) return rc;
-        ASAC_LAUNCH(k_conv2_bwd<true>, dim3(blocks), dim3(kConvThreads), lds, s, a);
-    } else {
-        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(k_conv2_bwd<false>), attr, "asac_conv2_backward")) return rc;
-        ASAC_LAUNCH(k_conv2_bwd<false>, dim3(blocks), dim3(kConvThreads), lds, s, a);
-    }
+    static bool attr3 = false, attr3_t = false;
+    const bool kt3 = a.d.K1 / 16 <= 12;            // (three column tiles per wave cover the filter: see k_conv2_bwd)
+    auto launch = [&](auto kernel, bool& done) -> int {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(kernel), done, "asac_conv2_backward")) return rc;
+        ASAC_LAUNCH(kernel, dim3(blocks), dim3(kConvThreads), lds, s, a);
+        return 0;
+    };
+    if (int rc = a.d.tiles > 1 ? (kt3 ? launch(k_conv2_bwd<true, 1, 3>, attr3_t) : launch(k_conv2_bwd<true, 1, 4>, attr_t))
+                               : (kt3 ? launch(k_conv2_bwd<false, 1, 3>, attr3) : launch(k_conv2_bwd<false, 1, 4>, attr)))
+        return rc;
     const int n = conv_param_count(a.d);
     // launched once (not under the repeat knob: it may accumulate)
     hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
                        (int)blocks, n, grad_params, accumulate);
     return finish_launch("asac_conv2_backward");
+}
+
+// the largest number of cotangents (1..4) whose buffers fit the LDS beside the double-buffered frames: what ONE launch of
+// asac_conv2_backward_multi takes (more are issued in launches of at most this many)
+int asac_conv2_backward_multi_max(const asac_conv2_desc_t* desc) {
+    ConvDims d;
+    if (!desc || !conv_dims(*desc, d)) return -1;
+    int best = 1;
+    for (int nc = 2; nc <= 3; ++nc)          // (a fourth set of accumulators leaves no registers for the operand pipeline)
+        if ((size_t)conv_bwd_plan(d, nc).total * sizeof(float) <= kConvLdsLimit) best = nc;
+    return best;
+}
+
+// Several backward walks of ONE forward pass (n_cot cotangents grad_ys[c], each [N][out2 * M2]) as one launch:
+// grads_out [n_cot][param_count], cotangent c's packed gradients (w1 | b1 | w2 | b2) in slab c; workspace:
+// n_cot x asac_conv2_backward_workspace floats.  Bit-identical to n_cot asac_conv2_backward(_windows) calls.
+int asac_conv2_backward_multi(const asac_conv2_desc_t* desc, const float* x, int64_t N, int frames_per_sample,
+                              int64_t sample_stride, const float* w2, const float* z1, const float* z2,
+                              const float* const* grad_ys, int n_cot, float* grads_out, int accumulate, float* workspace,
+                              void* stream) {
+    ConvArgs a{};
+    if (!desc || !conv_dims(*desc, a.d) || N <= 0 || !x || !w2 || !z1 || !z2 || !grad_ys || n_cot < 1 || n_cot > 4 ||
+        !grads_out || !workspace)
+        return bad_arg("asac_conv2_backward_multi");
+    for (int c = 0; c < n_cot; ++c)
+        if (!grad_ys[c]) return bad_arg("asac_conv2_backward_multi: cotangent");
+    if (n_cot == 1)
+        return asac_conv2_backward_windows(desc, x, N, frames_per_sample, sample_stride, w2, z1, z2, grad_ys[0], grads_out,
+                                           accumulate, workspace, stream);
+    if (frames_per_sample) {
+        if (frames_per_sample < 0 || frames_per_sample % a.d.G != 0 || N % frames_per_sample != 0 ||
+            sample_stride < (int64_t)frames_per_sample * a.d.FCHW)
+            return bad_arg("asac_conv2_backward_multi: windows");
+        a.x_sample_groups = frames_per_sample / a.d.G;
+        a.x_sample_stride = sample_stride;
+    }
+    if (a.d.tiles > 1 && ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(z1) & 15) ||
+                          (sample_stride & 3) || (a.d.FCHW & 3) || ((a.d.M1 * a.d.O1) & 3)))
+        return bad_arg("asac_conv2_backward_multi: tiled frames need 16-byte aligned rows");
+    const size_t lds = (size_t)conv_bwd_plan(a.d, n_cot).total * sizeof(float);
+    if (n_cot > asac_conv2_backward_multi_max(desc)) {         // (more buffer sets than fit: launches of as many as do)
+        const int64_t n = conv_param_count(a.d);
+        const int most = asac_conv2_backward_multi_max(desc);
+        for (int c = 0; c < n_cot; c += most)
+            if (int rc = asac_conv2_backward_multi(desc, x, N, frames_per_sample, sample_stride, w2, z1, z2, grad_ys + c,
+                                                   n_cot - c < most ? n_cot - c : most, grads_out + c * n, accumulate,
+                                                   workspace, stream))
+                return rc;
+        return 0;
+    }
+    a.x = x; a.w2 = w2;
+    a.z1 = const_cast<float*>(z1); a.z2 = const_cast<float*>(z2);
+    a.gy = grad_ys[0];
+    for (int c = 1; c < n_cot; ++c) a.gy_more[c - 1] = grad_ys[c];
+    a.partial = workspace;
+    a.N = N * a.d.tiles;
+    a.n_groups = (a.N + a.d.G - 1) / a.d.G;
+    static bool attr[2][2][2] = {};
+    const unsigned blocks = (unsigned)(a.n_groups < kConvBwdGroupsCap ? a.n_groups : kConvBwdGroupsCap);
+    hipStream_t s = as_stream(stream);
+    const bool tiled = a.d.tiles > 1, kt3 = a.d.K1 / 16 <= 12;
+    auto launch = [&](auto kernel, bool& done) -> int {
+        if (int rc = conv_lds_limit(reinterpret_cast<const void*>(kernel), done, "asac_conv2_backward_multi")) return rc;
+        ASAC_LAUNCH(kernel, dim3(blocks), dim3(kConvThreads), lds, s, a);
+        return 0;
+    };
+    int rc = 0;
+    if (n_cot == 2)
+        rc = tiled ? (kt3 ? launch(k_conv2_bwd<true, 2, 3>, attr[1][0][0]) : launch(k_conv2_bwd<true, 2, 4>, attr[1][0][1]))
+                   : (kt3 ? launch(k_conv2_bwd<false, 2, 3>, attr[0][0][0]) : launch(k_conv2_bwd<false, 2, 4>, attr[0][0][1]));
+    else
+        rc = tiled ? (kt3 ? launch(k_conv2_bwd<true, 3, 3>, attr[1][1][0]) : launch(k_conv2_bwd<true, 3, 4>, attr[1][1][1]))
+                   : (kt3 ? launch(k_conv2_bwd<false, 3, 3>, attr[0][1][0]) : launch(k_conv2_bwd<false, 3, 4>, attr[0][1][1]));
+    if (rc) return rc;
+    const int n = conv_param_count(a.d) * n_cot;       // (a block's n_cot slabs are consecutive: one reduction over all of them)
+    hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
+                       (int)blocks, n, grads_out, accumulate);
+    return finish_launch("asac_conv2_backward_multi");
 }
 
 }  // extern "C"

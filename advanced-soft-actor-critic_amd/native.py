@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 77
+ABI_VERSION = 78
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -329,6 +329,10 @@ _SIGNATURES = {
     'asac_conv2_backward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_void_p]),
+    'asac_conv2_backward_multi_max': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_backward_multi': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
     'asac_conv2_forward_windows': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p]),
@@ -1509,6 +1513,39 @@ def conv2_backward_windows(desc, x, w2, z1, z2, grad_y, grad_params, workspace, 
     _check(load().asac_conv2_backward_windows(C.byref(desc), _p(x), B * T, T, x.stride(0), _p(w2), _p(z1), _p(z2),
                                               _p(grad_y), _p(grad_params), int(bool(accumulate)), _p(workspace),
                                               _stream()), 'asac_conv2_backward_windows')
+
+
+CONV2_MAX_COTANGENTS = 4
+
+
+def conv2_backward_multi_max(desc) -> int:
+    """cotangents ONE launch of `conv2_backward_multi` takes for these frames (more: launches of at most this many)"""
+    return int(load().asac_conv2_backward_multi_max(C.byref(desc)))
+
+
+@_profiled
+def conv2_backward_multi(desc, x, w2, z1, z2, grad_ys, grads_out, workspace, accumulate=False):
+    """Several backward walks of ONE forward pass as one launch: `grad_ys` = 1..4 output gradients, `grads_out`
+    [len(grad_ys), param_count] <- the packed gradients per cotangent, bit-identical to one `conv2_backward(_windows)` each.
+    `x` [N, C, H, W] dense, or [B, T, C, H, W] a slice of the sampled windows read in place; workspace: len(grad_ys) x
+    `conv2_backward_workspace` floats."""
+    global _last_work
+    nc = len(grad_ys)
+    assert 1 <= nc <= CONV2_MAX_COTANGENTS and grads_out.shape[0] == nc
+    windows = x.dim() == 5
+    n_frames = x.shape[0] * x.shape[1] if windows else x.shape[0]
+    _last_work = nc * conv2_flops(desc, n_frames, backward=True)
+    _dense_f32(w2, z1, z2, grads_out, workspace, *grad_ys)
+    if windows:
+        assert x.dtype == torch.float32 and x.is_cuda and x[0].is_contiguous()
+        fps, stride = x.shape[1], x.stride(0)
+    else:
+        _dense_f32(x)
+        fps, stride = 0, 0
+    ptrs = (C.c_void_p * nc)(*[g.data_ptr() for g in grad_ys])
+    _check(load().asac_conv2_backward_multi(C.byref(desc), _p(x), n_frames, fps, stride, _p(w2), _p(z1), _p(z2), ptrs, nc,
+                                            _p(grads_out), int(bool(accumulate)), _p(workspace), _stream()),
+           'asac_conv2_backward_multi')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 77
+#define ASAC_ABI_VERSION 78
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -856,6 +856,20 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc_host, const float* 
 int asac_conv2_backward_windows(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, int frames_per_sample,
                                 int64_t sample_stride, const float* w2, const float* z1, const float* z2,
                                 const float* grad_y, float* grad_params, int accumulate, float* workspace, void* stream);
+
+/* Several backward walks of ONE forward pass as one launch: the reference differentiates the representation's graph once per
+ * gated auxiliary loss (`calculate_adaptive_weights`, sac_base.py:1607-1631, called from 1798-1839) — the same frames, the same
+ * saved pre-activations, n_cot (1..4) different output gradients grad_ys[c] [N][out2 * M2].  What does not depend on the
+ * cotangent (the frames' staging, the activations, the gathered patch operands of both weight-gradient products) is done once
+ * per group of frames.  grads_out [n_cot][asac_conv2_param_count]: cotangent c's packed gradients w1 | b1 | w2 | b2, bit-identical
+ * to asac_conv2_backward_windows(..., grad_ys[c], ...); workspace: n_cot x asac_conv2_backward_workspace floats.  More
+ * cotangents than asac_conv2_backward_multi_max (their LDS buffers beside the double-buffered frames: 3 for 30 x 30 frames)
+ * go in launches of at most that many. */
+int asac_conv2_backward_multi_max(const asac_conv2_desc_t* desc);     /* cotangents ONE launch takes for these frames (1..3) */
+int asac_conv2_backward_multi(const asac_conv2_desc_t* desc, const float* x, int64_t N, int frames_per_sample,
+                              int64_t sample_stride, const float* w2, const float* z1, const float* z2,
+                              const float* const* grad_ys, int n_cot, float* grads_out, int accumulate, float* workspace,
+                              void* stream);
 int asac_conv2_backward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w2,
                         const float* z1, const float* z2, const float* grad_y, float* grad_params, int accumulate,
                         float* workspace, void* stream);

@@ -160,3 +160,91 @@ def test_forward_over_a_window_slice_read_in_place(B, L, b):
         assert all(torch.equal(a, c) for a, c in zip(*grads))
         with pytest.raises(native.AsacNativeError):        # a slice whose samples do not hold whole groups
             native.conv2_forward_windows(desc, frames[:, 1:4], *wd, torch.empty(B * 3, 128, device='cuda'))
+
+
+@pytest.mark.parametrize('N,C,H,W,nc,windows', [
+    (4608, 3, 30, 30, 3, False),    # cfg5's three gated walks over the 512 x 9 frames of the windows
+    (4608, 3, 30, 30, 4, True),     # ... four cotangents, frames read in place as a slice of the windows
+    (37, 3, 30, 30, 2, False),      # ragged last group
+    (300, 3, 84, 84, 3, False),     # tiled mode (the reference environments' frames)
+    (64, 3, 84, 84, 4, True),
+    (23, 4, 30, 30, 4, False),      # K1 = 256
+])
+def test_conv_backward_for_several_cotangents_is_the_single_launches_bit_for_bit(N, C, H, W, nc, windows):
+    """`asac_conv2_backward_multi`: nc backward walks of ONE forward pass as one launch == nc `asac_conv2_backward(_windows)`
+    launches, every packed gradient bit for bit (the per-cotangent operations keep their order; only what does not depend
+    on the cotangent is shared)."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    torch.manual_seed(N + nc)
+    dev = _stack(C, 16, 8, 4, 32, 4, 2)[1]
+    c1, _, c2, _ = list(dev)
+    desc = native.conv2_desc(C, H, W, 16, 8, 4, 32, 4, 2)
+    assert native.conv2_supported(desc)
+    wd = [t.detach().contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias)]
+    if windows:
+        T = 4
+        frames = torch.randn(N // T, T + 3, C, H, W, device='cuda')
+        x = frames[:, 3:]
+        n_frames = (N // T) * T
+    else:
+        x = torch.randn(N, C, H, W, device='cuda')
+        n_frames = N
+    h1, w1 = (H - 8) // 4 + 1, (W - 8) // 4 + 1
+    out = 32 * ((h1 - 4) // 2 + 1) * ((w1 - 4) // 2 + 1)
+    y = torch.empty(n_frames, out, device='cuda')
+    z1 = torch.empty(native.conv2_z1_floats(desc, n_frames), device='cuda')
+    z2 = torch.empty_like(y)
+    (native.conv2_forward_windows if windows else native.conv2_forward)(desc, x, *wd, y, z1, z2)
+    gys = [torch.randn_like(y) * (0.3 + c) for c in range(nc)]
+    n = native.conv2_param_count(desc)
+    ws1 = torch.empty(native.conv2_backward_workspace(desc, n_frames), device='cuda')
+    want = torch.zeros(nc, n, device='cuda')
+    single = native.conv2_backward_windows if windows else native.conv2_backward
+    for c in range(nc):
+        single(desc, x, wd[2], z1, z2, gys[c], want[c], ws1)
+    got = torch.full((nc, n), 7.0, device='cuda')
+    ws = torch.empty(nc * ws1.numel(), device='cuda')
+    with native.LaunchProfiler() as prof:
+        native.conv2_backward_multi(desc, x, wd[2], z1, z2, gys, got, ws)
+    assert list(prof.summary()) == ['asac_conv2_backward_multi']
+    assert torch.equal(got, want) and float(want.abs().sum()) > 0
+    # three cotangents of 30 x 30 frames are ONE kernel launch (the fourth set of LDS buffers does not fit beside the
+    # double-buffered frames: 3 + 1)
+    if (C, H, W) == (3, 30, 30):
+        assert native.conv2_backward_multi_max(desc) == 3
+    # accumulate form
+    native.conv2_backward_multi(desc, x, wd[2], z1, z2, gys, got, ws, accumulate=True)
+    assert torch.equal(got, want + want)
+
+
+def test_deferred_conv_backward_equals_the_walks_own_launches():
+    """`fused_conv.DeferredConvBackward`: three `autograd.grad` walks of one forward pass with the convolution stack's
+    backward recorded and run as ONE launch afterwards — the gradients each walk would have returned, bit for bit; a walk
+    outside the context launches as always."""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm.fused_conv import DeferredConvBackward, conv_stack_desc, fused_conv_stack
+    dev = _stack(3, 16, 8, 4, 32, 4, 2)[1]
+    head = nn.Linear(128, 8).cuda()
+    x = torch.randn(400, 3, 30, 30, device='cuda')
+    desc = conv_stack_desc(dev, x)
+    params = [*dev.parameters(), *head.parameters()]
+    y = head(fused_conv_stack(x, desc, dev))
+    cots = [torch.randn_like(y) for _ in range(3)]
+    want = [torch.autograd.grad(y, params, grad_outputs=c, retain_graph=True) for c in cots]
+    later = DeferredConvBackward()
+    got = []
+    with native.LaunchProfiler() as prof:
+        for k, c in enumerate(cots):
+            later.walk = k
+            with later:
+                got.append(list(torch.autograd.grad(y, params, grad_outputs=c, retain_graph=True, allow_unused=True)))
+        conv_grads = later.flush()
+    assert 'asac_conv2_backward' not in prof.summary() and prof.summary()['asac_conv2_backward_multi']['calls'] == 1
+    for k in range(3):
+        for j, p in enumerate(params):
+            g = conv_grads[k].get(id(p)) if got[k][j] is None else got[k][j]
+            assert g is not None and torch.equal(g, want[k][j]), (k, j)
+        assert all(got[k][j] is None for j in range(4)) and set(conv_grads[k]) == {id(p) for p in dev.parameters()}
+    assert DeferredConvBackward._active is None
