@@ -295,6 +295,9 @@ __device__ __forceinline__ f32x4 conv1_tile(const float* base, const int* ktq, c
 // serves the four patch reads only — the two 16-byte table reads were two thirds of the layer's LDS bytes
 template <int Q1C>
 __device__ __forceinline__ f32x4 conv1_tile_reg(const float* base, const int4 (&ko)[Q1C], const float4 (&w)[Q1C]) {
+    // (requesting the patch elements two quads ahead of their MFMAs, pinned with scheduling barriers, changed nothing —
+    // 9.69 -> 9.56 k clocks a group, round 6: two workgroups a CU share each SIMD's matrix pipe, whose 108 + 32 MFMAs per
+    // wave and group are ~60 % of the group's time; the reads already travel under the other workgroup's MFMAs)
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < Q1C; ++q) {
@@ -323,6 +326,21 @@ __device__ __forceinline__ void conv1_finish(const ConvArgs& a, int64_t g, int r
     const float z = sum + bias;
     conv1_store(a, g, row, abase, z_rows, oc, z, gelu_f(z), a1);
 }
+
+// phase clocks of workgroup 0 (thread 0) summed over its groups, for tools/debug/conv_bwd_phases.py; compiled out of the library
+#ifdef ASAC_CONV_STAMPS
+__device__ unsigned long long g_conv_stamps[16];
+#define CONV_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[10] = {}
+#define CONV_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
+#define CONV_STAMP_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 10; ++k_) g_conv_stamps[k_] = st_acc[k_]; } while (0)
+extern "C" int asac_debug_conv_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define CONV_STAMP_INIT
+#define CONV_STAMP(k)
+#define CONV_STAMP_FLUSH
+#endif
 
 // (TILED: a second instantiation — the whole-frame form keeps the code it had before the tiled mode existed: with the
 // block addressing compiled in, its launches were 0.5-2.8 us longer at cfg4's sizes)
@@ -498,7 +516,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // consumed this group's, and land while layer 2 and the epilogues run
     // (tiled mode: the host has checked the 16-byte granularity the crops need)
     if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
+    CONV_STAMP_INIT;
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+        CONV_STAMP(9);
         const int n_img = (int)min((int64_t)d.G, a.N - g * d.G);
         const TileAt at = tile_at<TILED>(d, g);
         const int z_rows = n_img * d.M1;
@@ -508,6 +528,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             stage_frames(a, g, img);
             __syncthreads();
         }
+        CONV_STAMP(0);
         // ---- layer 1 ------------------------------------------------------------------------------------
         f32x4 tail[3];
 #pragma unroll
@@ -533,6 +554,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
                 for (int r = 0; r < 4; ++r) red[(u * 4 + wave) * 256 + (4 * lk + r) * 16 + lr] = tail[u][r];
             }
         lds_barrier();             // the frames are consumed
+        CONV_STAMP(1);
         if (dma && g + gridDim.x < a.n_groups) async_frames<TILED>(a, g + gridDim.x, img, wave, lane, croptab);
         for (int u = 0; u < rem; ++u) {
             const float* ru = red + u * 4 * 256;
@@ -542,6 +564,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             conv1_finish(a, g, row, rowa[row], z_rows, e & 15, sum, b1e, a1);
         }
         lds_barrier();
+        CONV_STAMP(2);
         // ---- layer 2: 16 positions (G frames x M2), wave = (column tile, k half) ---------------------------
         {
             const float* base = a1 + base2;
@@ -559,6 +582,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * lk + r) * 16 + lr] = acc[r];
         }
         lds_barrier();
+        CONV_STAMP(3);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
             const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
@@ -573,7 +597,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             }
         }
         // (the next iteration's first barrier orders these reads before the slabs / activations are rewritten)
+        CONV_STAMP(4);
     }
+    CONV_STAMP_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,21 +637,6 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc =
 
 // packed parameter gradients: w1 | b1 | w2 | b2
 __host__ __device__ inline int conv_param_count(const ConvDims& d) { return d.O1 * d.K1 + d.O1 + d.O2 * d.K2 + d.O2; }
-
-// phase clocks of workgroup 0 (thread 0) summed over its groups, for tools/debug/conv_bwd_phases.py; compiled out of the library
-#ifdef ASAC_CONV_STAMPS
-__device__ unsigned long long g_conv_stamps[16];
-#define CONV_STAMP_INIT unsigned long long st_last = __builtin_readcyclecounter(), st_acc[10] = {}
-#define CONV_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[k] += t_ - st_last; st_last = t_; } while (0)
-#define CONV_STAMP_FLUSH do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 10; ++k_) g_conv_stamps[k_] = st_acc[k_]; } while (0)
-extern "C" int asac_debug_conv_stamps(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 16);
-}
-#else
-#define CONV_STAMP_INIT
-#define CONV_STAMP(k)
-#define CONV_STAMP_FLUSH
-#endif
 
 constexpr int kNT1 = kConvMaxK / 16 / 4;        // layer-1 weight-gradient column tiles per wave (k1 index / 16)
 constexpr int kNT2 = kConvMaxK / 16 / 4;        // layer-2 weight-gradient column tiles per wave, per row tile

@@ -1,0 +1,39 @@
+"""Phase clocks of `k_conv2_fwd` (workgroup 0, summed over its groups); stamped variant as tools/debug/conv_bwd_phases.py"""
+import ctypes
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import asac_amd  # noqa: E402,F401
+from asac_amd import native  # noqa: E402
+
+NAMES = ['dma wait', 'layer 1 (full tiles + tail partials)', 'tail sums, GELU', 'layer 2', 'epilogue (stores)', '-', '-', '-', '-', 'loop top']
+lib = native.load()
+C, H, W = 3, 30, 30
+desc = native.conv2_desc(C, H, W, 16, 8, 4, 32, 4, 2)
+torch.manual_seed(0)
+w = [torch.randn(16, 3, 8, 8, device='cuda') * 0.1, torch.zeros(16, device='cuda'), torch.randn(32, 16, 4, 4, device='cuda') * 0.1,
+     torch.zeros(32, device='cuda')]
+for N, train in ((2048, False), (2048, True), (4608, False), (9216, True)):
+    x = torch.randn(N, C, H, W, device='cuda')
+    y = torch.empty(N, 128, device='cuda')
+    z1 = torch.empty(native.conv2_z1_floats(desc, N), device='cuda') if train else None
+    z2 = torch.empty_like(y) if train else None
+    for _ in range(3):
+        native.conv2_forward(desc, x, *w, y, z1, z2)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        native.conv2_forward(desc, x, *w, y, z1, z2)
+    e1.record()
+    torch.cuda.synchronize()
+    st = (ctypes.c_ulonglong * 16)()
+    lib.asac_debug_conv_stamps(st)
+    tot = sum(st[:10])
+    print(f'N = {N} train = {train}: {e0.elapsed_time(e1) * 100:.1f} us per launch; workgroup 0: {tot} clocks in its group loop')
+    for k, name in enumerate(NAMES):
+        if st[k]:
+            print(f'   {name:40s} {st[k]:9d} clocks  {100.0 * st[k] / tot:5.1f} %')
