@@ -134,21 +134,37 @@ def describe_q(q) -> 'native.MlpDesc | None':
     return desc
 
 
-def describe_dense(ll) -> 'native.MlpDesc | None':
+def _tail_params(ll, skip: int) -> list:
+    """the parameters of `ll` behind its first `skip` ResBlocks, in `parameters()` order"""
+    if skip == 0:
+        return list(ll.parameters())
+    parsed = _blocks_of(ll)
+    blocks, final = parsed
+    mods = [b.linear for b in blocks[skip:]] + ([final] if final is not None else [])
+    return [p for m in mods for p in m.parameters()]
+
+
+def describe_dense(ll, skip: int = 0) -> 'native.MlpDesc | None':
     """A `LinearLayers` stack on its own: input -> ResBlocks -> output Linear (<= 16 columns), offsets relative
-    to the stack's own parameters in `parameters()` order."""
+    to the stack's own parameters in `parameters()` order.  `skip`: describe the stack BEHIND its first `skip` ResBlocks
+    (a wide first layer runs on its own launches, csrc/wide.hip): offsets relative to the first parameter behind them."""
     if not isinstance(ll, LinearLayers):
         return None
     parsed = _blocks_of(ll)
-    if parsed is None or parsed[1] is None or not parsed[0]:
+    if parsed is None or parsed[1] is None or len(parsed[0]) <= skip:
         return None
     blocks, final = parsed
-    in0 = ll.input_size
+    in0 = ll.input_size if skip == 0 else blocks[skip - 1].linear.out_features
+    blocks = blocks[skip:]
     if final.bias is None or final.out_features > MAX_HEAD or in0 > MAX_INPUT:
         return None
     if in0 > MAX_WIDTH and (len(blocks) > 3 or blocks[0].residual):
         return None
-    desc, offs = native.MlpDesc(), _offsets(ll)
+    desc = native.MlpDesc()
+    offs, off = {}, 0
+    for p in _tail_params(ll, skip):
+        offs[id(p)] = off
+        off += p.numel()
     desc.in0, desc.in1 = in0, 0
     if _fill_blocks(desc, blocks, offs, in0) is None:
         return None
@@ -174,14 +190,21 @@ def _flat_alias(tensors):
 _DENSE_LAUNCHERS = weakref.WeakKeyDictionary()
 
 
-def fused_dense(ll, x):
+def fused_dense(ll, x, skip: int = 0):
     """`ll(x)` for a `LinearLayers` stack as ONE launch per pass on the parameters where they live, when the stack
     fits `describe_dense`, its parameters (and gradients, when it trains) are consecutive views of flat buffers
     — true for every module of a `SAC_Base` — and `x` is f32 on the device.  Returns None otherwise (the caller
-    keeps the module path).  Parameter gradients: see `direct_param_grads`."""
-    if not (FUSED_DENSE and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == ll.input_size):
+    keeps the module path).  Parameter gradients: see `direct_param_grads`.  `skip`: `x` is the output of the stack's
+    first `skip` ResBlocks (see `fused_dense_wide_first`), the launch covers the rest."""
+    in0 = ll.input_size
+    if skip:
+        parsed = _blocks_of(ll)
+        if parsed is None or len(parsed[0]) <= skip:
+            return None
+        in0 = parsed[0][skip - 1].linear.out_features
+    if not (FUSED_DENSE and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == in0):
         return None
-    params = list(ll.parameters())
+    params = _tail_params(ll, skip)
     if not params:
         return None
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -189,24 +212,46 @@ def fused_dense(ll, x):
         return None
     # one launcher per (parameter buffer, gradient buffer | inference): a stack alternates between its training
     # pass and no-grad passes within a step
-    key = (params[0].data_ptr(), params[0].grad.data_ptr() if train else 0, x.device)
+    key = (params[0].data_ptr(), params[0].grad.data_ptr() if train else 0, x.device, skip)
     cache = _DENSE_LAUNCHERS.setdefault(ll, {})     # kept off the module: not copied / pickled with it
     if key not in cache:
         if len(cache) > 8:
             cache.clear()
-        desc = describe_dense(ll)
+        desc = describe_dense(ll, skip)
         flat = _flat_alias([p.data for p in params]) if desc is not None else None
         gflat = _flat_alias([p.grad for p in params]) if (flat is not None and train) else None
-        ok = flat is not None and (gflat is not None or not train)
+        ok = flat is not None and (gflat is not None or not train) and flat.data_ptr() % 16 == 0
         cache[key] = StockMLP(desc, flat, gflat, 0, flat.numel(), 1, x.device, params) if ok else None
     mlp = cache[key]
     if mlp is None:
         return None
-    rows = x.reshape(-1, ll.input_size)
+    rows = x.reshape(-1, in0)
     if not rows.is_contiguous():
         rows = rows.contiguous()
     out = mlp(rows, None, param_grads=train)       # [1, rows, cols]
     return out.view(*x.shape[:-1], mlp.out_cols)
+
+
+def fused_dense_wide_first(ll, x):
+    """`ll(x)` for a stack whose FIRST ResBlock has a wide input (more than 128 features: the flattened convolution map in
+    front of `ConvLayers.dense`, reference image_layers.py:188-227) — that block on the launches of csrc/wide.hip
+    (`fused_rows_linear.rows_resblock`), everything behind it as one fused dense-stack launch per pass; None where the
+    wide launches do not apply (the caller keeps the module path)."""
+    parsed = _blocks_of(ll)
+    if parsed is None or not parsed[0] or parsed[0][0].linear.in_features <= MAX_INPUT or parsed[0][0].residual:
+        return None
+    from .fused_rows_linear import rows_resblock
+    first = parsed[0][0]
+    y = rows_resblock(first, x)
+    if y is None:
+        return None
+    out = fused_dense(ll, y, skip=1)
+    if out is not None:
+        return out
+    mods = list(ll.dense)
+    for mod in mods[mods.index(first) + 1:]:
+        y = mod(y)
+    return y
 
 
 def describe_policy(pi) -> 'native.MlpDesc | None':

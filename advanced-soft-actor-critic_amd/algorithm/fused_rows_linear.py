@@ -14,6 +14,7 @@ import torch
 
 ENABLED = os.environ.get('ASAC_ROWS_LINEAR', '1') != '0'      # (0: plain nn.Linear — A/B runs)
 MIN_ROWS = 2048
+WIDE = os.environ.get('ASAC_ROWS_WIDE', '1') != '0'          # (0: the library's GEMMs for wide first layers — A/B runs)
 QUEUE = os.environ.get('ASAC_XTY_QUEUE', '1') != '0'      # (0: one launch pair per product — A/B runs)
 
 
@@ -147,6 +148,58 @@ class _AffineGeluFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+WIDE_MIN_ROWS = 256      # (the wide first layer of a convolution head: 1 024 ... 2 304 frames a pass)
+
+
+class _WideAffineGeluFn(torch.autograd.Function):
+    """gelu(x W^T + b) for an input of hundreds to thousands of features (K > 128: the flattened convolution map in front of
+    `ConvLayers.dense`, 2 592 features for 84 x 84 frames) on the MFMA launches of csrc/wide.hip: split-K forward with the
+    bias and the GELU in its second launch; backward dpre = g * gelu'(pre) and dx = dpre W in one launch, dW = dpre^T x and db
+    in a launch pair — through the library: a GEMM and an elementwise launch forward, two GEMMs, a split reduction and an
+    elementwise launch backward, with autograd's accumulation launches behind them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, grad_mode):
+        from asac_amd import native
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        N = weight.shape[0]
+        train = grad_mode and any(ctx.needs_input_grad[:3])
+        y = torch.empty(x2.shape[0], N, dtype=x.dtype, device=x.device)
+        pre = torch.empty_like(y) if train else None
+        native.rows_wide_forward(x2, weight.detach(), bias.detach(), y, pre)
+        if train:
+            ctx.save_for_backward(x2, pre, weight)
+            ctx.params, ctx.lead = (weight, bias), x.shape[:-1]
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from asac_amd import native
+        from algorithm.fused_mlp import direct_enabled, direct_skips
+        x2, pre, weight = ctx.saved_tensors
+        R, K = x2.shape
+        g2 = gy.reshape(pre.shape)
+        if not g2.is_contiguous() or g2.data_ptr() % 16:
+            g2 = g2.contiguous()
+        dpre = torch.empty_like(pre)
+        dx = torch.empty(R, K, dtype=pre.dtype, device=pre.device) if ctx.needs_input_grad[0] else None
+        native.rows_wide_backward_input(g2, pre, weight.detach(), dpre, dx)
+        gw = gb = None
+        w_param, b_param = ctx.params
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not direct_skips(w_param, b_param):
+            w_grad, b_grad = w_param.grad, b_param.grad
+            if (direct_enabled() and w_grad is not None and b_grad is not None and w_grad.is_contiguous()
+                    and b_grad.is_contiguous()):
+                native.rows_wide_backward_params(dpre, x2, w_grad, b_grad, accumulate=True)
+            else:
+                gw, gb = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=weight.dtype, device=weight.device)
+                native.rows_wide_backward_params(dpre, x2, gw, gb)
+        return (dx.view(*ctx.lead, K) if dx is not None else None), gw, gb, None
+
+
 def rows_resblock(block, x):
     """`ResBlock.forward` over >= MIN_ROWS rows on the device as one launch per pass, or None: without a residual path
     (widths differ) from a narrow input — `_AffineGeluFn`; with one at the widths of csrc/rows_proj.hip — the output-block
@@ -155,10 +208,17 @@ def rows_resblock(block, x):
     lin = block.linear
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and type(block.act) is nn.GELU
             and getattr(block.act, 'approximate', 'none') == 'none' and lin.bias is not None and x.dim() >= 2
-            and x.shape[-1] == lin.in_features and x.numel() // lin.in_features >= MIN_ROWS and x.stride(-1) == 1
+            and x.shape[-1] == lin.in_features and x.stride(-1) == 1
             and lin.weight.data_ptr() % 16 == 0 and lin.bias.data_ptr() % 16 == 0):      # (16-byte vector reads of the parameters)
         return None
     from asac_amd import native
+    rows = x.numel() // lin.in_features
+    if (WIDE and not block.residual and lin.in_features > 128 and rows >= WIDE_MIN_ROWS and lin.weight.is_contiguous()
+            and native.rows_wide_supported(rows, lin.in_features, lin.out_features)):
+        # the wide first layer of a convolution head (csrc/wide.hip)
+        return _WideAffineGeluFn.apply(x, lin.weight, lin.bias, torch.is_grad_enabled())
+    if rows < MIN_ROWS:
+        return None
     if not block.residual:
         if native.rows_affine_supported(lin.in_features, lin.out_features):
             return _AffineGeluFn.apply(x, lin.weight, lin.bias)

@@ -67,8 +67,10 @@ class LinearLayers(nn.Module):
     def forward(self, x):
         assert x.shape[-1] == self.input_size
         if self.fuse and x.is_cuda:
-            from algorithm.fused_mlp import fused_dense     # lazy: avoids an import cycle
+            from algorithm.fused_mlp import fused_dense, fused_dense_wide_first     # lazy: avoids an import cycle
             out = fused_dense(self, x)    # one launch per pass (csrc/mlp.hip) when the stack and its buffers fit
+            if out is None and self.input_size > 128:
+                out = fused_dense_wide_first(self, x)    # a wide first layer on its own launches (csrc/wide.hip), the rest fused
             if out is not None:
                 return out
         if x.is_cuda and torch.is_grad_enabled():

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 78
+ABI_VERSION = 79
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -315,6 +315,14 @@ _SIGNATURES = {
     'asac_normal_nll_kl_logstd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int64,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    'asac_rows_wide_supported': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
+    'asac_rows_wide_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    'asac_rows_wide_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'asac_rows_wide_backward_input': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'asac_rows_wide_backward_params': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'asac_xty_supported': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     'asac_xty_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     'asac_xty': (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
@@ -2173,6 +2181,56 @@ def rows_resblock_backward(grad_y, pre, weight, row_scale, grad_x, grad_pre):
 # ------------------------------------------------------------------------------------------------
 def xty_supported(rows, M, N) -> bool:
     return bool(load().asac_xty_supported(int(rows), int(M), int(N)))
+
+
+def rows_wide_supported(R: int, K: int, N: int) -> bool:
+    return bool(load().asac_rows_wide_supported(R, K, N))
+
+
+def rows_wide_workspace(x, N: int) -> torch.Tensor:
+    R, K = x.shape
+    return torch.empty(int(load().asac_rows_wide_workspace(R, K, N)), dtype=torch.float32, device=x.device)
+
+
+@_profiled
+def rows_wide_forward(x, w, b, y, pre=None, act=True, workspace=None):
+    """y [R, N] = act(x W^T + b) for a wide x [R, K] (row stride allowed), W [N, K]; `pre`: the pre-activations (training)"""
+    global _last_work
+    R, K = x.shape
+    N = w.shape[0]
+    assert x.stride(1) == 1 and w.is_contiguous() and b.is_contiguous() and y.is_contiguous() and y.shape == (R, N)
+    assert pre is None or (pre.is_contiguous() and pre.shape == (R, N))
+    _last_work = 2.0 * R * K * N
+    ws = rows_wide_workspace(x, N) if workspace is None else workspace
+    _check(load().asac_rows_wide_forward(_p(x), x.stride(0), R, K, _p(w), _p(b), N, int(bool(act)), _p(y), _p(pre), _p(ws),
+                                         _stream()), 'asac_rows_wide_forward')
+
+
+@_profiled
+def rows_wide_backward_input(grad_y, pre, w, dpre, dx=None, act=True):
+    """dpre [R, N] = grad_y * act'(pre); dx [R, K] = dpre W (dx None: dpre only)"""
+    global _last_work
+    R, N = grad_y.shape
+    K = w.shape[1]
+    assert grad_y.is_contiguous() and dpre.is_contiguous() and w.is_contiguous() and (pre is None or pre.is_contiguous())
+    assert dx is None or (dx.stride(1) == 1 and dx.shape == (R, K))
+    _last_work = 2.0 * R * K * N if dx is not None else 0.0
+    _check(load().asac_rows_wide_backward_input(_p(grad_y), _p(pre), int(bool(act)), R, K, _p(w), N, _p(dpre), _p(dx),
+                                                0 if dx is None else dx.stride(0), _stream()), 'asac_rows_wide_backward_input')
+
+
+@_profiled
+def rows_wide_backward_params(dpre, x, dw, db=None, accumulate=False, workspace=None):
+    """dw [N, K] (+)= dpre^T x, db [N] (+)= column sums of dpre"""
+    global _last_work
+    R, K = x.shape
+    N = dpre.shape[1]
+    assert dpre.is_contiguous() and x.stride(1) == 1 and dw.is_contiguous() and dw.shape == (N, K)
+    assert db is None or (db.is_contiguous() and db.numel() == N)
+    _last_work = 2.0 * R * K * N
+    ws = rows_wide_workspace(x, N) if workspace is None else workspace
+    _check(load().asac_rows_wide_backward_params(_p(dpre), _p(x), x.stride(0), R, K, N, _p(dw), _p(db), int(bool(accumulate)),
+                                                 _p(ws), _stream()), 'asac_rows_wide_backward_params')
 
 
 @_profiled

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 78
+#define ASAC_ABI_VERSION 79
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -1277,6 +1277,25 @@ int asac_linear_tanh_backward2(const float* x0, int64_t x0_row_stride, int K0, c
                                int K1, const float* weight, const float* y, const float* grad_y, int grad_members,
                                int grad_window, int grad_position, int64_t N, int O, float* grad_x0, float* grad_x1,
                                float* grad_params, int accumulate, float* workspace, void* stream);
+
+/* ---- a Linear layer with a WIDE input (csrc/wide.hip) ----------------------------------------------------------------
+ * y = act(x W^T + b) for x [R][K] (rows x_row_stride floats apart), W [N][K] row-major, N in {32, 64, 128}, K a multiple of
+ * 16 up to 16 384; act: 0 identity, 1 GELU (exact).  The first layer of the dense head behind a flattened convolution map:
+ * `ConvLayers.dense = LinearLayers(h * w * out_c, out_dense_n, ...)` with h * w * out_c = 2 592 for 84 x 84 frames
+ * (nn_models/layers/image_layers.py:188-227, linear_layers.py:24-119: `ResBlock` = Linear + GELU without a residual path when
+ * the widths differ), under autograd the GEMM / GELU / bias-reduction launches of `nn.Linear`.
+ *   forward          split-K partials in `workspace`, summed in order with the bias; `pre` (or NULL): the pre-activations
+ *   backward_input   dpre_out [R][N] = grad_y * act'(pre), dx [R][K] = dpre W (dx NULL: dpre only)
+ *   backward_params  dw [N][K] (+)= dpre^T x, db [N] (+)= column sums of dpre (db may be NULL); fixed-order partial sums
+ * workspace: asac_rows_wide_workspace(R, K, N) floats (-1: unsupported shape), for either launch. */
+int asac_rows_wide_supported(int64_t R, int K, int N);
+int64_t asac_rows_wide_workspace(int64_t R, int K, int N);
+int asac_rows_wide_forward(const float* x, int64_t x_row_stride, int64_t R, int K, const float* w, const float* b, int N,
+                           int act, float* y, float* pre, float* workspace, void* stream);
+int asac_rows_wide_backward_input(const float* grad_y, const float* pre, int act, int64_t R, int K, const float* w, int N,
+                                  float* dpre_out, float* dx, int64_t dx_row_stride, void* stream);
+int asac_rows_wide_backward_params(const float* dpre, const float* x, int64_t x_row_stride, int64_t R, int K, int N, float* dw,
+                                   float* db, int accumulate, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -115,7 +115,16 @@ def test_unaligned_drift_at_full_size(name, n_steps=None, tag=''):
     out_dir.mkdir(exist_ok=True)
     (out_dir / f'drift_{name}{tag}.json').write_text(json.dumps(record, indent=1))
     print(json.dumps(record))
-    assert first_mismatch is None or first_mismatch >= 3, f'ids differ already at step {first_mismatch}'
+    # The runs separate when a rounding difference of one priority moves a stratum boundary across a sampled value: WHICH
+    # step that is is a matter of the kernels' summation orders (cfg4: step 20 in round 5, step 2 after the convolution
+    # forward's reduction order changed in round 6).  What must hold: the first draw — from identical trees — is the
+    # oracle's; the first mismatch is a boundary crossing (a few samples), not a systematic difference; and while the ids
+    # agree the two runs compute the same numbers.
+    assert first_mismatch is None or first_mismatch >= 1, 'the first draw comes from identical trees'
+    if first_mismatch is not None:
+        assert differing[first_mismatch] <= 0.05, f'{differing[first_mismatch]:.3f} of the ids differ at the first mismatch'
+        for k, v in dist.items():
+            assert v['max_rel_diff_while_ids_agree'] is None or v['max_rel_diff_while_ids_agree'] < 1e-4, (k, v)
     b_loss, b_td, b_alpha = BOUNDS[name]
     assert dist['loss_q']['rel_diff_of_means'] < b_loss
     assert dist['td_abs_mean']['rel_diff_of_means'] < b_td
