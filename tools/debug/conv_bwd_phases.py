@@ -13,18 +13,19 @@ from asac_amd import native  # noqa: E402
 
 NAMES = ['dma wait', 'z1 -> a1, gelu\', dz2', 'dW2 (+ db2)', 'dp = dz2 W2', 'col2im', 'dz1', 'dW1', '-', '-', 'loop top']
 lib = native.load()
-N, C, H, W = 9216, 3, 30, 30
+N, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (9216, 3, 30, 30)))
 desc = native.conv2_desc(C, H, W, 16, 8, 4, 32, 4, 2)
 torch.manual_seed(0)
 w = [torch.randn(16, 3, 8, 8, device='cuda') * 0.1, torch.zeros(16, device='cuda'), torch.randn(32, 16, 4, 4, device='cuda') * 0.1,
      torch.zeros(32, device='cuda')]
 x = torch.randn(N, C, H, W, device='cuda')
-y = torch.empty(N, 128, device='cuda')
+h1_, w1_ = (H - 8) // 4 + 1, (W - 8) // 4 + 1
+y = torch.empty(N, 32 * ((h1_ - 4) // 2 + 1) * ((w1_ - 4) // 2 + 1), device='cuda')
 z1 = torch.empty(native.conv2_z1_floats(desc, N), device='cuda')
 z2 = torch.empty_like(y)
 native.conv2_forward(desc, x, *w, y, z1, z2)
 n = native.conv2_param_count(desc)
-for nc in (1, 2, 3):
+for nc in range(1, native.conv2_backward_multi_max(desc) + 1):
     gys = [torch.randn_like(y) for _ in range(nc)]
     out = torch.empty(nc, n, device='cuda')
     ws = torch.empty(nc * native.conv2_backward_workspace(desc, N), device='cuda')
