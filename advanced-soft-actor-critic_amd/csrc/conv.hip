@@ -949,6 +949,16 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                 // and the colour bookkeeping cost its other branch registers — 34 more SGPR spills, +1.8 us a launch)
                 const int passes = TILED ? n_col : d.M2;
                 for (int col = 0; col < passes; ++col) {
+                    // (every candidate's current value is read first — all reads of the pass in flight, those of other
+                    // colours discarded —, then the pass's own elements are written: one by one each read-modify-write
+                    // waited for its own LDS round trip, a third of the tiled launch, round 6)
+                    float cur[NC][kNT2][4];
+#pragma unroll
+                    for (int i = 0; i < kNT2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) cur[c][i][r] = da1[c * p.da1_size + acc_base[r] + k2off[i]];
 #pragma unroll
                     for (int i = 0; i < kNT2; ++i) {
                         if (wave + 4 * i < NT2) {
@@ -957,7 +967,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                             for (int r = 0; r < 4; ++r)
                                 if ((TILED ? acc_col[r] : acc_pos[r]) == col) {
 #pragma unroll
-                                    for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + ko] += dp[c][i][r];
+                                    for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + ko] = cur[c][i][r] + dp[c][i][r];
                                 }
                         }
                     }
