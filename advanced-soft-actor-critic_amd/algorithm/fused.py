@@ -313,6 +313,30 @@ class _MseMeanFn(torch.autograd.Function):
         return grad * (g_loss / ctx.grad_scale), None, None, None
 
 
+class _SmallMseFn(torch.autograd.Function):
+    """mse_loss(pred, target) for a small tensor (the vector part of a plugin's observation loss): value and gradient from
+    one launch (`asac_masked_mse`), the backward one scaling — ATen: subtract / square, a reduction, and backwards a fill and
+    an elementwise launch"""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        from asac_amd import native
+        grad = torch.empty_like(pred)
+        loss = torch.empty((), dtype=pred.dtype, device=pred.device)
+        native.masked_mse(pred.detach(), target, None, grad, loss)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad,) = ctx.saved_tensors
+        from .sac_aux import _const_value
+        v = _const_value(g_loss)
+        if v == 1.0:
+            return grad, None
+        return grad * (v if v is not None else g_loss), None
+
+
 MSE_INTERCEPT_MIN = 1 << 20       # below this ATen's chain is a few launches of microseconds each
 
 
@@ -345,6 +369,13 @@ def fused_mse_loss(workspace: torch.Tensor, grad_scale: float = 1.0):
                 target3 = None
             if target3 is not None and native.mse_mean_grad_ok(pred3, target3):
                 return _MseMeanFn.apply(pred3, target3, workspace, grad_scale)
+        elif (threading.get_ident() == owner and not args and not kwargs and isinstance(input, torch.Tensor)
+              and isinstance(target, torch.Tensor) and input.is_cuda and input.dim() == 3 and input.shape == target.shape
+              and 0 < input.numel() <= native.MASKED_MSE_MAX and input.dtype == torch.float32 and target.dtype == torch.float32
+              and input.requires_grad and not target.requires_grad and torch.is_grad_enabled() and input.is_contiguous()
+              and target.stride(-1) == 1):
+            # the small companion of the frame loss (vector observations: tens of thousands of elements): one launch each way
+            return _SmallMseFn.apply(input, target)
         return orig(input, target, *args, **kwargs)
 
     F.mse_loss = mse_loss

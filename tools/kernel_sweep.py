@@ -42,8 +42,9 @@ def timed(name, fn, bytes_per_launch, repeat=20, rounds=5):
 
 def sweep_gather():
     # cfg4 shape: vector(10) + image(3,30,30) f32 rows (10.9 KB), L = 9 (b=5, n=3), B = 512
-    for B, L, C in (((1024, 9, 2 ** 15), (4096, 9, 2 ** 15)) if ONLY_SATURATING else
-                    ((512, 9, 2 ** 15), (1024, 9, 2 ** 15), (4096, 9, 2 ** 15))):
+    # (ring of 2^16 rows = 711 MB: larger than the Infinity Cache)
+    for B, L, C in (((1024, 9, 2 ** 16), (4096, 9, 2 ** 16)) if ONLY_SATURATING else
+                    ((512, 9, 2 ** 16), (1024, 9, 2 ** 16), (4096, 9, 2 ** 16))):
         img = torch.randn(C, 3, 30, 30, device=dev)
         vec = torch.randn(C, 10, device=dev)
         index = (torch.arange(C, device=dev, dtype=torch.int32) % 100)
@@ -58,8 +59,17 @@ def sweep_gather():
             dict(src=None, dst=mask, pad_mode=native.PAD_EMIT_MASK)])
         ids = torch.randint(10, C - 10, (B,), device=dev, dtype=torch.int64)
         T = 10800 + 40 + 4
-        timed(f'window_gather_pad cfg4 rows (T={T} B) B={B} L={L}',
+        # WARM: the same ids re-issued back to back — a launch's 50-400 MB of rows are still in the 256 MB Infinity Cache when
+        # the next one reads them (what rounds 1-5 quoted); COLD: fresh ids every launch, what a train step's draw sees
+        timed(f'window_gather_pad cfg4 rows B={B} L={L}  WARM (same ids)',
               lambda: native.window_gather_pad(keys, ids, B, 5, 3, C, index), 8 * B + 2 * B * L * T)
+        pool = [torch.randint(10, C - 10, (B,), device=dev, dtype=torch.int64) for _ in range(16)]
+        turn = [0]
+
+        def cold():
+            turn[0] = (turn[0] + 1) % len(pool)
+            native.window_gather_pad(keys, pool[turn[0]], B, 5, 3, C, index)
+        timed(f'window_gather_pad cfg4 rows B={B} L={L}  COLD (fresh ids)', cold, 8 * B + 2 * B * L * T, repeat=1, rounds=12)
 
 
 def sweep_sample():
