@@ -141,6 +141,11 @@ __device__ __forceinline__ void row_copy(float* dst, const float* src, int count
             float4 v[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) v[u] = s4[min(base + u * HP + j, c4 - 1)];
+            // (pinned behind the LAST load: left alone the compiler sinks each load into the branch of its predicated store
+            // — a load, a full wait and a store per element, NB dependent round trips where NB loads were meant to be in
+            // flight; round 6)
+#pragma unroll
+            for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
 #pragma unroll
             for (int u = 0; u < NB; ++u)
                 if (on && base + u * HP + j < c4) d4[base + u * HP + j] = v[u];
@@ -150,6 +155,8 @@ __device__ __forceinline__ void row_copy(float* dst, const float* src, int count
             float v[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) v[u] = src[min(base + u * HP + j, count - 1)];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) v[u] = pinned(v[u]);
 #pragma unroll
             for (int u = 0; u < NB; ++u)
                 if (on && base + u * HP + j < count) dst[base + u * HP + j] = v[u];

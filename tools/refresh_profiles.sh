@@ -43,7 +43,7 @@ rm -rf /tmp/prof_la
 ASAC_BENCH_HIP_CONFIG='{"lookahead": 1}' timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_la -- python $R/bench.py --no-extras --no-cpu-baseline --profile-steps 0 --steps 400 --warmup 40 --run-length 0 > /tmp/prof_la.log 2>&1
 python $R/tools/step_sequence.py $(find /tmp/prof_la -name "*kernel_trace.csv" | head -1) > $O/cfg2_lookahead_step_sequence.txt
 python $R/tools/summarize_rocprof.py $(find /tmp/prof_la -name "*kernel_stats.csv" | head -1) 440 40 $O/cfg2_lookahead_kernel_stats.json > $O/cfg2_lookahead_kernel_stats_summary.txt
-for c in cfg2 cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg5_without_prediction cfg_attn_h64; do cp $O/${c}_kernel_stats.json $R/profiles/r06_${c}_kernel_stats.json; done
+for c in cfg2 cfg3 cfg3_h64 cfg4 cfg4_84 cfg5 cfg5_without_prediction cfg_attn_h64; do cp $O/${c}_kernel_stats.json $R/profiles/r06_${c}_kernel_stats.json; [ -f $O/${c}_pmc_traffic.json ] && cp $O/${c}_pmc_traffic.json $R/profiles/r06_${c}_pmc_traffic.json; done
 cd $R
 timeout 1200 python bench.py > $O/cfg2_bench_line.json 2> $O/cfg2_bench.err
 cp $R/bench_details.json $O/cfg2_bench.json      # (the full record; cfg2_bench_line.json: the < 4 KB line the driver parses)
