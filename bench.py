@@ -540,7 +540,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but the launcher started {world} ranks')
-    device = torch.device('cuda', local_rank)
+    # ASAC_BENCH_ONE_DEVICE=1 (tests only: tests/test_parallel_world2_gpu.py): every rank on cuda:0, gloo instead of RCCL, no
+    # graph capture — the N > 1 HOST path of this script (launcher, shard fill, max-over-ranks timing, rank 0's line) on a
+    # one-GPU box.  The line says so (`config.collectives`); it is not a measurement.
+    one_device = os.environ.get('ASAC_BENCH_ONE_DEVICE') == '1'
+    device = torch.device('cuda', 0 if one_device else local_rank)
     torch.cuda.set_device(device)
     if args.scaling == 'strong':
         if CFG['batch_size'] % world:
@@ -554,7 +558,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
+        if one_device:
+            dist.init_process_group('gloo')
+            args.no_graph = True
+        else:
+            dist.init_process_group('nccl', device_id=device)
         import asac_amd  # noqa: F401
         from algorithm.parallel import DataParallelContext
         dist_ctx = DataParallelContext(always=args.force_dist)
@@ -742,7 +750,8 @@ def main():
                        'global_batch': CFG['batch_size'] * world,
                        'replay_shard_capacity': CFG['capacity'] // world,
                        'parallelism': f'dp{world}' if world > 1 else 'single',
-                       'ranks': torch.distributed.get_world_size() if dist_ctx is not None else 1, 'collectives': 'RCCL (nccl backend)' if dist_ctx is not None else None,
+                       'ranks': torch.distributed.get_world_size() if dist_ctx is not None else 1, 'collectives': (('gloo, every rank on ONE device (test mode, not a measurement)' if one_device else 'RCCL (nccl backend)')
+                                       if dist_ctx is not None else None),
                        'hipgraph': bool(graph_used),
                        'hipgraph_memset_nodes_replaced': None if graph_memsets is None else graph_memsets[0],
                        'steps_per_graph_launch': 1},

@@ -303,3 +303,29 @@ def _worker(rank, port, mode):
 def test_world2_product_learner_on_one_gpu(mode):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(_free_port(), mode), nprocs=WORLD, join=True)
+
+
+def test_bench_two_ranks_host_path_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` end to end on a one-GPU box (`ASAC_BENCH_ONE_DEVICE=1`: both ranks on cuda:0 over gloo, no graph):
+    the launcher, the per-rank shard fill, strong scaling's 128 rows a rank, the barrier + max-over-ranks timing and rank 0's
+    ONE parseable line — the host code the driver's N = 2 / 4 / 8 runs go through.  Not a measurement (the line says so)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, ASAC_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '24', '--warmup', '6', '--no-cpu-baseline',
+           '--no-extras', '--profile-steps', '4', '--run-length', '0', '--fill', '20000']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints ONE JSON line'
+    d = json.loads(lines[-1])
+    assert d['n_gpus'] == 2 and d['steps'] == 24 and d['warmup'] == 6 and d['scaling'] == 'strong' and d['value'] > 0
+    assert d['config']['per_gpu_batch'] == 128 and d['config']['global_batch'] == 256 and d['config']['ranks'] == 2
+    assert d['config']['replay_shard_capacity'] == 262144 and 'ONE device' in d['config']['collectives']
+    assert d['config']['hipgraph'] is False and d['cpu_baseline'] is None
+    assert abs(d['ms_per_step'] * d['value'] - 1000.0) < 1.0          # value = steps / max-over-ranks time
