@@ -18,7 +18,7 @@
 //           split in two along k (one (column tile, k half) per wave), weights in registers
 // Training saves the two pre-activations (position-major, so rows are contiguous); the backward recomputes
 // nothing but GELU and produces the parameter gradients only (frames are data, not activations):
-//   dz2 = g * gelu'(z2);  dW2 += dz2^T patches(a1);  da1 = col2im(dz2 W2);  dz1 = da1 * gelu'(z1);
+//   dz2 = g * gelu'(z2);  dW2 += dz2^T patches(a1);  dz1 = col2im(dz2 W2) * gelu'(z1)  (a gather, no da1 buffer);
 //   dW1 += dz1^T patches(x)
 // with the two weight-gradient GEMMs accumulating in MFMA registers across all groups of a workgroup, written
 // once as per-workgroup partials and summed in fixed order by a second kernel (no float atomics).
@@ -116,7 +116,7 @@ __device__ __forceinline__ TileAt tile_at(const ConvDims& d, int64_t g) {
 }
 
 // LDS plan (floats).  fwd: frames | a1 | index tables | reduction slabs
-struct ConvFwdPlan { int img, a1, ktab, koff2, rowx, rowa, ktq, w1q, red, croptab, total; };
+struct ConvFwdPlan { int img, a1, ktab, koff2, rowx, rowa, ktq, w1q, red, total; };
 __host__ __device__ inline ConvFwdPlan conv_fwd_plan(const ConvDims& d) {
     ConvFwdPlan p;
     int off = 0;
@@ -127,7 +127,6 @@ __host__ __device__ inline ConvFwdPlan conv_fwd_plan(const ConvDims& d) {
     p.rowa = take(d.RT1 * 16);
     p.ktq = take(d.K1);
     p.w1q = take(d.K1 * 16);
-    p.croptab = take(d.tiles > 1 ? d.crop4 : 0);
     off = (off + 255) & ~255;
     p.img = take((d.G * d.CHW + 255) & ~255);   // whole KiB: the DMA path writes 1 KiB pieces
     p.a1 = take(d.G * d.O1 * d.M1);
@@ -186,29 +185,48 @@ __device__ __forceinline__ void async_copy_kib(const float* src, float* dst, int
     }
 }
 
-// tiled mode: float4 i of a crop [C][H][W] sits at croptab[i] floats behind the crop's first pixel in the frame
-__device__ __forceinline__ void build_croptab(const ConvDims& d, int* croptab) {
-    for (int i = threadIdx.x; i < d.crop4; i += kConvThreads) {
-        const int c = i / (d.H * d.cw4), rem = i - c * d.H * d.cw4, y = rem / d.cw4, x4 = rem - y * d.cw4;
-        croptab[i] = c * d.FHW + y * d.FW + 4 * x4;
+// Marks a value as produced here: the wait for the global load behind it is paid once at this point.  Without it
+// the compiler, which cannot see that the setup loads completed long ago, guards every later use inside the
+// group loop with `s_waitcnt vmcnt(0)` — which also drains the stores and the DMA prefetch then in flight.
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void settle(int& v) { asm volatile("" : "+v"(v)); }
+
+// tiled mode: float4 i of a crop [C][H][W] sits `off` floats behind the crop's first pixel in the frame.  A thread moves the
+// same float4s of every crop (piece j of wave w: i = (w + 4 j) 64 + lane), so its offsets live in registers: a table in LDS
+// cost the backward its second workgroup per CU (87 KB with it)
+constexpr int kCropPieces = 8;                                  // per wave: crops up to 4 x 8 KiB (conv_dims checks)
+constexpr int kCropMaxFloats = kCropPieces * (kConvThreads / 64) * 256;
+struct CropOffsets { int off[kCropPieces]; };
+__device__ __forceinline__ CropOffsets crop_offsets(const ConvDims& d, int wave, int lane) {
+    CropOffsets t;
+#pragma unroll
+    for (int j = 0; j < kCropPieces; ++j) {
+        const int i = min((wave + (kConvThreads / 64) * j) * 64 + lane, max(d.crop4 - 1, 0));
+        const int hw4 = max(d.H * d.cw4, 1), cw4 = max(d.cw4, 1);
+        const int c = i / hw4, rem = i - c * hw4, y = rem / cw4, x4 = rem - y * cw4;
+        t.off[j] = c * d.FHW + y * d.FW + 4 * x4;
+        settle(t.off[j]);
     }
+    return t;
 }
 
 // frames of group g -> LDS through the DMA path; frames beyond the batch re-read the last real one (their results
 // are never stored and their gradients are zero)
 template <bool TILED = false>
 __device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float* img, int wave, int lane,
-                                             const int* croptab = nullptr) {
+                                             const CropOffsets* crop = nullptr) {
     const ConvDims& d = a.d;
     if (TILED) {
-        // the crop of frame g / tiles that block g % tiles needs: a lane's 16 bytes come from wherever the table says
+        // the crop of frame g / tiles that block g % tiles needs: a lane's 16 bytes come from wherever its offsets say
         const TileAt t = tile_at<true>(d, g);
         const float* src = group_frames(a, t.frame) + (int64_t)(t.r0 * d.s2 * d.s1) * d.FW + t.c0 * d.s2 * d.s1;
         const int chunks = (d.CHW + 255) >> 8;
-        for (int c = wave; c < chunks; c += kConvThreads / 64) {
-            const int i4 = min(c * 64 + lane, d.crop4 - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + croptab[i4]),
-                                             (__attribute__((address_space(3))) void*)(img + c * 256), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < kCropPieces; ++j) {
+            const int c = wave + (kConvThreads / 64) * j;
+            if (c < chunks)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + crop->off[j]),
+                                                 (__attribute__((address_space(3))) void*)(img + c * 256), 16, 0, 0);
         }
         return;
     }
@@ -249,12 +267,6 @@ __device__ __forceinline__ void coop_copy2(const float* __restrict__ srcA, int n
         for (int i = threadIdx.x; i < nB; i += kConvThreads) dst[nA + i] = srcB[i];
     }
 }
-
-// Marks a value as produced here: the wait for the global load behind it is paid once at this point.  Without it
-// the compiler, which cannot see that the setup loads completed long ago, guards every later use inside the
-// group loop with `s_waitcnt vmcnt(0)` — which also drains the stores and the DMA prefetch then in flight.
-__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void settle(int& v) { asm volatile("" : "+v"(v)); }
 
 // workgroup barrier that only drains this wave's LDS traffic (an LDS-DMA prefetch stays in flight across it)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -310,6 +322,32 @@ __device__ __forceinline__ f32x4 conv1_tile_reg(const float* base, const int4 (&
     return acc0 + acc1;
 }
 
+// ... and a wave's quarter of the reduction of a tail tile (quads [Q1C wave / 4, Q1C (wave + 1) / 4), the accumulator
+// pattern of conv1_tile: the same bits) from the same registers — through the LDS tables each of its quads was two
+// dependent round trips (constants, then patch elements) in front of four MFMAs
+template <int Q1C, int QA, int QB>
+__device__ __forceinline__ f32x4 conv1_quads_reg(const float* base, const int4 (&ko)[Q1C], const float4 (&w)[Q1C]) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = QA; q < QB; ++q) {
+        const float a0 = base[ko[q].x], a1v = base[ko[q].y], a2 = base[ko[q].z], a3 = base[ko[q].w];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, w[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, w[q].w, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+template <int Q1C>
+__device__ __forceinline__ f32x4 conv1_tail_reg(const float* base, const int4 (&ko)[Q1C], const float4 (&w)[Q1C], int wave) {
+    switch (wave) {                                 // (uniform: a scalar branch)
+        case 0: return conv1_quads_reg<Q1C, 0, Q1C / 4>(base, ko, w);
+        case 1: return conv1_quads_reg<Q1C, Q1C / 4, Q1C / 2>(base, ko, w);
+        case 2: return conv1_quads_reg<Q1C, Q1C / 2, 3 * Q1C / 4>(base, ko, w);
+        default: return conv1_quads_reg<Q1C, 3 * Q1C / 4, Q1C>(base, ko, w);
+    }
+}
+
 // bias + GELU of one layer-1 element; keeps the activation in LDS (channel-major, what layer 2's patches index)
 // and, when training, the pre-activation in HBM (position-major: frame*M1 + pos == group row).  `abase` = the
 // row's a1 offset frame*O1*M1 + pos (negative beyond the group's positions), `z_rows` = rows backed by real frames
@@ -358,9 +396,11 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     int* ktq = reinterpret_cast<int*>(lds + p.ktq);
     float* w1q = lds + p.w1q;
     float* red = lds + p.red;
-    int* croptab = reinterpret_cast<int*>(lds + p.croptab);
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    CropOffsets crop_r{};
+    if (TILED) crop_r = crop_offsets(d, wave, lane);
+    const CropOffsets* crop = &crop_r;
     const int rows_pad = d.RT1 * 16;
     // biases are requested first: their latency hides under the table builds instead of in front of the first DMA
     const float b1v = lr < d.O1 ? a.b1[lr] : 0.f;
@@ -393,11 +433,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     int4 ko_r[QR];
     float4 w_r[QR];
     if (direct) {
-        if (TILED) {
-            build_croptab(d, croptab);
-            __syncthreads();
-        }
-        if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
+        if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, crop);
         const auto* w2p = as_global(reinterpret_cast<const f32x4*>(a.w2 + (int64_t)min(oc2, d.O2 - 1) * d.K2));
 #pragma unroll
         for (int j = 0; j < S2H / 4; ++j) {
@@ -452,7 +488,6 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         rowx[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
-    if (TILED) build_croptab(d, croptab);
     // parameters pass through the (still free) work area: W1 | W2
     coop_copy2(a.w1, d.O1 * d.K1, a.w2, d.O2 * d.K2, img);
     __syncthreads();
@@ -515,7 +550,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
     // (tiled mode: the host has checked the 16-byte granularity the crops need)
-    if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, croptab);
+    if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, crop);
     CONV_STAMP_INIT;
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         CONV_STAMP(9);
@@ -533,7 +568,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         f32x4 tail[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u)     // the last tiles: every wave takes a quarter of the reduction of each
-            if (u < rem) tail[u] = conv1_tile(img + rowx[(full + u) * 16 + lr], ktq, w1q, qa, qb);
+            if (u < rem)
+                tail[u] = Q1C > 0 ? conv1_tail_reg<QR>(img + rowx[(full + u) * 16 + lr], ko_r, w_r, wave)
+                                  : conv1_tile(img + rowx[(full + u) * 16 + lr], ktq, w1q, qa, qb);
         for (int t = wave; t < full; t += 4) {
             const f32x4 acc = Q1C > 0 ? conv1_tile_reg<QR>(img + rowx[t * 16 + lr], ko_r, w_r)
                                       : conv1_tile(img + rowx[t * 16 + lr], ktq, w1q, 0, Q1);
@@ -553,9 +590,14 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[(u * 4 + wave) * 256 + (4 * lk + r) * 16 + lr] = tail[u][r];
             }
+        CONV_STAMP(7);
         lds_barrier();             // the frames are consumed
         CONV_STAMP(1);
-        if (dma && g + gridDim.x < a.n_groups) async_frames<TILED>(a, g + gridDim.x, img, wave, lane, croptab);
+        // (a crop's six requests per wave take ~1 700 clocks to issue — the CU's 64 B / clock address path shared with the
+        // other workgroup's, whose MFMAs run meanwhile; spreading them over the loop's later phases only moved the stall:
+        // 103 -> 108 us at 1 024 frames of 84 x 84, round 6)
+        if (dma && g + gridDim.x < a.n_groups) async_frames<TILED>(a, g + gridDim.x, img, wave, lane, crop);
+        CONV_STAMP(5);
         for (int u = 0; u < rem; ++u) {
             const float* ru = red + u * 4 * 256;
             const int e = threadIdx.x;                 // element (row e/16, channel e%16) of the tile
@@ -563,8 +605,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
             const int row = (full + u) * 16 + (e >> 4);
             conv1_finish(a, g, row, rowa[row], z_rows, e & 15, sum, b1e, a1);
         }
+        CONV_STAMP(6);
         lds_barrier();
         CONV_STAMP(2);
+
         // ---- layer 2: 16 positions (G frames x M2), wave = (column tile, k half) ---------------------------
         {
             const float* base = a1 + base2;
@@ -581,8 +625,10 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * lk + r) * 16 + lr] = acc[r];
         }
+        CONV_STAMP(8);
         lds_barrier();
         CONV_STAMP(3);
+
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
             const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
@@ -604,15 +650,21 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Backward: parameter gradients only.
-// LDS: frames | z1 -> gelu'(z1) (position-major) | a1 (channel-major) | da1 (channel-major) | dz2 [16][32] |
-//      position offsets.  Per-lane constants (patch offsets of the lane's gradient columns, the W2 elements of its
-//      da1 column tiles) live in registers; 76 KB for 30x30 frames: two workgroups per CU
+// LDS: frames (two buffers) | raw z1 rows | gelu'(z1) -> dz1 (position-major) | a1 (channel-major), later the product tile
+//      dz2 W2 | dz1 of further cotangents | dz2 [16][32] | position offsets, col2im contributions.  Per-lane constants (patch
+//      offsets of the lane's gradient columns, the W2 elements of its column tiles) live in registers; 128 KB for 30 x 30
+//      frames (one workgroup per CU), 79 KB for the crops of 84 x 84 frames (two)
 // ------------------------------------------------------------------------------------------------
-struct ConvBwdPlan { int img, img_size, zraw, g1, a1, da1, da1_size, dz2, rowoff1, rowa, ktab, red, croptab, total; };
-// nc cotangents (k_conv2_bwd<., NC>): one dz2 and one da1 buffer each.  dz1 = da1 * gelu'(z1): a single cotangent forms it
-// in place of gelu'(z1) (position-major: conflict-free A operand reads), several form it in place of their da1
-// (channel-major: 2-way conflicts on 4 NC of a step's 16 + 4 NC reads) — a third set of buffers would not fit the 160 KB
-// beside the double-buffered frames (30 x 30: 130 KB + 11.2 KB per further cotangent)
+struct ConvBwdPlan { int img, img_size, zraw, g1, a1, dp_pitch, dz1x, dz1_size, dz2, rowoff1, rowa, cont, n_cont, ktab, red, total; };
+// positions of the second layer's map that one first-layer position feeds, per axis: ceil(k2 / s2)
+__host__ __device__ inline int conv_reach(const ConvDims& d) { return (d.k2 + d.s2 - 1) / d.s2; }
+// nc cotangents (k_conv2_bwd<., NC>): one dz2 buffer each; dz1 = col2im(dz2 W2) * gelu'(z1) is formed position-major
+// ([row][16 channels]: conflict-free A operand reads) — cotangent 0 in place of gelu'(z1), which every cotangent needs
+// and which therefore goes last, the others in buffers of their own (30 x 30: 128 KB + 11.2 KB per further cotangent).
+// The product tile dz2 W2 [16 positions][K2] passes through LDS as [position][ky k2 + kx][17: channel] (pitch dp_pitch,
+// rows 4 apart 16 banks apart: the gather's reads — a channel per lane — and, for 4 x 4 patches, the fragments' stores at
+// the minimum of two lanes per bank) in the place of a1, which is dead by then; the setup's patch-offset table lives
+// there too.
 __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc = 1) {
     ConvBwdPlan p;
     int off = 0;
@@ -621,16 +673,22 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc =
     p.img_size = (d.G * d.CHW + 255) & ~255;     // whole KiB pieces (LDS-DMA); two buffers: the next group's frames
     p.img = take(2 * p.img_size);                // travel while this group computes
     p.zraw = take((d.rows1 * d.O1 + 255) & ~255);   // the group's saved z1 rows as they sit in HBM (LDS-DMA target)
-    p.g1 = take(rows_pad * 16);                  // gelu'(z1), then dz1: [position row][16 channels]
-    p.a1 = take(d.G * d.O1 * d.M1);
-    p.da1_size = (d.G * d.O1 * d.M1 + 3) & ~3;
-    p.da1 = take(nc * p.da1_size);
+    p.g1 = take(rows_pad * 16);                  // gelu'(z1), then dz1 of cotangent 0: [position row][16 channels]
+    p.dp_pitch = 17 * d.k2 * d.k2;
+    p.dp_pitch += (12 - (p.dp_pitch & 7)) & 7;   // = 4 mod 8
+    int shared = d.G * d.O1 * d.M1;              // a1 | the product tile | the setup's patch offsets
+    if (shared < 16 * p.dp_pitch) shared = 16 * p.dp_pitch;
+    if (shared < 2 * kConvMaxK) shared = 2 * kConvMaxK;
+    p.a1 = take(shared);
+    p.ktab = p.a1;
+    p.dz1_size = rows_pad * 16;
+    p.dz1x = take((nc - 1) * p.dz1_size);
     p.dz2 = take(nc * 16 * 32);
     p.rowoff1 = take(rows_pad);
     p.rowa = take(rows_pad);
-    p.ktab = take(2 * kConvMaxK);
+    p.n_cont = (conv_reach(d) * conv_reach(d) + 3) & ~3;
+    p.cont = take(rows_pad * p.n_cont);          // per first-layer row: where its col2im contributions sit in the product tile
     p.red = take(kConvThreads);
-    p.croptab = take(d.tiles > 1 ? d.crop4 : 0);
     p.total = off;
     return p;
 }
@@ -657,18 +715,21 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     float* zraw = lds + p.zraw;
     float* g1 = lds + p.g1;
     float* a1 = lds + p.a1;
-    float* da1 = lds + p.da1;              // [NC][da1_size]
+    float* dpb = lds + p.a1;               // the product tile dz2 W2 of one cotangent (a1 is dead by then)
+    float* dz1x = lds + p.dz1x;            // [NC - 1][dz1_size]: dz1 of cotangents 1 .. NC - 1
+    int* cont = reinterpret_cast<int*>(lds + p.cont);
     float* dz2 = lds + p.dz2;              // [NC][16 * 32]
     int* rowoff1 = reinterpret_cast<int*>(lds + p.rowoff1);
     int* rowa = reinterpret_cast<int*>(lds + p.rowa);
     int* ktab = reinterpret_cast<int*>(lds + p.ktab);
     float* red = lds + p.red;
-    int* croptab = reinterpret_cast<int*>(lds + p.croptab);
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    CropOffsets crop_r{};
+    if (TILED) crop_r = crop_offsets(d, wave, lane);
+    const CropOffsets* crop = &crop_r;
     const int rows_pad = d.RT1 * 16;
     const int NT1 = d.K1 / 16, NT2 = d.K2 / 16;
-    if (TILED) build_croptab(d, croptab);
 
     // index tables, one entry per thread (see the note on integer division above)
     for (int row = threadIdx.x; row < rows_pad; row += kConvThreads) {
@@ -677,13 +738,27 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         rowoff1[row] = im * d.CHW + d.s1 * oy * d.W + d.s1 * ox;
         rowa[row] = row < d.rows1 ? im * d.O1 * d.M1 + pos : -1;
     }
+    // col2im as a gather: first-layer position (y, x) of a frame receives element (ky, kx) = (y - s2 oy, x - s2 ox) of the
+    // patch gradient of every second-layer position (oy, ox) whose patch covers it — at most reach^2 of them, listed here
+    // as the offset of that element's 17 channel slots in the product tile, -1: none; ascending (oy, ox): the order of the sum
+    for (int row = threadIdx.x; row < rows_pad; row += kConvThreads) {
+        const int im = row / d.M1, pos = row - im * d.M1, y = pos / d.W1, x = pos - y * d.W1;
+        int n = 0;
+        if (row < d.rows1) {
+            for (int oy = max(0, (y - d.k2 + d.s2) / d.s2); oy <= min(y / d.s2, d.H2 - 1); ++oy)
+                for (int ox = max(0, (x - d.k2 + d.s2) / d.s2); ox <= min(x / d.s2, d.W2 - 1); ++ox)
+                    cont[row * p.n_cont + n++] =
+                        (im * d.M2 + oy * d.W2 + ox) * p.dp_pitch + 17 * ((y - d.s2 * oy) * d.k2 + (x - d.s2 * ox));
+        }
+        for (; n < p.n_cont; ++n) cont[row * p.n_cont + n] = -1;
+    }
     for (int k = threadIdx.x; k < kConvMaxK; k += kConvThreads) {
         ktab[k] = k < d.K1 ? patch_offset(k, d.k1, d.H * d.W, d.W) : 0;
         ktab[kConvMaxK + k] = k < d.K2 ? patch_offset(k, d.k2, d.M1, d.W1) : 0;
     }
     __syncthreads();
     // this lane's gradient columns: k index 16 c + lr of column tile c = wave + 4 i
-    int k1off[KT1], k2off[kNT2];
+    int k1off[KT1], k2off[kNT2], dpoff[kNT2];      // (dpoff: where k2 index 16 c + lr = (channel, ky, kx) sits in a product-tile row)
     float w2b[kNT2][8];             // W2[4 s + lk][16 c + lr]: B operand of the da1 GEMM (reduction over out2)
 #pragma unroll
     for (int i = 0; i < KT1; ++i) {
@@ -694,12 +769,14 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     for (int i = 0; i < kNT2; ++i) {
         const int c = wave + 4 * i;
         k2off[i] = c < NT2 ? ktab[kConvMaxK + c * 16 + lr] : 0;
+        dpoff[i] = 17 * ((c * 16 + lr) % (d.k2 * d.k2)) + (c * 16 + lr) / (d.k2 * d.k2);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int oc = 4 * s + lk;
             w2b[i][s] = (c < NT2 && oc < d.O2) ? a.w2[oc * d.K2 + c * 16 + lr] : 0.f;
         }
     }
+    __syncthreads();                // (the offsets' table sits where the first group's a1 goes)
     // accumulators: dW1 [O1 <= 16][K1]: column tiles c = wave + 4 i;  dW2 [O2 <= 32][K2]: row tiles 0/1, same columns
     f32x4 dw1[NC][KT1], dw2[NC][2][kNT2];
     float db1[NC], db2[NC];                      // thread (channel = tid % 16 | tid % 32, row slice) partial bias sums
@@ -716,20 +793,11 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     // (rows beyond the group's G * M2 positions — 7 of the 16 with a 3 x 3 block — carry dz2 = 0: their operand
     // addresses repeat the last real row's, their col2im contributions are dropped)
     const int last_row = TILED ? d.G * d.M2 - 1 : 15;
-    const int reach = (d.k2 + d.s2 - 1) / d.s2, n_col = reach * reach;
-    int rowbase[4], acc_pos[4], acc_base[4], acc_col[4], e_im[2], e_out[2], e_py[2], e_px[2];
+    int rowbase[4], e_im[2], e_out[2], e_py[2], e_px[2];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int row = min(4 * s + lk, last_row), im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
         rowbase[s] = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = min(4 * lk + r, last_row), im = row / d.M2, pos = row - im * d.M2, oy = pos / d.W2, ox = pos - oy * d.W2;
-        acc_pos[r] = 4 * lk + r <= last_row ? pos : -1;
-        acc_base[r] = im * d.O1 * d.M1 + d.s2 * oy * d.W1 + d.s2 * ox;
-        // colour class of the position (frames of a group never overlap, but one pass per colour serves them all)
-        acc_col[r] = !TILED || acc_pos[r] < 0 ? -1 : (oy % reach) * reach + (ox % reach);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -746,7 +814,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                       ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0);
     auto request = [&](int64_t g, int buf) {
         if (TILED) {
-            async_frames<true>(a, g, lds + p.img + buf * p.img_size, wave, lane, croptab);
+            async_frames<true>(a, g, lds + p.img + buf * p.img_size, wave, lane, crop);
             return;
         }
         const int64_t first = g * d.G;
@@ -812,7 +880,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         // phase reads LDS the DMA path writes (zraw) and registers earlier loads filled (gy, z2), and in front of such a
         // use the compiler waits for EVERY outstanding memory operation — `s_waitcnt vmcnt(0)` — i.e. for the prefetch just
         // issued: the launch had no overlap of a group's transfers with the previous group's arithmetic, round 6)
-        // z1 (position-major rows, contiguous for the group) -> a1 (channel-major) and gelu'(z1); da1 <- 0
+        // z1 (position-major rows, contiguous for the group) -> a1 (channel-major) and gelu'(z1)
         {
             const float* src = a.z1 + first * d.M1 * d.O1;
             const int count = n_img * d.M1 * d.O1;
@@ -853,7 +921,6 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
             };
             if (dma) rows(std::true_type{});
             else rows(std::false_type{});
-            for (int i = threadIdx.x; i < NC * p.da1_size; i += kConvThreads) da1[i] = 0.f;
             // dz2 [row = frame*M2 + pos][32 channels] = gy * gelu'(z2)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -920,103 +987,98 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
                 }
             }
             CONV_STAMP(3);
-            // col2im: the M2 positions of a frame overlap, the k2 indices of one position do not: one pass per
-            // position (element r of the accumulator: row 4 lk + r), a barrier between passes
-            if (d.M2 <= 4) {
-                // ... with at most 4 positions a frame, element r of every lane's accumulator (row 4 lk + r) belongs to
-                // a different frame than the other lanes' element r: pass = r, uniform across the wave
+            // ---- da1 = col2im(dz2 W2) as a gather, dz1 = da1 * gelu'(z1), bias 1 ------------------------------------
+            // A cotangent's product tile goes to LDS as the fragments hold it; element (position row, channel) of dz1 then
+            // sums its <= reach^2 contributions and is scaled — no read-modify-write passes with a barrier each (one per
+            // position, or per colour class of positions whose patches cannot overlap: a third of the tiled launch and a
+            // seventh of the whole-frame one, with the da1 buffer they needed), no da1 at all.
+            lds_barrier();                                     // dW2's reads of a1 are done: the tile takes its place
+            const int oc = threadIdx.x & 15, r0 = threadIdx.x >> 4, nq = p.n_cont >> 2;
+            const bool oc_on = oc < d.O1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // (a pass's addresses are pairwise distinct — other column tiles, other cotangents' buffers: all reads,
-                    // then all additions, then all writes; one after the other each waited for its own LDS round trip)
-                    float cur[NC][kNT2];
+            for (int c = NC - 1; c >= 0; --c) {                // (cotangent 0 last: it overwrites gelu'(z1))
 #pragma unroll
-                    for (int i = 0; i < kNT2; ++i)
+                for (int i = 0; i < kNT2; ++i) {
+                    if (wave + 4 * i < NT2) {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) cur[c][i] = da1[c * p.da1_size + acc_base[r] + k2off[i]];
-#pragma unroll
-                    for (int i = 0; i < kNT2; ++i)
-                        if (wave + 4 * i < NT2 && (!TILED || acc_pos[r] >= 0)) {
-#pragma unroll
-                            for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + k2off[i]] = cur[c][i] + dp[c][i][r];
-                        }
-                    lds_barrier();
+                        for (int r = 0; r < 4; ++r) dpb[(4 * lk + r) * p.dp_pitch + dpoff[i]] = dp[c][i][r];
+                    }
                 }
-            } else {
-                // positions whose patches cannot overlap — same (oy, ox) modulo ceil(k2 / s2) — go in one pass: 4 passes
-                // for the `simple` preset's 4 x 4 / 2 second layer instead of one per position (15 with 3 x 5 blocks)
-                // (the whole-frame form keeps one pass per position: its maps of 8 / 16 positions are not on a BASELINE path,
-                // and the colour bookkeeping cost its other branch registers — 34 more SGPR spills, +1.8 us a launch)
-                const int passes = TILED ? n_col : d.M2;
-                for (int col = 0; col < passes; ++col) {
-                    // (every candidate's current value is read first — all reads of the pass in flight, those of other
-                    // colours discarded —, then the pass's own elements are written: one by one each read-modify-write
-                    // waited for its own LDS round trip, a third of the tiled launch, round 6)
-                    float cur[NC][kNT2][4];
+                // (a chunk of rows per step; a chunk's table entries and gelu' values — they do not depend on the tile — are
+                // requested one step ahead, the first chunk's in front of the barrier: one LDS round trip per step, not three)
+                constexpr int UB = 3;
+                float* out = c == 0 ? g1 : dz1x + (c - 1) * p.dz1_size;
+                auto fetch = [&](int it0, int4 (&cn_)[UB], float (&gp_)[UB]) {
 #pragma unroll
-                    for (int i = 0; i < kNT2; ++i)
+                    for (int u = 0; u < UB; ++u) {
+                        const int row = r0 + 16 * min(it0 + u, d.RT1 - 1);
+                        cn_[u] = reinterpret_cast<const int4*>(cont)[row * nq];
+                        gp_[u] = g1[row * 16 + oc];
+                    }
+                };
+                float s = 0.f;
+                auto finish = [&](int it0, const int4 (&cn_)[UB], const float (&gp_)[UB]) {
+                    float sum[UB], t[UB][4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                    for (int u = 0; u < UB; ++u) {
+                        const int e[4] = {cn_[u].x, cn_[u].y, cn_[u].z, cn_[u].w};
 #pragma unroll
-                            for (int c = 0; c < NC; ++c) cur[c][i][r] = da1[c * p.da1_size + acc_base[r] + k2off[i]];
+                        for (int j = 0; j < 4; ++j) t[u][j] = dpb[max(e[j], 0) + oc];
+                    }
+                    // (every read is issued, then masked: left to itself the compiler branches around each read of an absent
+                    // contribution and waits for each one that is present by itself)
 #pragma unroll
-                    for (int i = 0; i < kNT2; ++i) {
-                        if (wave + 4 * i < NT2) {
-                            const int ko = k2off[i];
+                    for (int u = 0; u < UB; ++u)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if ((TILED ? acc_col[r] : acc_pos[r]) == col) {
+                        for (int j = 0; j < 4; ++j) settle(t[u][j]);
 #pragma unroll
-                                    for (int c = 0; c < NC; ++c) da1[c * p.da1_size + acc_base[r] + ko] = cur[c][i][r] + dp[c][i][r];
-                                }
+                    for (int u = 0; u < UB; ++u) {
+                        const int e[4] = {cn_[u].x, cn_[u].y, cn_[u].z, cn_[u].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[u][j] = (e[j] >= 0 && oc_on) ? t[u][j] : 0.f;
+                        sum[u] = ((t[u][0] + t[u][1]) + t[u][2]) + t[u][3];
+                    }
+                    for (int q = 1; q < nq; ++q) {             // (patches reaching further than two positions per axis)
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int4 cq = reinterpret_cast<const int4*>(cont)[(r0 + 16 * min(it0 + u, d.RT1 - 1)) * nq + q];
+                            const int e[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float v = dpb[max(e[j], 0) + oc];
+                                sum[u] += (e[j] >= 0 && oc_on) ? v : 0.f;
+                            }
                         }
                     }
-                    lds_barrier();
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        if (it0 + u < d.RT1) {
+                            const float v = sum[u] * gp_[u];
+                            out[(r0 + 16 * (it0 + u)) * 16 + oc] = v;
+                            s += v;
+                        }
+                    }
+                };
+                int4 cnA[UB], cnB[UB];
+                float gpA[UB], gpB[UB];
+                fetch(0, cnA, gpA);
+                lds_barrier();
+                CONV_STAMP(7);
+                for (int it0 = 0; it0 < d.RT1; it0 += 2 * UB) {
+                    fetch(it0 + UB, cnB, gpB);                 // (beyond the end: the last row's again, not used)
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(it0, cnA, gpA);
+                    if (it0 + UB < d.RT1) {
+                        fetch(it0 + 2 * UB, cnA, gpA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        finish(it0 + UB, cnB, gpB);
+                    }
                 }
+                db1[c] += s;
+                if (c > 0) lds_barrier();                      // the tile is consumed: the next cotangent's replaces it
             }
         }
         CONV_STAMP(4);
-        // ---- dz1 = da1 * gelu'(z1) (position-major, in place of gelu'), bias 1 -------------------------------
-        {
-            const int oc = threadIdx.x & 15, r0 = threadIdx.x >> 4;
-            float s[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) s[c] = 0.f;
-            constexpr int UB = 3;                   // (three rows' reads in flight, as in the first phase)
-            for (int it0 = 0; it0 < d.RT1; it0 += UB) {
-                int ab[UB], at[UB];
-                float gp[UB], dv[NC][UB];
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const int row = r0 + 16 * min(it0 + u, d.RT1 - 1);
-                    ab[u] = rowa[row];
-                    gp[u] = g1[row * 16 + oc];
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    at[u] = (ab[u] >= 0 && oc < d.O1) ? ab[u] + oc * d.M1 : 0;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) dv[c][u] = da1[c * p.da1_size + at[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    if (it0 + u < d.RT1) {
-                        const int row = r0 + 16 * (it0 + u);
-                        const bool on = ab[u] >= 0 && oc < d.O1;
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            float v = 0.f;
-                            if (on) v = dv[c][u] * gp[u];
-                            if (NC == 1) g1[row * 16 + oc] = v;
-                            else if (on) da1[c * p.da1_size + at[u]] = v;
-                            s[c] += v;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) db1[c] += s[c];
-        }
         lds_barrier();
         CONV_STAMP(5);
         // ---- dW1 += dz1^T patches(x): reduction over the group's positions, 4 per step -------------------
@@ -1036,18 +1098,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int row = 4 * (s0 + u) + lk;
-                    if (NC == 1) {
-                        av_[0][u] = g1[row * 16 + lr];             // A[m = channel lr][k = row]
-                    } else {
-                        const int ab = rowa[row];                  // (rows beyond the group's positions: zero)
-                        const bool on = ab >= 0 && lr < d.O1;
-                        const int at = on ? ab + lr * d.M1 : 0;
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) {
-                            const float v = da1[c * p.da1_size + at];
-                            av_[c][u] = on ? v : 0.f;
-                        }
-                    }
+                    for (int c = 0; c < NC; ++c)                   // A[m = channel lr][k = row]
+                        av_[c][u] = (c == 0 ? g1 : dz1x + (c - 1) * p.dz1_size)[row * 16 + lr];
 #pragma unroll
                     for (int i = 0; i < KT1; ++i) bv_[u][i] = img[ro_[u] + k1off[i]];     // (gathered once for all cotangents)
                 }
@@ -1196,13 +1249,13 @@ static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
     ConvDims pick{};
     for (int bh = 1; bh <= 16 && bh <= full.H2; ++bh)
         for (int bw = 1; bh * bw <= 16 && bw <= full.W2; ++bw) {
-            if (bh * bw <= 4) continue;           // (the col2im pass of M2 <= 4 assumes whole groups of frames)
+            if (bh * bw <= 4) continue;           // (never the cheapest cover; not exercised)
             ConvDims t = full;
             t.bh = bh, t.bw = bw;
             t.H2 = bh, t.W2 = bw, t.M2 = bh * bw;
             t.H1 = (bh - 1) * t.s2 + t.k2, t.W1 = (bw - 1) * t.s2 + t.k2, t.M1 = t.H1 * t.W1;
             t.H = (t.H1 - 1) * t.s1 + t.k1, t.W = (t.W1 - 1) * t.s1 + t.k1, t.CHW = t.C * t.H * t.W;
-            if (t.W & 3) continue;
+            if ((t.W & 3) || t.CHW > kCropMaxFloats) continue;
             const int nby = (full.H2 + bh - 1) / bh;
             t.nbx = (full.W2 + bw - 1) / bw;
             t.tiles = nby * t.nbx;

@@ -11,7 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import asac_amd  # noqa: E402,F401
 from asac_amd import native  # noqa: E402
 
-NAMES = ['dma wait', 'z1 -> a1, gelu\', dz2', 'dW2 (+ db2)', 'dp = dz2 W2', 'col2im', 'dz1', 'dW1', '-', '-', 'loop top']
+NAMES = ['dma wait', 'z1 -> a1, gelu\', dz2', 'dW2 (+ db2)', 'dp = dz2 W2', 'col2im gather -> dz1', 'barrier', 'dW1', 'product tile -> LDS, barrier', '-', 'loop top']
 lib = native.load()
 N, C, H, W = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (9216, 3, 30, 30)))
 desc = native.conv2_desc(C, H, W, 16, 8, 4, 32, 4, 2)
@@ -39,8 +39,9 @@ for nc in range(1, native.conv2_backward_multi_max(desc) + 1):
     e1.record()
     torch.cuda.synchronize()
     st = (ctypes.c_ulonglong * 16)()
-    lib.asac_debug_conv_stamps(st)
-    tot = sum(st[:10])
+    if hasattr(lib, "asac_debug_conv_stamps"):
+        lib.asac_debug_conv_stamps(st)       # (a library built without -DASAC_CONV_STAMPS: the timing only)
+    tot = sum(st[:10]) or 1
     print(f'NC = {nc}: {e0.elapsed_time(e1) * 100:.1f} us per launch pair; workgroup 0: {tot} clocks over its groups')
     for k, name in enumerate(NAMES):
         if st[k]:
