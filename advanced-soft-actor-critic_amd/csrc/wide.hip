@@ -57,23 +57,32 @@ __global__ __launch_bounds__(kThreads) void k_wide_fwd(const FwdArgs a) {
     f32x4 acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // two quads in flight: the loads of quad q + 1 are requested before the MFMAs of quad q
-    f32x4 xa = xp[q0 * 4], wb[NTW];
+    // WIDE_DEPTH quads in flight: slot d holds quad q + d; its successor q + d + DEPTH is requested as soon as the slot's
+    // MFMAs are issued (slots beyond the chunk hold zeros: no branch around an MFMA)
+#ifndef WIDE_DEPTH
+#define WIDE_DEPTH 2
+#endif
+    constexpr int D = WIDE_DEPTH;
+    f32x4 xa[D], wb[D][NTW];
+    auto fetch = [&](int d, int q) {
+        const bool on = q < q1;
+        const int qc = min(q, q1 - 1);
+        const f32x4 xv = xp[qc * 4];
+        xa[d] = on ? xv : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) wb[t] = wp[t][q0 * 4];
-    for (int q = q0; q < q1; ++q) {
-        const int qn = min(q + 1, q1 - 1);
-        const f32x4 xn = xp[qn * 4];
-        f32x4 wn[NTW];
+        for (int t = 0; t < NTW; ++t) wb[d][t] = wp[t][qc * 4];
+    };
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) wn[t] = wp[t][qn * 4];
+    for (int d = 0; d < D; ++d) fetch(d, q0 + d);
+    for (int q = q0; q < q1; q += D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int d = 0; d < D; ++d) {
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[j], wb[t][j], acc[t], 0, 0, 0);
-        xa = xn;
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) wb[t] = wn[t];
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[d][j], wb[d][t][j], acc[t], 0, 0, 0);
+            fetch(d, q + d + D);
+        }
     }
     // D[row 4 g + r][column m] of each column tile -> the chunk's partial slab
     float* out = a.part + (int64_t)blockIdx.y * a.R * a.N;
