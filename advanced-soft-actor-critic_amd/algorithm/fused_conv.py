@@ -83,12 +83,19 @@ class DeferredConvBackward:
             x, z1, z2, w2 = ctx.saved_tensors
             n_frames = x.shape[0] * x.shape[1] if ctx.windows else x.shape[0]
             walks = sorted(by_walk)
-            for lo in range(0, len(walks), native.CONV2_MAX_COTANGENTS):
-                part = walks[lo:lo + native.CONV2_MAX_COTANGENTS]
+            from .fused_mlp import DeferredPartialSums
+            later = DeferredPartialSums.active()      # (the launch's own second launch — the slab sums — may wait as well)
+            most = native.conv2_backward_multi_max(desc) if later is not None else native.CONV2_MAX_COTANGENTS
+            for lo in range(0, len(walks), most):
+                part = walks[lo:lo + most]
                 n = native.conv2_param_count(desc)
                 g = torch.empty(len(part), n, dtype=x.dtype, device=x.device)
-                ws = torch.empty(len(part) * native.conv2_backward_workspace(desc, n_frames), dtype=x.dtype, device=x.device)
-                native.conv2_backward_multi(desc, x, w2.detach().contiguous(), z1, z2, [by_walk[k] for k in part], g, ws)
+                slabs = native.conv2_backward_workspace(desc, n_frames) // n
+                ws = torch.empty(len(part) * slabs * n, dtype=x.dtype, device=x.device)
+                native.conv2_backward_multi(desc, x, w2.detach().contiguous(), z1, z2, [by_walk[k] for k in part], g, ws,
+                                            native.SUM_DEFER if later is not None else False)
+                if later is not None:
+                    later.add(ws, slabs, 16, len(part) * n, len(part) * n, g.view(-1))
                 for row, k in enumerate(part):
                     off, grads = 0, out.setdefault(k, {})
                     for p_ in ctx.params:
@@ -157,16 +164,27 @@ class _ConvStackFn(torch.autograd.Function):
         flat = None
         if DIRECT_PARAM_GRADS and direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
+        from .fused_mlp import DeferredPartialSums
+        later = DeferredPartialSums.active()          # (the slab sums as one launch with the walk's other second launches)
+        n = native.conv2_param_count(desc)
         if flat is not None:
-            run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws, True)
+            run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws,
+                native.SUM_DEFER if later is not None else True)
+            if later is not None:
+                later.add(ws, ws.numel() // n, 16, n, n, flat, accumulate=True)
             return (None, None, None, None, None, None, None, None)
-        g = torch.empty(native.conv2_param_count(desc), dtype=x.dtype, device=x.device)
-        run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws)
+        g = torch.empty(n, dtype=x.dtype, device=x.device)
+        run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws,
+            native.SUM_DEFER if later is not None else False)
         grads, off = [], 0
         for p in params:
             k = p.numel()
             grads.append(g[off:off + k].view(p.shape) if p.requires_grad else None)
             off += k
+        if later is not None:           # (the gradients reach the caller through `later.flush()`)
+            later.add(ws, ws.numel() // n, 16, n, n, g)
+            later.record(params, grads)
+            grads = [None] * 4
         return (None, None, *grads, None, None)
 
 

@@ -6,6 +6,7 @@ Anything else (user-defined models, discrete heads, other activations, widths > 
 generic module path; `describe_*` returns None and the caller falls back.
 """
 import contextlib
+import os
 import weakref
 
 import torch
@@ -280,6 +281,57 @@ def describe_policy(pi) -> 'native.MlpDesc | None':
     return desc
 
 
+class DeferredPartialSums:
+    """While active, the backward launches below (and the attention blocks', seq_layers._AttnProjFn) that would hand
+    parameter gradients BACK to autograd — `autograd.grad` walks, not the learner's direct mode — return None for them and
+    leave the second launch of each (the per-workgroup partials summed in workgroup order) to `flush()`, which runs up to
+    sixteen of them as ONE launch (`native.sum_partials_multi`; per job the order, hence the bits, of the launch it stands
+    for) and returns {walk: {id(parameter): gradient}} for the caller to put where autograd left None — like
+    fused_conv.DeferredConvBackward, and for the same walks: those of `calculate_adaptive_weights` / `_train_rpm` (reference
+    sac_base.py:1607-1631, 1798-1839), which only collect their parameter gradients.  `walk`: set by the caller in front of
+    each `autograd.grad`.  A parameter other nodes of the graph use as well still gets those nodes' contributions from
+    autograd; the caller adds."""
+    _active = None
+
+    def __init__(self):
+        self.jobs, self.grads, self.walk, self._outer = [], {}, 0, None
+
+    @classmethod
+    def active(cls):
+        return cls._active if SUM_PARTIALS_LATER else None
+
+    def __enter__(self):
+        self._outer, DeferredPartialSums._active = DeferredPartialSums._active, self
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        DeferredPartialSums._active = self._outer
+        return False
+
+    def add(self, partial, slabs, slices, slab_stride, n, out, accumulate=False):
+        self.jobs.append((partial, slabs, slices, slab_stride, n, out, bool(accumulate)))
+
+    def record(self, params, grads):
+        """the gradients (views of buffers `add`ed above) this walk owes `params`"""
+        mine = self.grads.setdefault(self.walk, {})
+        for p, g in zip(params, grads):
+            if g is not None:
+                mine.setdefault(id(p), []).append(g)
+
+    def flush(self):
+        """-> {walk: {id(parameter): gradient}}; the sums run here (one launch per sixteen recorded backwards)"""
+        jobs, self.jobs = self.jobs, []
+        for k in range(0, len(jobs), native.SUM_PARTIALS_MAX_JOBS):
+            native.sum_partials_multi(jobs[k:k + native.SUM_PARTIALS_MAX_JOBS])
+        taken, self.grads = self.grads, {}
+        # (a parameter two recorded nodes of one walk share: their gradients added, as autograd would have)
+        return {walk: {pid: gl[0] if len(gl) == 1 else sum(gl[1:], gl[0]) for pid, gl in mine.items()}
+                for walk, mine in taken.items()}
+
+
+SUM_PARTIALS_LATER = os.environ.get('ASAC_SUM_PARTIALS_LATER', '1') != '0'    # (A/B switch)
+
+
 def _param_grad_target(mlp, param_grads, n_params):
     """-> (kernel target | None, gradients to return to autograd): the flat `.grad` views in direct mode, else a
     scratch buffer with the parameters' layout, returned as one view per parameter"""
@@ -311,8 +363,12 @@ class _MlpFn(torch.autograd.Function):
         mlp = ctx.mlp
         need0, need1 = ctx.needs_input_grad[1], ctx.has_x1 and ctx.needs_input_grad[2]
         target, pg = _param_grad_target(mlp, ctx.param_grads, ctx.n_params)
+        later = DeferredPartialSums.active() if ctx.param_grads else None
         g0, g1 = mlp._launch_backward(x0, x1, grad_out.contiguous(), need0, need1, ctx.param_grads,
-                                      grad_target=target)
+                                      grad_target=target, later=later)
+        if later is not None and target is not None:       # (the gradients reach the caller through `later.flush()`)
+            later.record(mlp.param_tensors, pg)
+            pg = [None] * ctx.n_params
         return (None, g0, g1, None, None, *pg)
 
 
@@ -338,8 +394,12 @@ class _MlpSelectFn(torch.autograd.Function):
         mlp, t = ctx.mlp, ctx.t
         need0, need1 = ctx.needs_input_grad[1], ctx.has_x1 and ctx.needs_input_grad[3]
         target, pg = _param_grad_target(mlp, ctx.param_grads, ctx.n_params)
+        later = DeferredPartialSums.active() if ctx.param_grads else None
         g0, g1 = mlp._launch_backward(base[:, t], x1, grad_out.contiguous(), need0, need1, ctx.param_grads,
-                                      reduce_members=False, grad_target=target)
+                                      reduce_members=False, grad_target=target, later=later)
+        if later is not None and target is not None:       # (the gradients reach the caller through `later.flush()`)
+            later.record(mlp.param_tensors, pg)
+            pg = [None] * ctx.n_params
         g_base = None
         if g0 is not None:
             g_base = torch.zeros_like(base)
@@ -499,7 +559,7 @@ class StockMLP:
         return native.mlp_job(self.desc, self.params, self.member_stride, self.E, x0, x1, N, out), out
 
     def _launch_backward(self, x0, x1, grad_out, need0, need1, param_grads, reduce_members=True, defer=False,
-                         grad_target=None):
+                         grad_target=None, later=None):
         """-> (grad_x0, grad_x1).  An input shared by the E members ([N, in]) gets the sum of the members'
         gradients unless `reduce_members` is False (then [E, N, in] comes back for a consumer kernel
         that sums itself).  `defer`: see `backward_qloss`.  `grad_target`: a buffer laid out like the parameters
@@ -516,6 +576,17 @@ class StockMLP:
             if grad_target is not None:
                 assert not defer
                 gp, mode = grad_target, native.MLP_REDUCE_OVERWRITE
+            if later is not None and not defer:
+                # the partials stay in a workspace of this call's own until `later.flush()` sums them into the target — the
+                # scratch buffer autograd would have been handed, or (direct mode) the flat gradient views
+                # (`later`: DeferredPartialSums; the cached workspace would be overwritten by the network's next pass)
+                ws = torch.empty(native.mlp_backward_workspace(self.member_stride, E, N), dtype=torch.float32,
+                                 device=self.device)
+                tiles, used = native.mlp_backward_tiles(N, E), native.mlp_param_extent(self.desc)
+                for e in range(E):
+                    later.add(ws[e * self.member_stride:], tiles, 16 if tiles >= 64 else 1, E * self.member_stride, used,
+                              gp[e * self.member_stride:], accumulate=mode == native.MLP_REDUCE_ACCUMULATE)
+                mode = native.MLP_REDUCE_DEFER
         native.mlp_backward(self.desc, self.params, self.member_stride, E, x0, x1, N, grad_out, g0, g1, gp, ws,
                             reduce_mode=mode)
         if reduce_members:

@@ -318,18 +318,29 @@ class _AttnProjFn(torch.autograd.Function):
         flat = None
         if direct_enabled() and all(p.requires_grad and p.grad is not None for p in params):
             flat = _flat_alias([p.grad for p in params])
+        from algorithm.fused_mlp import DeferredPartialSums
+        later = DeferredPartialSums.active()
         if flat is not None:
-            native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, flat, True, ws,
-                                           keep, attn_out, ctx.row_zero)
+            native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, flat,
+                                           native.SUM_DEFER if later is not None else True, ws, keep, attn_out, ctx.row_zero)
+            if later is not None:
+                slabs, n = native.attention_proj_partials(ws, E, len(params) == 8)
+                later.add(ws, slabs, 16, n, n, flat, accumulate=True)
             return (g_xq, g_xk, None, None, *([None] * len(params)))
         g = torch.empty(sum(p.numel() for p in params), dtype=xq.dtype, device=xq.device)
-        native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, g, False, ws, keep,
-                                       attn_out, ctx.row_zero)
+        native.attention_proj_backward(xq, xk, pd, weights, g_out, gw, g_xq, g_xk, g,
+                                       native.ATTN_SUM_DEFER if later is not None else False, ws, keep, attn_out, ctx.row_zero)
+        if later is not None:       # (the workgroups' partials are summed into g with the other walks', one launch)
+            slabs, n = native.attention_proj_partials(ws, E, len(params) == 8)
+            later.add(ws, slabs, 16, n, n, g)
         grads, off = [], 0
         for p_ in params:
             k = p_.numel()
             grads.append(g[off:off + k].view(p_.shape) if p_.requires_grad else None)
             off += k
+        if later is not None:       # (the gradients reach the caller through `later.flush()`)
+            later.record(params, grads)
+            grads = [None] * len(params)
         return (g_xq, g_xk, None, None, *grads)
 
 

@@ -448,26 +448,44 @@ class AuxHeadsMixin:
             # until all three output gradients are known and runs as ONE launch (fused_conv.DeferredConvBackward)
             from .fused_conv import DeferredConvBackward
             conv_later = DeferredConvBackward() if self._rpm_conv_one_launch else None
-            for loss_i, params_i in zip(losses, model_params):
-                got = autograd.grad(loss_i, [nx_states, *params_i], grad_outputs=unit_gradient(loss_i), allow_unused=True,
-                                    retain_graph=True)
-                gs += got[1:]
-                if got[0] is None:
-                    aux.append([None] * len(rep_params))
-                elif conv_later is None:
-                    aux.append(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
-                                             retain_graph=True))
-                else:
-                    conv_later.walk = len(aux)
-                    with conv_later:
+            # ... and none of the walks' parameter gradients is read before all walks are done: the fixed-order sums of the
+            # backward launches' per-workgroup partials (twelve second launches) wait too and run as one launch
+            # (fused_mlp.DeferredPartialSums; walk ('m', k): through model k down to `nx_states`, ('r', k): the representation)
+            from .fused_mlp import DeferredPartialSums
+            with DeferredPartialSums() as sums_later:
+                for k, (loss_i, params_i) in enumerate(zip(losses, model_params)):
+                    sums_later.walk = ('m', k)
+                    got = autograd.grad(loss_i, [nx_states, *params_i], grad_outputs=unit_gradient(loss_i), allow_unused=True,
+                                        retain_graph=True)
+                    gs += got[1:]
+                    sums_later.walk = ('r', k)
+                    if got[0] is None:
+                        aux.append([None] * len(rep_params))
+                    elif conv_later is None:
                         aux.append(list(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
                                                       retain_graph=True)))
-            if conv_later is not None:
-                for walk, grads in conv_later.flush().items():
-                    for j, p_ in enumerate(rep_params):
-                        g_conv = grads.get(id(p_))
-                        if g_conv is not None:
-                            aux[walk][j] = g_conv if aux[walk][j] is None else aux[walk][j] + g_conv
+                    else:
+                        conv_later.walk = len(aux)
+                        with conv_later:
+                            aux.append(list(autograd.grad(nx_states, rep_params, grad_outputs=got[0], allow_unused=True,
+                                                          retain_graph=True)))
+                conv_late = conv_later.flush() if conv_later is not None else {}     # (its slab sums join the others)
+
+            def put(grads, params, late):       # a deferred launch's gradients where autograd left None (or beside its own)
+                for j, p_ in enumerate(params):
+                    g_late = late.get(id(p_))
+                    if g_late is not None:
+                        grads[j] = g_late if grads[j] is None else grads[j] + g_late
+
+            late, off = sums_later.flush(), 0
+            for k, params_i in enumerate(model_params):
+                put_into = gs[off:off + len(params_i)]
+                put(put_into, params_i, late.get(('m', k), {}))
+                gs[off:off + len(params_i)] = put_into
+                off += len(params_i)
+                put(aux[k], rep_params, late.get(('r', k), {}))
+            for walk, grads in conv_late.items():
+                put(aux[walk], rep_params, grads)
             self._add_gated_gradients(grads_rep_main, aux, rep_params)
         else:
             if grads_rep_main:

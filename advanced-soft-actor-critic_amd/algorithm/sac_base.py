@@ -35,7 +35,7 @@ from asac_amd import native
 
 from . import fused_gru, fused_linear
 from .fused import DeviceNoise, FlatAdam, FlatParamGroup, squash_sample, squash_sample_ls, time_slice
-from .fused_mlp import StockMLP, describe_policy, describe_q, direct_param_grads
+from .fused_mlp import DeferredPartialSums, StockMLP, describe_policy, describe_q, direct_param_grads
 from .nn_models import *  # noqa: F401,F403
 from .nn_models.layers.seq_layers import step_mask_cache
 from .nn_models.representation import ModelSimpleRep
@@ -1308,7 +1308,9 @@ class SAC_Base(AuxHeadsMixin):
                 if not (at_position or from_head):
                     torch.sum(g0, dim=0, out=g_base[:, t])
             rep_stepped = False
-            with direct_param_grads():
+            # (the backward launches' second launches — per-workgroup partials summed into the flat gradient — run as one
+            # launch when the walk is done, in front of the optimizer step: fused_mlp.DeferredPartialSums)
+            with direct_param_grads(), DeferredPartialSums() as sums_later:
                 if at_position:
                     # the window IS a fused GRU's output: its backward sums the members' gradients itself and starts at
                     # position t (the steps behind it only feed detached targets) — no member-sum launch in between;
@@ -1320,6 +1322,7 @@ class SAC_Base(AuxHeadsMixin):
                     fused_linear.backward_from_members(base, g0, t, g_base)
                 else:
                     torch.autograd.backward([base], [g_base])
+            sums_later.flush()
             if fold:
                 if not rep_stepped:
                     self.optimizer_q_list[0].step(*self._params.span('rep'))
@@ -1352,9 +1355,10 @@ class SAC_Base(AuxHeadsMixin):
                     w = priority_is.reshape(-1).contiguous() if priority_is is not None else None
                     native.q_loss_fwd_bwd(c_q.detach().contiguous(), t_q.contiguous(), c_y.reshape(-1), w,
                                           self.clip_epsilon, self._loss_q_e, self._grad_q)
-                    with direct_param_grads():
+                    with direct_param_grads(), DeferredPartialSums() as sums_later:
                         torch.autograd.backward([c_q], [self._grad_q],
                                                 retain_graph=aux is not None and self.use_prediction)
+                    sums_later.flush()
                     if aux is None:
                         return self._finish_rep_q(None, None)
                     return self._finish_rep_q(None, None, aux,
@@ -1402,8 +1406,9 @@ class SAC_Base(AuxHeadsMixin):
             # the prediction heads differentiate the representation graph again (sac_aux._train_rpm)
             # the main loss accumulates into every parameter it reaches (representation + Q ensemble): the fused
             # layers add their parameter gradients in place
-            with direct_param_grads():
+            with direct_param_grads(), DeferredPartialSums() as sums_later:
                 total_loss.backward(retain_graph=aux is not None and self.use_prediction)
+            sums_later.flush()
             self._stats['loss_q'].copy_(loss_q0.detach())
         start, stop = self._params.span('rep', f'q_{self.ensemble_q_num - 1}')
         if aux is None:

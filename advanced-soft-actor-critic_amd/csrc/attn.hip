@@ -737,8 +737,9 @@ int asac_attention_proj_backward(const float* xq, int64_t xq_stride_b, int64_t x
     else
         ASAC_LAUNCH(k_attn_proj_bwd<16>, dim3((unsigned)blocks), dim3(kAttnThreads), 0, s, a, P, EPB);
     // launched once (not under the repeat knob: it may accumulate)
-    hipLaunchKernelGGL(k_attn_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * 16), 0, s, workspace, blocks, n,
-                       grad_params, accumulate);
+    if (accumulate != ASAC_ATTN_SUM_DEFER)
+        hipLaunchKernelGGL(k_attn_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * 16), 0, s, workspace, blocks, n,
+                           grad_params, accumulate);
     return finish_launch("asac_attention_proj_backward");
 }
 

@@ -15,7 +15,7 @@ PKG = CSRC.parent
 REPO = PKG.parent
 LIB_DIR = PKG / 'lib'
 LIB = LIB_DIR / 'libasac_hip.so'
-SOURCES = ['sumtree.hip', 'gather.hip', 'returns.hip', 'optim.hip', 'mlp.hip', 'gru.hip', 'gru_wide.hip', 'noise.hip', 'conv.hip', 'attn.hip', 'attn_mh.hip', 'rows_proj.hip', 'graph_fix.hip', 'xty.hip', 'linear.hip', 'episode.hip', 'decoder.hip', 'wide.hip']
+SOURCES = ['sumtree.hip', 'gather.hip', 'returns.hip', 'optim.hip', 'mlp.hip', 'gru.hip', 'gru_wide.hip', 'noise.hip', 'conv.hip', 'attn.hip', 'attn_mh.hip', 'rows_proj.hip', 'graph_fix.hip', 'xty.hip', 'linear.hip', 'episode.hip', 'decoder.hip', 'wide.hip', 'reduce.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
          '-Wall', '-Wno-unused-function']
 

@@ -1414,9 +1414,10 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
                                : (kt3 ? launch(k_conv2_bwd<false, 1, 3>, attr3) : launch(k_conv2_bwd<false, 1, 4>, attr)))
         return rc;
     const int n = conv_param_count(a.d);
-    // launched once (not under the repeat knob: it may accumulate)
-    hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
-                       (int)blocks, n, grad_params, accumulate);
+    // launched once (not under the repeat knob: it may accumulate); ASAC_CONV_SUM_DEFER: left to asac_sum_partials_multi
+    if (accumulate != ASAC_CONV_SUM_DEFER)
+        hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
+                           (int)blocks, n, grad_params, accumulate);
     return finish_launch("asac_conv2_backward");
 }
 
@@ -1459,6 +1460,8 @@ int asac_conv2_backward_multi(const asac_conv2_desc_t* desc, const float* x, int
         return bad_arg("asac_conv2_backward_multi: tiled frames need 16-byte aligned rows");
     const size_t lds = (size_t)conv_bwd_plan(a.d, n_cot).total * sizeof(float);
     if (n_cot > asac_conv2_backward_multi_max(desc)) {         // (more buffer sets than fit: launches of as many as do)
+        if (accumulate == ASAC_CONV_SUM_DEFER)                 // (... which share the workspace: their partials cannot wait)
+            return bad_arg("asac_conv2_backward_multi: deferred sums take at most asac_conv2_backward_multi_max cotangents");
         const int64_t n = conv_param_count(a.d);
         const int most = asac_conv2_backward_multi_max(desc);
         for (int c = 0; c < n_cot; c += most)
@@ -1493,8 +1496,9 @@ int asac_conv2_backward_multi(const asac_conv2_desc_t* desc, const float* x, int
                    : (kt3 ? launch(k_conv2_bwd<false, 3, 3>, attr[0][1][0]) : launch(k_conv2_bwd<false, 3, 4>, attr[0][1][1]));
     if (rc) return rc;
     const int n = conv_param_count(a.d) * n_cot;       // (a block's n_cot slabs are consecutive: one reduction over all of them)
-    hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
-                       (int)blocks, n, grads_out, accumulate);
+    if (accumulate != ASAC_CONV_SUM_DEFER)
+        hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
+                           (int)blocks, n, grads_out, accumulate);
     return finish_launch("asac_conv2_backward_multi");
 }
 

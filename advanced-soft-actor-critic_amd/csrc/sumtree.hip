@@ -592,6 +592,7 @@ int asac_version(void) { return ASAC_ABI_VERSION; }
 int64_t asac_struct_size(const char* name) {
 #define ASAC_SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T)
     ASAC_SZ(asac_gather_key_t);
+    ASAC_SZ(asac_partial_sum_t);
     ASAC_SZ(asac_row_move_t);
     ASAC_SZ(asac_sidecar_t);
     ASAC_SZ(asac_squash_job_t);

@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 79
+ABI_VERSION = 80
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -139,6 +139,12 @@ class SampleEpilogue(C.Structure):
     """asac_mlp_sample_epilogue_t: asac_squash_multi's jobs as the epilogue of a policy job of `mlp_forward_multi_sampled`"""
     _fields_ = [('sample', SquashJob), ('eps2', C.c_void_p), ('t2', C.c_int32), ('reserved_', C.c_int32),
                 ('a2_out', C.c_void_p), ('logp2_out', C.c_void_p)]
+
+
+class PartialSum(C.Structure):
+    """asac_partial_sum_t: one fixed-order sum of per-workgroup partials (`sum_partials_multi`)"""
+    _fields_ = [('partial', C.c_void_p), ('out', C.c_void_p), ('slab_stride', C.c_int64), ('n', C.c_int64),
+                ('slabs', C.c_int32), ('slices', C.c_int32), ('accumulate', C.c_int32), ('pad_', C.c_int32)]
 
 
 class GruDesc(C.Structure):
@@ -315,6 +321,7 @@ _SIGNATURES = {
     'asac_normal_nll_kl_logstd': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_int64,
                                             C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    'asac_sum_partials_multi': (C.c_int, [C.c_int, C.POINTER(PartialSum), C.c_void_p]),
     'asac_rows_wide_supported': (C.c_int, [C.c_int64, C.c_int, C.c_int]),
     'asac_rows_wide_workspace': (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     'asac_rows_wide_forward': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -1269,8 +1276,34 @@ def attention_proj_backward(xq, xk, params, weights, grad_out, grad_weights, gra
     _check(load().asac_attention_proj_backward(pq, qsb, qsr, pk, ksb, ksr, _proj_ptrs(params), _p(weights), _p(keep),
                                                _p(attn_out), pg, gsb, gsr, _p(grad_weights), *_row_mask(row_zero),
                                                xq.shape[0], xq.shape[1], xk.shape[1], xq.shape[2],
-                                               _p(grad_xq), _p(grad_xk), _p(grad_params), int(bool(accumulate)),
+                                               _p(grad_xq), _p(grad_xk), _p(grad_params),
+                                               _sum_mode(accumulate),
                                                _p(workspace), _stream()), 'asac_attention_proj_backward')
+
+
+ATTN_SUM_DEFER = CONV_SUM_DEFER = SUM_DEFER = 2      # `accumulate` of attention_proj_backward / conv2_backward*: the partials
+                                                     # stay in the workspace (for `sum_partials_multi`)
+SUM_PARTIALS_MAX_JOBS = 16
+
+
+def attention_proj_partials(workspace, E: int, output_block: bool):
+    """-> (slabs, n) of the partials an `attention_proj_backward(..., accumulate=ATTN_SUM_DEFER)` left in `workspace`"""
+    return workspace.numel() // (4 * (E * E + E)), (4 if output_block else 3) * (E * E + E)
+
+
+@_profiled
+def sum_partials_multi(jobs):
+    """jobs: [(partial, slabs, slices, slab_stride, n, out, accumulate), ...] (at most SUM_PARTIALS_MAX_JOBS) — out[:n]
+    (+)= the slabs of `partial` in the fixed order of the launch each job stands for (slices 16: the sliced reductions of
+    `mlp_backward` with >= 64 tiles and of `attention_proj_backward`; 1: slab order), as ONE launch"""
+    assert 1 <= len(jobs) <= SUM_PARTIALS_MAX_JOBS
+    arr = (PartialSum * len(jobs))()
+    for k, (partial, slabs, slices, slab_stride, n, out, accumulate) in enumerate(jobs):
+        assert partial.dtype == out.dtype == torch.float32 and partial.is_cuda and out.is_cuda
+        assert partial.numel() >= (slabs - 1) * slab_stride + n and out.numel() >= n
+        arr[k] = PartialSum(partial.data_ptr(), out.data_ptr(), int(slab_stride), int(n), int(slabs), int(slices),
+                            int(bool(accumulate)), 0)
+    _check(load().asac_sum_partials_multi(len(jobs), arr, _stream()), 'asac_sum_partials_multi')
 
 
 LINEAR_TANH_MAX_IN, LINEAR_TANH_MAX_OUT = 64, 16
@@ -1452,6 +1485,11 @@ def conv2_param_count(desc) -> int:
     return int(load().asac_conv2_param_count(C.byref(desc)))
 
 
+def _sum_mode(accumulate) -> int:
+    """False / True / SUM_DEFER -> the entry points' `accumulate` argument"""
+    return SUM_DEFER if (accumulate is not True and accumulate is not False and accumulate == SUM_DEFER) else int(bool(accumulate))
+
+
 def conv2_backward_workspace(desc, N) -> int:
     return int(load().asac_conv2_backward_workspace(C.byref(desc), N))
 
@@ -1519,7 +1557,7 @@ def conv2_backward_windows(desc, x, w2, z1, z2, grad_y, grad_params, workspace, 
     _dense_f32(w2, z1, z2, grad_y, grad_params, workspace)
     assert x.dtype == torch.float32 and x.is_cuda and x[0].is_contiguous()
     _check(load().asac_conv2_backward_windows(C.byref(desc), _p(x), B * T, T, x.stride(0), _p(w2), _p(z1), _p(z2),
-                                              _p(grad_y), _p(grad_params), int(bool(accumulate)), _p(workspace),
+                                              _p(grad_y), _p(grad_params), _sum_mode(accumulate), _p(workspace),
                                               _stream()), 'asac_conv2_backward_windows')
 
 
@@ -1552,7 +1590,7 @@ def conv2_backward_multi(desc, x, w2, z1, z2, grad_ys, grads_out, workspace, acc
         fps, stride = 0, 0
     ptrs = (C.c_void_p * nc)(*[g.data_ptr() for g in grad_ys])
     _check(load().asac_conv2_backward_multi(C.byref(desc), _p(x), n_frames, fps, stride, _p(w2), _p(z1), _p(z2), ptrs, nc,
-                                            _p(grads_out), int(bool(accumulate)), _p(workspace), _stream()),
+                                            _p(grads_out), _sum_mode(accumulate), _p(workspace), _stream()),
            'asac_conv2_backward_multi')
 
 
@@ -1563,7 +1601,7 @@ def conv2_backward(desc, x, w2, z1, z2, grad_y, grad_params, workspace, accumula
     _last_work = conv2_flops(desc, x.shape[0], backward=True)
     _dense_f32(x, w2, z1, z2, grad_y, grad_params, workspace)
     _check(load().asac_conv2_backward(C.byref(desc), _p(x), x.shape[0], _p(w2), _p(z1), _p(z2), _p(grad_y),
-                                      _p(grad_params), int(bool(accumulate)), _p(workspace), _stream()),
+                                      _p(grad_params), _sum_mode(accumulate), _p(workspace), _stream()),
            'asac_conv2_backward')
 
 

@@ -595,6 +595,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item())
 
+    # The interpreter's full (generation 2) collections take 45-60 ms over the ~2e5 objects a filled learner holds, and where
+    # one falls depends on allocation counts (it fell inside the 0.1 s timed region of every process but the first on a box —
+    # byte-code caches change the counts — and read as 2 300 instead of 3 170 steps/s at cfg4, round 6): everything alive
+    # after the warm-up is long-lived, so it is collected once here and frozen; the collector stays ON for what the timed
+    # steps allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

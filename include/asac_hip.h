@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 79
+#define ASAC_ABI_VERSION 80
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -1048,8 +1048,9 @@ int asac_attention_backward(const float* q, const float* k, const float* v, cons
  * longer gradient needs no copy); grad_xq [B][Lq][E] and grad_xk [B][Lk][E] are written dense — grad_xq == NULL: the
  * queries are the LAST Lq key rows (the episode blocks' cut query, seq_layers.py:600-610) and their input gradient is added
  * to those rows of grad_xk inside the launch; the parameter
- * gradients, packed Wq | bq | Wk | bk | Wv | bv (| Wo | bo) (3 or 4 times E*E+E floats), are written or (accumulate != 0) added to
- * grad_params after a fixed-order reduction over workgroups; workspace of asac_attention_proj_workspace floats. */
+ * gradients, packed Wq | bq | Wk | bk | Wv | bv (| Wo | bo) (3 or 4 times E*E+E floats), are written or (accumulate == 1) added to
+ * grad_params after a fixed-order reduction over workgroups; accumulate == ASAC_ATTN_SUM_DEFER (2): the reduction is left to
+ * asac_sum_partials_multi (the partials stay in the workspace); workspace of asac_attention_proj_workspace floats. */
 int64_t asac_attention_proj_workspace(int B, int Lq, int Lk, int E);
 int asac_attention_proj_forward(const float* xq, int64_t xq_stride_b, int64_t xq_stride_r, const float* xk,
                                 int64_t xk_stride_b, int64_t xk_stride_r, const float* const* params_host,
@@ -1296,6 +1297,32 @@ int asac_rows_wide_backward_input(const float* grad_y, const float* pre, int act
                                   float* dpre_out, float* dx, int64_t dx_row_stride, void* stream);
 int asac_rows_wide_backward_params(const float* dpre, const float* x, int64_t x_row_stride, int64_t R, int K, int N, float* dw,
                                    float* db, int accumulate, float* workspace, void* stream);
+
+/* ---- several fixed-order partial sums as one launch (csrc/reduce.hip) ---------------------------------------------------
+ * The second launch of a backward — the per-workgroup parameter-gradient partials added in workgroup order — for up to
+ * ASAC_SUM_PARTIALS_MAX_JOBS backwards at once: the walks of the representation's graph, one per gated loss, of
+ * `calculate_adaptive_weights` (reference sac_base.py:1607-1631, entered from `_train_rpm` 1798-1839) read none of their
+ * parameter gradients before all walks are done.  A job: out[i] (+)= sum over slabs t of partial[t * slab_stride + i], i < n,
+ * in the order of the launch it replaces — slices = 16: sixteen contiguous slices of the slabs, each summed in order, then
+ * the slice sums in order (asac_mlp_backward with >= 64 tiles, asac_attention_proj_backward); slices = 1: slab order
+ * (asac_mlp_backward with fewer tiles).  The partials are what those entry points leave in their workspace under
+ * ASAC_MLP_REDUCE_DEFER / accumulate == ASAC_ATTN_SUM_DEFER:
+ *   asac_mlp_backward             [tiles = asac_mlp_backward_tiles(N, E)][E][member_stride], n = asac_mlp_param_extent(desc)
+ *   asac_attention_proj_backward  [blocks][n], n = (3 | 4) (E E + E), blocks = asac_attention_proj_workspace / (4 (E E + E))
+ *   asac_conv2_backward(_windows / _multi)  (accumulate == ASAC_CONV_SUM_DEFER)  [blocks][n], n = n_cot x the packed parameter
+ *                                 count, blocks = asac_conv2_backward_workspace / parameter count; 16 slices
+ * jobs_host: a HOST array. */
+#define ASAC_SUM_PARTIALS_MAX_JOBS 16
+#define ASAC_ATTN_SUM_DEFER 2
+#define ASAC_CONV_SUM_DEFER 2
+typedef struct {
+    const float* partial;
+    float* out;
+    int64_t slab_stride;
+    int64_t n;
+    int32_t slabs, slices, accumulate, pad_;
+} asac_partial_sum_t;
+int asac_sum_partials_multi(int n_jobs, const asac_partial_sum_t* jobs_host, void* stream);
 
 #ifdef __cplusplus
 }

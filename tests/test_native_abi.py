@@ -57,7 +57,7 @@ def test_struct_layouts_match_header_sizes():
     mirrors = {'asac_gather_key_t': native.GatherKey, 'asac_row_move_t': native.RowMove, 'asac_sidecar_t': native.Sidecar,
                'asac_squash_job_t': native.SquashJob, 'asac_vtrace_args_t': native.VtraceArgs,
                'asac_mlp_desc_t': native.MlpDesc, 'asac_mlp_job_t': native.MlpJob, 'asac_pi_q_job_t': native.PiQJob, 'asac_mlp_sample_epilogue_t': native.SampleEpilogue,
-               'asac_gru_desc_t': native.GruDesc, 'asac_conv2_desc_t': native.Conv2Desc}
+               'asac_gru_desc_t': native.GruDesc, 'asac_conv2_desc_t': native.Conv2Desc, 'asac_partial_sum_t': native.PartialSum}
     for name, mirror in mirrors.items():
         assert lib.asac_struct_size(name.encode()) == ctypes.sizeof(mirror), name
     assert lib.asac_struct_size(b'no_such_struct') == -1
