@@ -402,7 +402,14 @@ class _MlpSelectFn(torch.autograd.Function):
             pg = [None] * ctx.n_params
         g_base = None
         if g0 is not None:
-            g_base = torch.zeros_like(base)
+            # (a window gradient that is zero outside position t: the zeros are kept between calls — only the slice is written,
+            # no fill launch; the buffer is never handed out exclusively, so autograd does not accumulate into it in place)
+            key = (tuple(base.shape), t % base.shape[1], base.device)
+            g_base = mlp._window_grads.get(key)
+            if g_base is None:
+                if len(mlp._window_grads) > 4:
+                    mlp._window_grads.clear()
+                g_base = mlp._window_grads[key] = torch.zeros_like(base)
             torch.sum(g0, dim=0, out=g_base[:, t])
         if g1 is not None and x1.dim() == 2:
             g1 = g1.sum(0) if mlp.E > 1 else g1[0]
@@ -417,6 +424,7 @@ class StockMLP:
         """`param_tensors`: the networks' `nn.Parameter`s (views of `flat`, member by member) — the autograd inputs
         of the differentiable calls; may stay empty for inference-only instances"""
         self.desc, self.E, self.member_stride = desc, E, member_stride
+        self._window_grads = {}     # (_MlpSelectFn.backward)
         self.wide = desc.in0 + desc.in1 > MAX_WIDTH      # first layer wider than 64 inputs: single-network launches only
         self.param_tensors = list(param_tensors)
         self.params = flat[start:start + E * member_stride]
