@@ -67,6 +67,14 @@ struct ConvDims {
     int tiles, nbx, bh, bw;
     int FH, FW, FHW, FCHW, FH2, FW2, FM2;       // the real frame, its plane / frame strides, its second-layer map
     int crop4, cw4;                             // float4s of a crop, of a crop row
+    // FORWARD only, block-row mode (conv_block_rows): the unit of work is a whole ROW of blocks — one crop of full-width
+    // frame rows (contiguous in memory), layer 1 once over the union of the blocks' first-layer regions (H1 x the frame's
+    // whole first-layer width: C, H, W, W1, M1, rows1, RT1 above describe that union, tiles = block rows per frame,
+    // nbx = 1), then layer 2 and the epilogue block by block (`sub` blocks of width bw; M2, H2, W2 stay the block's).
+    // sub == 1: one block per unit.  The first-layer pre-activations are then saved per UNIT (slab (frame tiles + block row)
+    // of H1 x zW1 positions); the backward, which stays block by block, picks its block's columns out of the slab
+    // (zW1 != 0 in ITS dims says so: the union's first-layer width).
+    int sub, zW1;
 };
 
 struct ConvArgs {
@@ -99,19 +107,19 @@ __device__ __forceinline__ const float* group_frames(const ConvArgs& a, int64_t 
 // the block that a neighbour already produced (tiled mode; otherwise frame g * G, origin (0, 0), nothing skipped)
 struct TileAt {
     int64_t frame;
-    int r0, c0, skip_y, skip_x;
+    int r0, c0, skip_y, skip_x, by;             // (by: the block's row of blocks)
 };
 template <bool TILED>
 __device__ __forceinline__ TileAt tile_at(const ConvDims& d, int64_t g) {
     TileAt t;
     if (!TILED) {
-        t.frame = g * d.G, t.r0 = t.c0 = t.skip_y = t.skip_x = 0;
+        t.frame = g * d.G, t.r0 = t.c0 = t.skip_y = t.skip_x = t.by = 0;
         return t;
     }
     t.frame = g / d.tiles;
     const int tile = (int)(g - t.frame * d.tiles), by = tile / d.nbx, bx = tile - by * d.nbx;
     t.r0 = min(by * d.bh, d.FH2 - d.bh), t.c0 = min(bx * d.bw, d.FW2 - d.bw);
-    t.skip_y = by * d.bh - t.r0, t.skip_x = bx * d.bw - t.c0;
+    t.skip_y = by * d.bh - t.r0, t.skip_x = bx * d.bw - t.c0, t.by = by;
     return t;
 }
 
@@ -194,13 +202,18 @@ __device__ __forceinline__ void settle(int& v) { asm volatile("" : "+v"(v)); }
 // tiled mode: float4 i of a crop [C][H][W] sits `off` floats behind the crop's first pixel in the frame.  A thread moves the
 // same float4s of every crop (piece j of wave w: i = (w + 4 j) 64 + lane), so its offsets live in registers: a table in LDS
 // cost the backward its second workgroup per CU (87 KB with it)
-constexpr int kCropPieces = 8;                                  // per wave: crops up to 4 x 8 KiB (conv_dims checks)
+constexpr int kCropPieces = 8;                                  // per wave: a block's crop up to 4 x 8 KiB (conv_dims checks)
+constexpr int kConvZPieces = 2;                                 // per wave: a block's z1 rows up to 4 x 2 KiB (conv_block_rows checks)
+constexpr int kCropPiecesRow = 10;                              // ... the forward's crop of a row of blocks up to 4 x 10 KiB
 constexpr int kCropMaxFloats = kCropPieces * (kConvThreads / 64) * 256;
-struct CropOffsets { int off[kCropPieces]; };
-__device__ __forceinline__ CropOffsets crop_offsets(const ConvDims& d, int wave, int lane) {
-    CropOffsets t;
+constexpr int kCropMaxFloatsRow = kCropPiecesRow * (kConvThreads / 64) * 256;
+template <int P>
+struct CropOffsets { int off[P]; };
+template <int P>
+__device__ __forceinline__ CropOffsets<P> crop_offsets(const ConvDims& d, int wave, int lane) {
+    CropOffsets<P> t;
 #pragma unroll
-    for (int j = 0; j < kCropPieces; ++j) {
+    for (int j = 0; j < P; ++j) {
         const int i = min((wave + (kConvThreads / 64) * j) * 64 + lane, max(d.crop4 - 1, 0));
         const int hw4 = max(d.H * d.cw4, 1), cw4 = max(d.cw4, 1);
         const int c = i / hw4, rem = i - c * hw4, y = rem / cw4, x4 = rem - y * cw4;
@@ -212,17 +225,17 @@ __device__ __forceinline__ CropOffsets crop_offsets(const ConvDims& d, int wave,
 
 // frames of group g -> LDS through the DMA path; frames beyond the batch re-read the last real one (their results
 // are never stored and their gradients are zero)
-template <bool TILED = false>
+template <bool TILED = false, int P = kCropPieces>
 __device__ __forceinline__ void async_frames(const ConvArgs& a, int64_t g, float* img, int wave, int lane,
-                                             const CropOffsets* crop = nullptr) {
+                                             const CropOffsets<P>* crop = nullptr, const TileAt* at = nullptr) {
     const ConvDims& d = a.d;
     if (TILED) {
         // the crop of frame g / tiles that block g % tiles needs: a lane's 16 bytes come from wherever its offsets say
-        const TileAt t = tile_at<true>(d, g);
+        const TileAt t = at ? *at : tile_at<true>(d, g);
         const float* src = group_frames(a, t.frame) + (int64_t)(t.r0 * d.s2 * d.s1) * d.FW + t.c0 * d.s2 * d.s1;
         const int chunks = (d.CHW + 255) >> 8;
 #pragma unroll
-        for (int j = 0; j < kCropPieces; ++j) {
+        for (int j = 0; j < P; ++j) {
             const int c = wave + (kConvThreads / 64) * j;
             if (c < chunks)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + crop->off[j]),
@@ -396,11 +409,12 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     int* ktq = reinterpret_cast<int*>(lds + p.ktq);
     float* w1q = lds + p.w1q;
     float* red = lds + p.red;
+    const int n_sub = TILED ? d.sub : 1;                       // (block-row mode: the blocks of a row share crop and layer 1)
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    CropOffsets crop_r{};
-    if (TILED) crop_r = crop_offsets(d, wave, lane);
-    const CropOffsets* crop = &crop_r;
+    CropOffsets<kCropPiecesRow> crop_r{};
+    if (TILED) crop_r = crop_offsets<kCropPiecesRow>(d, wave, lane);
+    const CropOffsets<kCropPiecesRow>* crop = &crop_r;
     const int rows_pad = d.RT1 * 16;
     // biases are requested first: their latency hides under the table builds instead of in front of the first DMA
     const float b1v = lr < d.O1 ? a.b1[lr] : 0.f;
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     int4 ko_r[QR];
     float4 w_r[QR];
     if (direct) {
-        if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, crop);
+        if (dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED, kCropPiecesRow>(a, blockIdx.x, img, wave, lane, crop);
         const auto* w2p = as_global(reinterpret_cast<const f32x4*>(a.w2 + (int64_t)min(oc2, d.O2 - 1) * d.K2));
 #pragma unroll
         for (int j = 0; j < S2H / 4; ++j) {
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
     // frames travel by LDS-DMA when they are 16-byte granular: the next group's are requested as soon as layer 1 has
     // consumed this group's, and land while layer 2 and the epilogues run
     // (tiled mode: the host has checked the 16-byte granularity the crops need)
-    if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED>(a, blockIdx.x, img, wave, lane, crop);
+    if (!direct && dma && (int64_t)blockIdx.x < a.n_groups) async_frames<TILED, kCropPiecesRow>(a, blockIdx.x, img, wave, lane, crop);
     CONV_STAMP_INIT;
     for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
         CONV_STAMP(9);
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         // (a crop's six requests per wave take ~1 700 clocks to issue — the CU's 64 B / clock address path shared with the
         // other workgroup's, whose MFMAs run meanwhile; spreading them over the loop's later phases only moved the stall:
         // 103 -> 108 us at 1 024 frames of 84 x 84, round 6)
-        if (dma && g + gridDim.x < a.n_groups) async_frames<TILED>(a, g + gridDim.x, img, wave, lane, crop);
+        if (dma && g + gridDim.x < a.n_groups) async_frames<TILED, kCropPiecesRow>(a, g + gridDim.x, img, wave, lane, crop);
         CONV_STAMP(5);
         for (int u = 0; u < rem; ++u) {
             const float* ru = red + u * 4 * 256;
@@ -610,37 +624,43 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
         CONV_STAMP(2);
 
         // ---- layer 2: 16 positions (G frames x M2), wave = (column tile, k half) ---------------------------
-        {
-            const float* base = a1 + base2;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            float av[S2H];
+        // (block-row mode: once per block of the row, on the shared activations: the block's first column moves the window)
+        for (int sb = 0; sb < n_sub; ++sb) {
+            const int sb_c0 = TILED && n_sub > 1 ? min(sb * d.bw, d.FW2 - d.bw) : 0;      // the block's first output column
+            {
+                const float* base = a1 + base2 + sb_c0 * d.s2;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                float av[S2H];
 #pragma unroll
-            for (int s = 0; s < S2H; ++s) av[s] = base[koff2[4 * (kh * S2H + s) + lk]];
+                for (int s = 0; s < S2H; ++s) av[s] = base[koff2[4 * (kh * S2H + s) + lk]];
 #pragma unroll
-            for (int s = 0; s < S2H; s += 2) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w2r[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s + 1], w2r[s + 1], acc1, 0, 0, 0);
+                for (int s = 0; s < S2H; s += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], w2r[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s + 1], w2r[s + 1], acc1, 0, 0, 0);
+                }
+                const f32x4 acc = acc0 + acc1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * lk + r) * 16 + lr] = acc[r];
             }
-            const f32x4 acc = acc0 + acc1;
+            CONV_STAMP(8);
+            lds_barrier();
+            CONV_STAMP(3);
+            const int at_c0 = TILED && n_sub > 1 ? sb_c0 : at.c0;
+            const int at_skip_x = TILED && n_sub > 1 ? sb * d.bw - sb_c0 : at.skip_x;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave * 256 + (4 * lk + r) * 16 + lr] = acc[r];
-        }
-        CONV_STAMP(8);
-        lds_barrier();
-        CONV_STAMP(3);
-
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
-            const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
-            if (e_out[q] >= 0 && e_im[q] < n_img && (!TILED || (e_py[q] >= at.skip_y && e_px[q] >= at.skip_x))) {
-                const int i = row * 16 + (oc & 15);
-                const float z = (red[(2 * c2) * 256 + i] + red[(2 * c2 + 1) * 256 + i]) + e_bias[q];
-                const int64_t o = TILED ? (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] +
-                                              (at.r0 + e_py[q]) * d.FW2 + at.c0 + e_px[q]
-                                        : (g * d.G + e_im[q]) * (d.O2 * d.M2) + e_out[q];
-                a.y[o] = gelu_f(z);
-                if (a.z2) a.z2[o] = z;
+            for (int q = 0; q < 2; ++q) {                       // (position row, output channel) = e / 32, e % 32
+                const int e = threadIdx.x + q * kConvThreads, row = e >> 5, oc = e & 31, c2 = oc >> 4;
+                if (e_out[q] >= 0 && e_im[q] < n_img && (!TILED || (e_py[q] >= at.skip_y && e_px[q] >= at_skip_x))) {
+                    const int i = row * 16 + (oc & 15);
+                    const float z = (red[(2 * c2) * 256 + i] + red[(2 * c2 + 1) * 256 + i]) + e_bias[q];
+                    const int64_t o = TILED ? (at.frame + e_im[q]) * ((int64_t)d.O2 * d.FM2) + e_out[q] +
+                                                  (at.r0 + e_py[q]) * d.FW2 + at_c0 + e_px[q]
+                                            : (g * d.G + e_im[q]) * (d.O2 * d.M2) + e_out[q];
+                    a.y[o] = gelu_f(z);
+                    if (a.z2) a.z2[o] = z;
+                }
             }
+            if (sb + 1 < n_sub) lds_barrier();                 // (the slabs are read: the next block's sums may land)
         }
         // (the next iteration's first barrier orders these reads before the slabs / activations are rewritten)
         CONV_STAMP(4);
@@ -725,9 +745,9 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     float* red = lds + p.red;
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    CropOffsets crop_r{};
-    if (TILED) crop_r = crop_offsets(d, wave, lane);
-    const CropOffsets* crop = &crop_r;
+    CropOffsets<kCropPieces> crop_r{};
+    if (TILED) crop_r = crop_offsets<kCropPieces>(d, wave, lane);
+    const CropOffsets<kCropPieces>* crop = &crop_r;
     const int rows_pad = d.RT1 * 16;
     const int NT1 = d.K1 / 16, NT2 = d.K2 / 16;
 
@@ -812,17 +832,45 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     const bool dma = TILED ||
                      ((d.CHW & 3) == 0 && ((d.M1 * d.O1 * d.G) & 3) == 0 && (a.x_sample_stride & 3) == 0 &&
                       ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.z1)) & 15) == 0);
+    // (tiled, the forward saved z1 per ROW of blocks, H1 x zW1 positions (ConvDims::zW1): this block's columns are picked out
+    // of the slab, 16 bytes per lane, into the dense [rows1][O1] form the first phase reads — where a lane's pieces sit inside
+    // a slab does not depend on the block: kConvZPieces offsets in registers)
+    constexpr int kZPieces = kConvZPieces;
+    int zoff[kZPieces];
+    const int z_chunks = (d.rows1 * d.O1 + 255) >> 8;
+    if (TILED && d.zW1) {
+        const int per = d.O1 >> 2, n4 = d.rows1 * per;
+#pragma unroll
+        for (int j = 0; j < kZPieces; ++j) {
+            const int i4 = min((wave + (kConvThreads / 64) * j) * 64 + lane, n4 - 1);
+            const int pos = i4 / per, part = i4 - pos * per, y = pos / d.W1, xl = pos - y * d.W1;
+            zoff[j] = (y * d.zW1 + xl) * d.O1 + 4 * part;
+            settle(zoff[j]);
+        }
+    }
+    const int z_slab = d.H1 * d.zW1 * d.O1, z_nby = TILED && d.zW1 ? d.tiles / d.nbx : 1;
+    // the next group's frames (and raw z1 rows: the current ones are consumed) by LDS-DMA
     auto request = [&](int64_t g, int buf) {
         if (TILED) {
-            async_frames<true>(a, g, lds + p.img + buf * p.img_size, wave, lane, crop);
-            return;
+            const TileAt t = tile_at<true>(d, g);
+            async_frames<true>(a, g, lds + p.img + buf * p.img_size, wave, lane, crop, &t);
+            if (d.zW1) {
+                const float* src = a.z1 + (t.frame * z_nby + t.by) * (int64_t)z_slab + t.c0 * d.s2 * d.O1;
+#pragma unroll
+                for (int j = 0; j < kZPieces; ++j) {
+                    const int c = wave + (kConvThreads / 64) * j;
+                    if (c < z_chunks)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + zoff[j]),
+                                                         (__attribute__((address_space(3))) void*)(zraw + c * 256), 16, 0, 0);
+                }
+                return;
+            }
+        } else {
+            const int64_t first = g * d.G;
+            const int n_img = (int)min((int64_t)d.G, a.N - first);
+            async_copy_kib(group_frames(a, g), lds + p.img + buf * p.img_size, (n_img * d.CHW) >> 2, p.img_size >> 8, wave,
+                           lane);
         }
-        const int64_t first = g * d.G;
-        const int n_img = (int)min((int64_t)d.G, a.N - first);
-        async_copy_kib(group_frames(a, g), lds + p.img + buf * p.img_size, (n_img * d.CHW) >> 2, p.img_size >> 8, wave,
-                       lane);
-    };
-    auto request_z = [&](int64_t g) {
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
         async_copy_kib(a.z1 + first * d.M1 * d.O1, zraw, (n_img * d.M1 * d.O1) >> 2, (d.rows1 * d.O1 + 255) >> 8, wave,
@@ -854,7 +902,6 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     if ((int64_t)blockIdx.x < a.n_groups) {
         if (dma) {
             request(blockIdx.x, 0);
-            request_z(blockIdx.x);
         }
         fetch_out(blockIdx.x);
     }
@@ -933,8 +980,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         CONV_STAMP(1);
         if (more) {
             if (dma) {
-                request(g + gridDim.x, buf ^ 1);
-                request_z(g + gridDim.x);               // the raw rows are consumed
+                request(g + gridDim.x, buf ^ 1);        // (the raw rows are consumed)
             }
             fetch_out(g + gridDim.x);
         }
@@ -1215,6 +1261,7 @@ __global__ __launch_bounds__(64 * kSumSlices) void k_conv_sum_partials(const flo
 
 constexpr size_t kConvLdsLimit = 160 * 1024;
 
+static bool conv_block_rows(const ConvDims& d, ConvDims& u);
 static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
     if (c.channels < 1 || c.height < 1 || c.width < 1 || c.out1 < 1 || c.out2 < 1 || c.kernel1 < 1 || c.kernel2 < 1 ||
         c.stride1 < 1 || c.stride2 < 1)
@@ -1231,6 +1278,7 @@ static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
     d.tiles = 1, d.nbx = 1, d.bh = d.H2, d.bw = d.W2;
     d.FH = d.H, d.FW = d.W, d.FHW = d.H * d.W, d.FCHW = d.CHW, d.FH2 = d.H2, d.FW2 = d.W2, d.FM2 = d.M2;
     d.crop4 = 0, d.cw4 = 0;
+    d.sub = 1, d.zW1 = 0;
     auto fits = [&]() {
         return (size_t)conv_fwd_plan(d).total * sizeof(float) <= kConvLdsLimit &&
                (size_t)conv_bwd_plan(d).total * sizeof(float) <= kConvLdsLimit;
@@ -1269,7 +1317,27 @@ static bool conv_dims(const asac_conv2_desc_t& c, ConvDims& d) {
         }
     if (best < 0) return false;
     d = pick;
+    d.sub = 1, d.zW1 = 0;
+    ConvDims rows;
+    if (conv_block_rows(d, rows)) d.zW1 = rows.W1;       // (the forward works by block rows: z1 is saved per row of blocks)
     return true;
+}
+
+// The forward's block-row form of a tiled geometry (ConvDims::sub): the blocks of one block row as ONE unit of work — their
+// crops are the same frame rows (full width: contiguous, 1.25x instead of 1.6x the frame's bytes at 84 x 84) and their
+// first-layer regions overlap (8 x 20 positions once instead of two times 8 x 12).  Taken when there are at least two
+// blocks a row and the unit still fits two workgroups per CU; false: the caller keeps one block per unit.
+static bool conv_block_rows(const ConvDims& d, ConvDims& u) {
+    if (d.tiles <= 1 || d.nbx < 2 || (d.O1 & 3)) return false;       // (O1 % 4: the backward picks 16-byte pieces of a position)
+    u = d;
+    u.W = d.FW, u.CHW = d.C * d.H * d.FW;
+    u.W1 = (d.FW - d.k1) / d.s1 + 1, u.M1 = d.H1 * u.W1;
+    u.rows1 = u.M1, u.RT1 = (u.rows1 + 15) / 16;
+    u.crop4 = u.CHW / 4, u.cw4 = u.W / 4;
+    u.sub = d.nbx, u.zW1 = u.W1;
+    u.tiles = d.tiles / d.nbx, u.nbx = 1;
+    if ((u.W & 3) || u.CHW > kCropMaxFloatsRow || d.rows1 * d.O1 > kConvZPieces * (kConvThreads / 64) * 256) return false;
+    return (size_t)conv_fwd_plan(u).total * sizeof(float) <= 80 * 1024;
 }
 
 static int conv_lds_limit(const void* fn, bool& done, const char* where) {
@@ -1315,6 +1383,7 @@ int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc, int64_t N) 
 int64_t asac_conv2_z1_floats(const asac_conv2_desc_t* desc, int64_t N) {
     ConvDims d;
     if (!desc || !conv_dims(*desc, d) || N <= 0) return -1;
+    if (d.zW1) return N * (d.tiles / d.nbx) * d.H1 * d.zW1 * d.O1;      // (one slab per row of blocks: see ConvDims::sub)
     return N * d.tiles * d.M1 * d.O1;
 }
 
@@ -1345,6 +1414,11 @@ int asac_conv2_forward_windows(const asac_conv2_desc_t* desc, const float* x, in
         return bad_arg("asac_conv2_forward: tiled frames need 16-byte aligned rows");
     a.x = x; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.y = y; a.z1 = z1_out; a.z2 = z2_out;
+    if (a.d.zW1) {                                           // (tiled: a row of blocks per unit where that fits)
+        ConvDims rows;
+        conv_block_rows(a.d, rows);
+        a.d = rows;
+    }
     a.N = N * a.d.tiles;                                     // (tiled: virtual frames, one group each)
     a.n_groups = (a.N + a.d.G - 1) / a.d.G;
     const size_t lds = (size_t)conv_fwd_plan(a.d).total * sizeof(float);

@@ -834,7 +834,8 @@ int asac_conv2_supported(const asac_conv2_desc_t* desc_host);
 /* Frames whose second-layer map has more than 16 positions (the 84 x 84 frames of the reference's environments:
  * ConvLayers(84, 84, C, 'simple'), 20 x 20 -> 9 x 9, envs/roller/nn_visual_hard_attn.py) run TILED: asac_conv2_tiles(desc)
  * blocks of <= 16 positions per frame, each formed from the crop of the frame it needs (csrc/conv.hip).  Same results;
- * z1_out then holds asac_conv2_z1_floats(desc, N) floats (the crops' first-layer pre-activations, not the frame's map). */
+ * z1_out then holds asac_conv2_z1_floats(desc, N) floats (the crops' first-layer pre-activations, not the frame's map:
+ * per block, or — where the forward works by rows of blocks — per row of blocks; an opaque buffer between the two passes). */
 int asac_conv2_tiles(const asac_conv2_desc_t* desc_host);
 int64_t asac_conv2_z1_floats(const asac_conv2_desc_t* desc_host, int64_t N);
 int64_t asac_conv2_param_count(const asac_conv2_desc_t* desc_host);
