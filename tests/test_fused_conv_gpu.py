@@ -34,6 +34,7 @@ def _stack(C, o1, k1, s1, o2, k2, s2, seed=0):
     (23, 4, 30, 30, 16, 8, 4, 32, 4, 2, 1),     # four input channels: K1 = 256, sixteen quads of operand constants in registers
     (9, 4, 44, 44, 16, 8, 4, 32, 4, 2, 1),      # ... 10x10 -> 4x4 = 16 positions: one frame per group
     (9, 4, 52, 52, 16, 8, 4, 32, 4, 2, -1),     # ... 12x12 -> 5x5: tiled
+    (9, 4, 84, 84, 16, 8, 4, 32, 4, 2, -1),     # four channels at 84 x 84: a row of blocks' crop exceeds the DMA pieces -> block by block
     (25, 3, 30, 30, 16, 8, 4, 32, 3, 1, 1),     # 3 x 3 second layer, stride 1: 9 col2im contributions a position, K2 = 144
     (17, 3, 32, 32, 16, 4, 4, 32, 2, 2, 1),     # 2 x 2 second layer, stride 2: patches do not overlap (one contribution)
 ])
