@@ -146,3 +146,21 @@ def test_direct_mode_backward_with_deferred_sums_adds_the_same_gradients():
     assert torch.equal(mid, start), 'a deferred backward wrote parameter gradients before the flush'
     assert torch.equal(group.grad, want)
     assert prof.summary()['asac_sum_partials_multi']['calls'] == 1
+
+
+def test_a_stack_used_twice_in_one_walk_gets_both_contributions():
+    """a parameter two recorded nodes of one walk share: `flush()` hands back the sum autograd would have formed"""
+    import asac_amd  # noqa: F401
+    from algorithm.fused_mlp import DeferredPartialSums
+    dense, _ = _dense(40, [64], 8)
+    x1, x2 = torch.randn(300, 40, device='cuda'), torch.randn(300, 40, device='cuda')
+    y = dense(x1) + 2.0 * dense(x2)
+    gy = torch.randn_like(y)
+    params = list(dense.parameters())
+    want = torch.autograd.grad(y, params, grad_outputs=gy, retain_graph=True)
+    with DeferredPartialSums() as later:
+        got = torch.autograd.grad(y, params, grad_outputs=gy, retain_graph=True, allow_unused=True)
+    assert all(g is None for g in got)
+    late = later.flush()[0]
+    for p, w in zip(params, want):
+        np.testing.assert_allclose(late[id(p)].cpu().numpy(), w.cpu().numpy(), rtol=1e-6, atol=1e-7)
