@@ -90,8 +90,8 @@ class DeferredConvBackward:
                 part = walks[lo:lo + most]
                 n = native.conv2_param_count(desc)
                 g = torch.empty(len(part), n, dtype=x.dtype, device=x.device)
-                slabs = native.conv2_backward_workspace(desc, n_frames) // n
-                ws = torch.empty(len(part) * slabs * n, dtype=x.dtype, device=x.device)
+                slabs = native.conv2_backward_slabs(desc, n_frames, len(part))
+                ws = torch.empty(len(part) * native.conv2_backward_workspace(desc, n_frames), dtype=x.dtype, device=x.device)
                 native.conv2_backward_multi(desc, x, w2.detach().contiguous(), z1, z2, [by_walk[k] for k in part], g, ws,
                                             native.SUM_DEFER if later is not None else False)
                 if later is not None:
@@ -171,7 +171,7 @@ class _ConvStackFn(torch.autograd.Function):
             run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), flat, ws,
                 native.SUM_DEFER if later is not None else True)
             if later is not None:
-                later.add(ws, ws.numel() // n, 16, n, n, flat, accumulate=True)
+                later.add(ws, native.conv2_backward_slabs(desc, n_frames), 16, n, n, flat, accumulate=True)
             return (None, None, None, None, None, None, None, None)
         g = torch.empty(n, dtype=x.dtype, device=x.device)
         run(desc, x, w2.detach().contiguous(), z1, z2, grad_y.contiguous(), g, ws,
@@ -182,7 +182,7 @@ class _ConvStackFn(torch.autograd.Function):
             grads.append(g[off:off + k].view(p.shape) if p.requires_grad else None)
             off += k
         if later is not None:           # (the gradients reach the caller through `later.flush()`)
-            later.add(ws, ws.numel() // n, 16, n, n, g)
+            later.add(ws, native.conv2_backward_slabs(desc, n_frames), 16, n, n, g)
             later.record(params, grads)
             grads = [None] * 4
         return (None, None, *grads, None, None)

@@ -50,7 +50,7 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(
 
 constexpr int kConvThreads = 256;              // 4 waves
 constexpr int kConvMaxK = ASAC_CONV2_MAX_K;     // patch length of either layer (C*k1*k1, O1*k2*k2)
-constexpr int kConvBwdGroupsCap = 256;          // workgroups of the backward (each writes one partial slab)
+constexpr int kConvBwdGroupsCap = 256;          // workgroups of the backward per resident workgroup of a CU (each writes one partial slab)
 
 struct ConvDims {
     int C, H, W, CHW;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_fwd(const ConvArgs a) {
 //      offsets of the lane's gradient columns, the W2 elements of its column tiles) live in registers; 128 KB for 30 x 30
 //      frames (one workgroup per CU), 79 KB for the crops of 84 x 84 frames (two)
 // ------------------------------------------------------------------------------------------------
-struct ConvBwdPlan { int img, img_size, zraw, g1, a1, dp_pitch, dz1x, dz1_size, dz2, rowoff1, rowa, cont, n_cont, ktab, red, total; };
+struct ConvBwdPlan { int img, img_size, bufs, zraw, g1, a1, dp_pitch, dz1x, dz1_size, dz2, rowoff1, rowa, cont, n_cont, ktab, red, total; };
 // positions of the second layer's map that one first-layer position feeds, per axis: ceil(k2 / s2)
 __host__ __device__ inline int conv_reach(const ConvDims& d) { return (d.k2 + d.s2 - 1) / d.s2; }
 // nc cotangents (k_conv2_bwd<., NC>): one dz2 buffer each; dz1 = col2im(dz2 W2) * gelu'(z1) is formed position-major
@@ -685,15 +685,18 @@ __host__ __device__ inline int conv_reach(const ConvDims& d) { return (d.k2 + d.
 // rows 4 apart 16 banks apart: the gather's reads — a channel per lane — and, for 4 x 4 patches, the fragments' stores at
 // the minimum of two lanes per bank) in the place of a1, which is dead by then; the setup's patch-offset table lives
 // there too.
-__host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc = 1) {
+__host__ __device__ inline ConvBwdPlan conv_bwd_layout(const ConvDims& d, int nc, int bufs) {
     ConvBwdPlan p;
     int off = 0;
     auto take = [&](int n) { const int o = off; off += (n + 3) & ~3; return o; };
     const int rows_pad = d.RT1 * 16;
+    p.bufs = bufs;
     p.img_size = (d.G * d.CHW + 255) & ~255;     // whole KiB pieces (LDS-DMA); two buffers: the next group's frames
-    p.img = take(2 * p.img_size);                // travel while this group computes
-    p.zraw = take((d.rows1 * d.O1 + 255) & ~255);   // the group's saved z1 rows as they sit in HBM (LDS-DMA target)
+    p.img = take(bufs * p.img_size);             // travel while this group computes
     p.g1 = take(rows_pad * 16);                  // gelu'(z1), then dz1 of cotangent 0: [position row][16 channels]
+    // the group's saved z1 rows as they sit in HBM (LDS-DMA target).  One frame buffer: they land where gelu'(z1) goes
+    // (16 channels: the same [row][16] layout, every thread of the first phase rewrites the element it read)
+    p.zraw = bufs == 1 ? p.g1 : take((d.rows1 * d.O1 + 255) & ~255);
     p.dp_pitch = 17 * d.k2 * d.k2;
     p.dp_pitch += (12 - (p.dp_pitch & 7)) & 7;   // = 4 mod 8
     int shared = d.G * d.O1 * d.M1;              // a1 | the product tile | the setup's patch offsets
@@ -711,6 +714,22 @@ __host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc =
     p.red = take(kConvThreads);
     p.total = off;
     return p;
+}
+// Two frame buffers (the next group's frames and z1 rows travel while this group computes) — unless ONE buffer, with the raw
+// z1 rows landing in gelu'(z1)'s place, is what lets a second workgroup share the CU (80 KB each): whole 30 x 30 frames in
+// groups of four are 128 KB with two buffers and 78 KB with one; the other workgroup's arithmetic then covers a group's
+// transfers, and every phase's LDS / MFMA latencies besides (the launch is latency-bound: 19 % of its clocks are MFMAs).
+__host__ __device__ inline ConvBwdPlan conv_bwd_plan(const ConvDims& d, int nc = 1) {
+    const ConvBwdPlan two = conv_bwd_layout(d, nc, 2);
+    if (nc != 1 || d.tiles > 1 || d.O1 != 16 || (size_t)two.total * sizeof(float) <= 80 * 1024) return two;
+    const ConvBwdPlan one = conv_bwd_layout(d, nc, 1);
+    return (size_t)one.total * sizeof(float) <= 80 * 1024 ? one : two;
+}
+
+// workgroups of a backward launch (each writes one partial slab per cotangent): one per CU, two where the launch's LDS
+// leaves room for two
+inline int64_t conv_bwd_cap(const ConvDims& d, int nc = 1) {
+    return kConvBwdGroupsCap * ((size_t)conv_bwd_plan(d, nc).total * sizeof(float) <= 80 * 1024 ? 2 : 1);
 }
 
 // packed parameter gradients: w1 | b1 | w2 | b2
@@ -907,7 +926,8 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
     }
     int buf = 0;
     CONV_STAMP_INIT;
-    for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x, buf ^= 1) {
+    const bool one_buf = p.bufs == 1;         // (the next group's transfers wait for the end of this group: see conv_bwd_plan)
+    for (int64_t g = blockIdx.x; g < a.n_groups; g += gridDim.x, buf = one_buf ? 0 : buf ^ 1) {
         CONV_STAMP(9);
         const int64_t first = g * d.G;
         const int n_img = (int)min((int64_t)d.G, a.N - first);
@@ -980,7 +1000,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
         CONV_STAMP(1);
         if (more) {
             if (dma) {
-                request(g + gridDim.x, buf ^ 1);        // (the raw rows are consumed)
+                if (!one_buf) request(g + gridDim.x, buf ^ 1);        // (the raw rows are consumed)
             }
             fetch_out(g + gridDim.x);
         }
@@ -1181,6 +1201,7 @@ __global__ __launch_bounds__(kConvThreads) void k_conv2_bwd(const ConvArgs a) {
             }
         }
         lds_barrier();             // everything of this group is consumed
+        if (one_buf && dma && more) request(g + gridDim.x, 0);
         CONV_STAMP(6);
     }
     CONV_STAMP_FLUSH;
@@ -1377,7 +1398,7 @@ int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc, int64_t N) 
     ConvDims d;
     if (!desc || !conv_dims(*desc, d) || N <= 0) return -1;
     const int64_t groups = (N * d.tiles + d.G - 1) / d.G;
-    return (groups < kConvBwdGroupsCap ? groups : kConvBwdGroupsCap) * conv_param_count(d);
+    return (groups < conv_bwd_cap(d) ? groups : conv_bwd_cap(d)) * conv_param_count(d);
 }
 
 int64_t asac_conv2_z1_floats(const asac_conv2_desc_t* desc, int64_t N) {
@@ -1475,7 +1496,7 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
     a.n_groups = (a.N + a.d.G - 1) / a.d.G;
     static bool attr = false, attr_t = false;
     const size_t lds = (size_t)conv_bwd_plan(a.d).total * sizeof(float);
-    const unsigned blocks = (unsigned)(a.n_groups < kConvBwdGroupsCap ? a.n_groups : kConvBwdGroupsCap);
+    const unsigned blocks = (unsigned)(a.n_groups < conv_bwd_cap(a.d) ? a.n_groups : conv_bwd_cap(a.d));
     hipStream_t s = as_stream(stream);
     static bool attr3 = false, attr3_t = false;
     const bool kt3 = a.d.K1 / 16 <= 12;            // (three column tiles per wave cover the filter: see k_conv2_bwd)
@@ -1493,6 +1514,15 @@ int asac_conv2_backward_windows(const asac_conv2_desc_t* desc, const float* x, i
         hipLaunchKernelGGL(k_conv_sum_partials, dim3((unsigned)((n + 63) / 64)), dim3(64 * kSumSlices), 0, s, workspace,
                            (int)blocks, n, grad_params, accumulate);
     return finish_launch("asac_conv2_backward");
+}
+
+// partial slabs (= workgroups) a backward launch over N frames with n_cot cotangents leaves in its workspace: what a deferred
+// reduction (asac_sum_partials_multi) sums
+int asac_conv2_backward_slabs(const asac_conv2_desc_t* desc, int64_t N, int n_cot) {
+    ConvDims d;
+    if (!desc || !conv_dims(*desc, d) || N <= 0 || n_cot < 1 || n_cot > asac_conv2_backward_multi_max(desc)) return -1;
+    const int64_t groups = (N * d.tiles + d.G - 1) / d.G, cap = conv_bwd_cap(d, n_cot);
+    return (int)(groups < cap ? groups : cap);
 }
 
 // the largest number of cotangents (1..4) whose buffers fit the LDS beside the double-buffered frames: what ONE launch of
@@ -1553,7 +1583,7 @@ int asac_conv2_backward_multi(const asac_conv2_desc_t* desc, const float* x, int
     a.N = N * a.d.tiles;
     a.n_groups = (a.N + a.d.G - 1) / a.d.G;
     static bool attr[2][2][2] = {};
-    const unsigned blocks = (unsigned)(a.n_groups < kConvBwdGroupsCap ? a.n_groups : kConvBwdGroupsCap);
+    const unsigned blocks = (unsigned)(a.n_groups < conv_bwd_cap(a.d, n_cot) ? a.n_groups : conv_bwd_cap(a.d, n_cot));
     hipStream_t s = as_stream(stream);
     const bool tiled = a.d.tiles > 1, kt3 = a.d.K1 / 16 <= 12;
     auto launch = [&](auto kernel, bool& done) -> int {

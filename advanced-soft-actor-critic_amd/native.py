@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 import os as _os
 
 LIB_PATH = Path(_os.environ.get('ASAC_HIP_LIB', PKG_DIR / 'lib' / 'libasac_hip.so'))   # env override: debugging builds
-ABI_VERSION = 80
+ABI_VERSION = 81
 
 MAX_GATHER_KEYS = 16
 PAD_KEEP, PAD_WORD, PAD_BYTE, PAD_ROW, PAD_EMIT_MASK = 0, 1, 2, 3, 4
@@ -345,6 +345,7 @@ _SIGNATURES = {
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_void_p]),
     'asac_conv2_backward_multi_max': (C.c_int, [C.POINTER(Conv2Desc)]),
+    'asac_conv2_backward_slabs': (C.c_int, [C.POINTER(Conv2Desc), C.c_int64, C.c_int]),
     'asac_conv2_backward_multi': (C.c_int, [C.POINTER(Conv2Desc), C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p]),
@@ -1488,6 +1489,11 @@ def conv2_param_count(desc) -> int:
 def _sum_mode(accumulate) -> int:
     """False / True / SUM_DEFER -> the entry points' `accumulate` argument"""
     return SUM_DEFER if (accumulate is not True and accumulate is not False and accumulate == SUM_DEFER) else int(bool(accumulate))
+
+
+def conv2_backward_slabs(desc, N, n_cot=1) -> int:
+    """partial slabs a backward launch over N frames with n_cot cotangents leaves in its workspace (`SUM_DEFER`)"""
+    return int(load().asac_conv2_backward_slabs(C.byref(desc), N, n_cot))
 
 
 def conv2_backward_workspace(desc, N) -> int:

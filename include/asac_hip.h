@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ASAC_ABI_VERSION 80
+#define ASAC_ABI_VERSION 81
 #define ASAC_MAX_GATHER_KEYS 16
 #define ASAC_MAX_ENSEMBLE 16
 #define ASAC_MAX_ACTION 64
@@ -840,6 +840,9 @@ int asac_conv2_tiles(const asac_conv2_desc_t* desc_host);
 int64_t asac_conv2_z1_floats(const asac_conv2_desc_t* desc_host, int64_t N);
 int64_t asac_conv2_param_count(const asac_conv2_desc_t* desc_host);
 int64_t asac_conv2_backward_workspace(const asac_conv2_desc_t* desc_host, int64_t N);
+/* partial slabs (one per workgroup, n_cot x the packed parameter count floats each) a backward launch over N frames with
+ * n_cot cotangents leaves in its workspace — what asac_sum_partials_multi sums after accumulate == ASAC_CONV_SUM_DEFER */
+int asac_conv2_backward_slabs(const asac_conv2_desc_t* desc_host, int64_t N, int n_cot);
 int asac_conv2_forward(const asac_conv2_desc_t* desc_host, const float* x, int64_t N, const float* w1,
                        const float* b1, const float* w2, const float* b2, float* y, float* z1_out, float* z2_out,
                        void* stream);
@@ -1311,7 +1314,7 @@ int asac_rows_wide_backward_params(const float* dpre, const float* x, int64_t x_
  *   asac_mlp_backward             [tiles = asac_mlp_backward_tiles(N, E)][E][member_stride], n = asac_mlp_param_extent(desc)
  *   asac_attention_proj_backward  [blocks][n], n = (3 | 4) (E E + E), blocks = asac_attention_proj_workspace / (4 (E E + E))
  *   asac_conv2_backward(_windows / _multi)  (accumulate == ASAC_CONV_SUM_DEFER)  [blocks][n], n = n_cot x the packed parameter
- *                                 count, blocks = asac_conv2_backward_workspace / parameter count; 16 slices
+ *                                 count, blocks = asac_conv2_backward_slabs(desc, N, n_cot); 16 slices
  * jobs_host: a HOST array. */
 #define ASAC_SUM_PARTIALS_MAX_JOBS 16
 #define ASAC_ATTN_SUM_DEFER 2

@@ -211,14 +211,27 @@ def test_conv_backward_for_several_cotangents_is_the_single_launches_bit_for_bit
     with native.LaunchProfiler() as prof:
         native.conv2_backward_multi(desc, x, wd[2], z1, z2, gys, got, ws)
     assert list(prof.summary()) == ['asac_conv2_backward_multi']
-    assert torch.equal(got, want) and float(want.abs().sum()) > 0
+    # a workgroup's arithmetic per cotangent is the single launch's; where both forms run the same number of workgroups the
+    # final sums see the same slabs in the same order: bit for bit.  (A single launch that fits two workgroups per CU — one
+    # frame buffer, 30 x 30 — has twice the slabs of the multi form: the same numbers summed in another grouping.)
+    per_launch = min(nc, native.conv2_backward_multi_max(desc))
+    same_slabs = native.conv2_backward_slabs(desc, n_frames, 1) == native.conv2_backward_slabs(desc, n_frames, per_launch)
+
+    def check(a, b):
+        if same_slabs:
+            assert torch.equal(a, b)
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(b.abs().max()))
+    check(got, want)
+    assert float(want.abs().sum()) > 0
     # three cotangents of 30 x 30 frames are ONE kernel launch (the fourth set of LDS buffers does not fit beside the
     # double-buffered frames: 3 + 1)
     if (C, H, W) == (3, 30, 30):
         assert native.conv2_backward_multi_max(desc) == 3
     # accumulate form
+    before = got.clone()
     native.conv2_backward_multi(desc, x, wd[2], z1, z2, gys, got, ws, accumulate=True)
-    assert torch.equal(got, want + want)
+    assert torch.equal(got, before + before)
 
 
 def test_deferred_conv_backward_equals_the_walks_own_launches():
