@@ -225,22 +225,37 @@ constexpr int kProjStage = 768;                 // floats per staged array of th
 //   wL: 4 blocks of [EM*EM weights (out, in) | EM biases]
 template <int EM>
 __device__ __forceinline__ void stage_weights(const AttnProjArgs& a, float* wL) {
-    constexpr int blk = EM * EM + EM;
+    constexpr int blk = EM * EM + EM, total = 4 * blk, IT = (total + kAttnThreads - 1) / kAttnThreads;
     const int E = a.E;
-    for (int i = threadIdx.x; i < 4 * blk; i += kAttnThreads) {
+    // every element's load is issued before the first LDS store (a loop of load -> wait -> store was one global round trip
+    // per 64 elements: five in a row for E <= 8 at the head of every launch of the block, forward and backward): padding
+    // slots load a valid address and are zeroed afterwards
+    float v[IT];
+    bool on[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = min((int)threadIdx.x + k * kAttnThreads, total - 1);
         const int m = i / blk, r = i - m * blk;
         const float* W = m == 0 ? a.wq : (m == 1 ? a.wk : (m == 2 ? a.wv : a.wo));
         const float* bb = m == 0 ? a.bq : (m == 1 ? a.bk : (m == 2 ? a.bv : a.bo));
-        float v = 0.f;
+        const float* src = a.wq;
+        on[k] = false;
         if (W) {
             if (r < EM * EM) {
                 const int o = r / EM, c = r - o * EM;
-                if (o < E && c < E) v = W[o * E + c];
+                if (o < E && c < E) src = W + o * E + c, on[k] = true;
             } else if (r - EM * EM < E) {
-                v = bb[r - EM * EM];
+                src = bb + (r - EM * EM), on[k] = true;
             }
         }
-        wL[i] = v;
+        v[k] = *src;
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) asm volatile("" : "+v"(v[k]));     // (pinned behind the LAST load: no load sinks into a branch)
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = (int)threadIdx.x + k * kAttnThreads;
+        if (i < total) wL[i] = on[k] ? v[k] : 0.f;
     }
 }
 
@@ -310,15 +325,15 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_fwd(const AttnProjAr
     constexpr int blk = EM * EM + EM;
     const int E = a.E;
     const int b0 = blockIdx.x * EPB, nb = min(EPB, a.B - b0);
-    stage_weights<EM>(a, wL);
     const int bl = threadIdx.x / P, r = threadIdx.x - bl * P;
     const bool on = bl < nb;
     const int b = b0 + (on ? bl : 0);
     const bool row_on = on && r < a.Lq;
-    // inputs travel while the weights are being staged
+    // inputs travel while the weights are being staged (requested first: the staging waits for its own loads)
     float xk[EM], xq[EM];
     load_row<EM>(a.xk + (int64_t)b * a.xk_sb + (int64_t)min(r, a.Lk - 1) * a.xk_sr, E, xk);
     load_row<EM>(a.xq + (int64_t)b * a.xq_sb + (int64_t)min(r, a.Lq - 1) * a.xq_sr, E, xq);
+    stage_weights<EM>(a, wL);
     unsigned blocked = 0u;
     if (row_on && a.mask) blocked = mask_bits(a.mask, a.mask_sb, a.mask_si, a.mask_sj, b, r, a.Lk);
     __syncthreads();
@@ -386,6 +401,17 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_fwd(const AttnProjAr
     a.keep[row] = kp;
 }
 
+// phase clocks of workgroup 0 (tools/debug/attn_bwd_phases.py); compiled out of the library
+#ifdef ASAC_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[8];
+#define ATTN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_attn_stamps[k] = __builtin_readcyclecounter(); } while (0)
+extern "C" int asac_debug_attn_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps));
+}
+#else
+#define ATTN_STAMP(k)
+#endif
+
 template <int EM>
 __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjArgs a, int P, int EPB) {
     __shared__ float gs_l[kAttnThreads * kAttnPitch], w_l[kAttnThreads * kAttnPitch];
@@ -397,11 +423,9 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
     const int E = a.E;
     const bool tail = a.g_xq == nullptr;     // the queries ARE the last Lq key rows: one gradient serves both
     const int b0 = blockIdx.x * EPB, nb = min(EPB, a.B - b0);
-    stage_weights<EM>(a, wL);
-    for (int f = threadIdx.x; f < nb * a.Lq * a.Lk; f += kAttnThreads) {
-        const int e = f / (a.Lq * a.Lk), rem = f - e * a.Lq * a.Lk, i = rem / a.Lk, j = rem - i * a.Lk;
-        w_l[(e * P + i) * kAttnPitch + j] = a.w[(int64_t)b0 * a.Lq * a.Lk + f];
-    }
+    ATTN_STAMP(0);
+    // this lane's rows first: their loads travel under the staging of the weights and of the attention weights (issued
+    // behind it each of the three waited for a global round trip of its own)
     const int bl = threadIdx.x / P, r = threadIdx.x - bl * P;
     const bool on = bl < nb;
     const int b = b0 + (on ? bl : 0);
@@ -411,6 +435,16 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
     load_row<EM>(a.xk + (int64_t)b * a.xk_sb + (int64_t)min(r, a.Lk - 1) * a.xk_sr, E, xk);
     load_row<EM>(a.xq + (int64_t)b * a.xq_sb + (int64_t)min(r, a.Lq - 1) * a.xq_sr, E, xq);
     load_row<EM>(a.g_out + (int64_t)b * a.go_sb + (int64_t)min(r, a.Lq - 1) * a.go_sr, E, go);
+    stage_weights<EM>(a, wL);
+    // (the weights' gradient is staged with the weights: read inside phase 1's loop over the keys it was one global round
+    // trip per key in front of every row's chain)
+    for (int f = threadIdx.x; f < nb * a.Lq * a.Lk; f += kAttnThreads) {
+        const int e = f / (a.Lq * a.Lk), rem = f - e * a.Lq * a.Lk, i = rem / a.Lk, j = rem - i * a.Lk;
+        const float wv = a.w[(int64_t)b0 * a.Lq * a.Lk + f];
+        const float gv = a.g_w ? a.g_w[(int64_t)b0 * a.Lq * a.Lk + f] : 0.f;
+        w_l[(e * P + i) * kAttnPitch + j] = wv;
+        gs_l[(e * P + i) * kAttnPitch + j] = gv;
+    }
     float kp = 1.f;
     if (a.wo) {
         load_row<EM>(a.attn_out + row * E, E, o);
@@ -418,6 +452,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         if (a.row_zero && a.row_zero[(int64_t)b * a.rz_sb + (int64_t)min(r, a.Lq - 1) * a.rz_si]) kp = 0.f;
     }
     __syncthreads();
+    ATTN_STAMP(1);
     // recompute the projections of this entry (lane (bl, j): k, v; lane (bl, i): q), keep the inputs for the
     // parameter gradients
     if (k_on) {
@@ -484,6 +519,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         }
     }
     __syncthreads();
+    ATTN_STAMP(2);
     const float* kb = kL + bl * a.Lk * EM;
     const float* vb = vL + bl * a.Lk * EM;
     // phase 1: query row i = r -> gs (LDS), g_q, gradient of x_q
@@ -492,7 +528,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         const float* w = w_l + (bl * P + r) * kAttnPitch;
         float dot = 0.f;
         for (int j = 0; j < a.Lk; ++j) {
-            float gw = a.g_w ? a.g_w[row * a.Lk + j] : 0.f;
+            float gw = gs[j];                                      // (d loss / d weight, staged above; 0: none)
 #pragma unroll
             for (int d = 0; d < EM; ++d) gw = fmaf(go[d], vb[j * EM + d], gw);
             gs[j] = gw;
@@ -529,6 +565,7 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         }
     }
     __syncthreads();
+    ATTN_STAMP(3);
     // phase 2: key row j = r -> g_k, g_v (sums over the entry's queries), gradient of x_k
     if (k_on) {
         float gk[EM], gv[EM], gx[EM], gx2[EM];
@@ -567,24 +604,79 @@ __global__ __launch_bounds__(kAttnThreads) void k_attn_proj_bwd(const AttnProjAr
         }
     }
     __syncthreads();
-    // phase 3: this workgroup's partial parameter gradients (fixed order over its rows), packed for width E
+    ATTN_STAMP(4);
+    // phase 3: this workgroup's partial parameter gradients, packed for width E.  dW_m[o][c] = sum over the rows t of
+    // g_m[t][o] x_m[t][c] on the matrix pipe (16x16x4 f32: A[m = o][k = t], B[k = t][n = c], four rows a step; E <= 8: two
+    // matrices share a tile — o / c of the second in rows / columns 8..15, the mixed blocks are not stored): as a loop of
+    // one product per (o, c) and row with its two LDS reads this phase was 46 % of the launch (17.8 of 38.6 k clocks at
+    // 1 024 x 9 x 8, tools/debug/attn_bwd_phases.py).  Biases: plain sums in row order.
     const int nmat = a.wo ? 4 : 3, pblk = E * E + E;
     float* part = a.partial + (int64_t)blockIdx.x * nmat * pblk;
-    for (int idx = threadIdx.x; idx < nmat * pblk; idx += kAttnThreads) {
-        const int m = idx / pblk, rr = idx - m * pblk;
-        const float* g = m == 0 ? gqL : (m == 1 ? gkL : (m == 2 ? gvL : gzL));
-        const float* x = m == 0 ? xqL : (m == 3 ? ovL : xkL);
-        const int rows = nb * ((m == 0 || m == 3) ? a.Lq : a.Lk);
-        float acc = 0.f;
-        if (rr < E * E) {
-            const int oo = rr / E, c = rr - oo * E;
-            for (int t = 0; t < rows; ++t) acc = fmaf(g[t * EM + oo], x[t * EM + c], acc);
+    {
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const int lm = threadIdx.x & 15, lq = threadIdx.x >> 4;
+        constexpr bool PAIR = EM == 8;
+        auto outer = [&](const float* gA, const float* xA, const float* gB, const float* xB, int rows) -> f32x4 {
+            const bool second = PAIR && lm >= 8;
+            const float* gp = second ? gB + (lm - 8) : gA + lm;
+            const float* xp = second ? xB + (lm - 8) : xA + lm;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            constexpr int SB = 4;                      // steps whose operands are read before the first of their products
+            for (int t0 = 0; t0 < rows; t0 += 4 * SB) {
+                float av[SB], bv[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int t = t0 + 4 * u + lq, tc = min(t, rows - 1);
+                    av[u] = gp[tc * EM];
+                    bv[u] = xp[tc * EM];
+                    av[u] = t < rows ? av[u] : 0.f;    // (rows beyond the workgroup's: no contribution)
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            }
+            return acc;
+        };
+        auto store = [&](const f32x4& acc, int mA, int mB) {       // D[4 lq + r][lm] -> the matrices' blocks of the slab
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mrow = 4 * lq + r;
+                if (PAIR) {
+                    const bool second = lm >= 8;
+                    if ((mrow >= 8) != second) continue;            // (a mixed block: g of one matrix with x of the other)
+                    const int o = mrow & 7, c = lm & 7, mi = second ? mB : mA;
+                    if (mi >= 0 && o < E && c < E) part[mi * pblk + o * E + c] = acc[r];
+                } else if (mrow < E && lm < E) {
+                    part[mA * pblk + mrow * E + lm] = acc[r];
+                }
+            }
+        };
+        if (PAIR) {
+            store(outer(gqL, xqL, gzL, ovL, nb * a.Lq), 0, a.wo ? 3 : -1);
+            store(outer(gkL, xkL, gvL, xkL, nb * a.Lk), 1, 2);
         } else {
-            const int oo = rr - E * E;
-            for (int t = 0; t < rows; ++t) acc += g[t * EM + oo];
+            store(outer(gqL, xqL, gqL, xqL, nb * a.Lq), 0, -1);
+            store(outer(gkL, xkL, gkL, xkL, nb * a.Lk), 1, -1);
+            store(outer(gvL, xkL, gvL, xkL, nb * a.Lk), 2, -1);
+            if (a.wo) store(outer(gzL, ovL, gzL, ovL, nb * a.Lq), 3, -1);
         }
-        part[idx] = acc;
     }
+    for (int idx = threadIdx.x; idx < nmat * EM; idx += kAttnThreads) {
+        const int m = idx / EM, oo = idx - m * EM;
+        if (oo >= E) continue;
+        const float* g = m == 0 ? gqL : (m == 1 ? gkL : (m == 2 ? gvL : gzL));
+        const int rows = nb * ((m == 0 || m == 3) ? a.Lq : a.Lk);
+        constexpr int UB = 6;
+        float acc = 0.f;
+        for (int t0 = 0; t0 < rows; t0 += UB) {
+            float gv[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) gv[u] = g[min(t0 + u, rows - 1) * EM + oo];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) acc = t0 + u < rows ? acc + gv[u] : acc;
+        }
+        part[m * pblk + E * E + oo] = acc;
+    }
+    ATTN_STAMP(5);
 }
 
 // grad[i] (+)= sum over workgroups of partial[block][i]: 64 parameters per workgroup, 16 slices of blocks
