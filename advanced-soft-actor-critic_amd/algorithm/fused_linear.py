@@ -104,13 +104,25 @@ class _LinearTanhFn(torch.autograd.Function):
         if (direct_enabled() and weight.requires_grad and bias.requires_grad and weight.grad is not None
                 and bias.grad is not None):
             flat = _flat_alias([weight.grad, bias.grad])     # the learner's flat gradient buffer: add in place
+        from .fused_mlp import DeferredPartialSums
+        later = DeferredPartialSums.active()      # (the workgroups' partials summed with the walk's other second launches)
+        if later is not None:
+            ws = torch.empty(native.linear_tanh_workspace(N, K, O), dtype=dt, device=dev)      # (kept until the flush)
         if flat is not None:
-            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, flat, True, ws, members, window, position)
+            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, flat,
+                                         native.SUM_DEFER if later is not None else True, ws, members, window, position)
             gw = gb = None
+            if later is not None:
+                later.add(ws, (N + 63) // 64, 16, O * K + O, O * K + O, flat, accumulate=True)
         else:
             g = torch.empty(O * K + O, dtype=dt, device=dev)
-            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, g, False, ws, members, window, position)
+            native.linear_tanh_backward2(r0, r1, weight.detach(), y, gy, gx0, gx1, g,
+                                         native.SUM_DEFER if later is not None else False, ws, members, window, position)
             gw, gb = g[:O * K].view(O, K), g[O * K:]
+            if later is not None:       # (the gradients reach the caller through `later.flush()`)
+                later.add(ws, (N + 63) // 64, 16, O * K + O, O * K + O, g)
+                later.record([weight, bias], [gw, gb])
+                gw = gb = None
         return (None if gx0 is None else gx0.view(ctx.x0_shape), None if gx1 is None else gx1.view(ctx.x1_shape),
                 gw, gb, None, None)
 

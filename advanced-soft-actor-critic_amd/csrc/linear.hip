@@ -19,7 +19,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kLinMaxK = ASAC_LINEAR_TANH_MAX_IN;      // 64
 constexpr int kLinMaxO = ASAC_LINEAR_TANH_MAX_OUT;     // 16
 constexpr int kLinRows = 64, kLinThreads = 256;        // rows per workgroup (4 waves: one 16-row tile each)
-constexpr int64_t kLinTailMax = 12288;                 // partial floats (workgroups x O (K + 1)) the last workgroup sums itself
+#ifndef ASAC_LIN_TAIL_MAX
+#define ASAC_LIN_TAIL_MAX 12288
+#endif
+constexpr int64_t kLinTailMax = ASAC_LIN_TAIL_MAX;
+constexpr int64_t kLinTailBlocks = 48;                 // workgroups the last one still sums faster than a second launch would                 // partial floats (workgroups x O (K + 1)) the last workgroup sums itself
 
 struct LinArgs {
     const float* x;         // the input rows: x [N][K0] | x1 [N][K - K0] side by side (x1 NULL: K0 == K) — the
@@ -322,11 +326,15 @@ int asac_linear_tanh_backward2w(const float* x0, int64_t x0_row_stride, int x0_w
     a.gy_position = grad_position, a.gx = grad_x0, a.gx1 = grad_x1, a.gp = grad_params, a.accumulate = accumulate;
     a.partial = workspace;
     a.counter = reinterpret_cast<unsigned int*>(workspace + blocks * (int64_t)O * (K + 1));
-    if (blocks * O * (K + 1) <= kLinTailMax) {
+    // the last workgroup sums the partials itself while there are few of them (sixteen agent-scope loads a round: 144
+    // workgroups' tail took 6.4 us, more than the reduction launch it saves); ASAC_LINEAR_SUM_DEFER: the sums are left to
+    // asac_sum_partials_multi
+    if (accumulate != ASAC_LINEAR_SUM_DEFER && blocks <= kLinTailBlocks && blocks * O * (K + 1) <= kLinTailMax) {
         ASAC_LAUNCH(k_linear_tanh_bwd<true>, dim3((unsigned)blocks), dim3(kLinThreads), 0, as_stream(stream), a);
     } else {
         ASAC_LAUNCH(k_linear_tanh_bwd<false>, dim3((unsigned)blocks), dim3(kLinThreads), 0, as_stream(stream), a);
-        xty_reduce_launch(workspace, (int)blocks, O * K, O, grad_params, grad_params + O * K, accumulate, as_stream(stream));
+        if (accumulate != ASAC_LINEAR_SUM_DEFER)
+            xty_reduce_launch(workspace, (int)blocks, O * K, O, grad_params, grad_params + O * K, accumulate, as_stream(stream));
     }
     return finish_launch("asac_linear_tanh_backward");
 }

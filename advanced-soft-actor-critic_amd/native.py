@@ -1470,7 +1470,7 @@ def linear_tanh_backward2(x0, x1, weight, y, grad_y, grad_x0, grad_x1, grad_para
     assert grad_y.numel() == members * (N // window) * O and N % window == 0
     _check(load().asac_linear_tanh_backward2w(p0, s0, T, sb, K0, p1, s1, 0 if x1 is None else x1.shape[1], _p(weight),
                                               _p(y), _p(grad_y), members, window, position, N, O, _p(grad_x0),
-                                              _p(grad_x1), _p(grad_params), int(bool(accumulate)), _p(workspace),
+                                              _p(grad_x1), _p(grad_params), _sum_mode(accumulate), _p(workspace),
                                               _stream()), 'asac_linear_tanh_backward2')
 
 

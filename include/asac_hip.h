@@ -1313,12 +1313,14 @@ int asac_rows_wide_backward_params(const float* dpre, const float* x, int64_t x_
  * ASAC_MLP_REDUCE_DEFER / accumulate == ASAC_ATTN_SUM_DEFER:
  *   asac_mlp_backward             [tiles = asac_mlp_backward_tiles(N, E)][E][member_stride], n = asac_mlp_param_extent(desc)
  *   asac_attention_proj_backward  [blocks][n], n = (3 | 4) (E E + E), blocks = asac_attention_proj_workspace / (4 (E E + E))
+ *   asac_linear_tanh_backward*    (accumulate == ASAC_LINEAR_SUM_DEFER)  [blocks = ceil(N / 64)][n = O K + O]; 16 slices
  *   asac_conv2_backward(_windows / _multi)  (accumulate == ASAC_CONV_SUM_DEFER)  [blocks][n], n = n_cot x the packed parameter
  *                                 count, blocks = asac_conv2_backward_slabs(desc, N, n_cot); 16 slices
  * jobs_host: a HOST array. */
 #define ASAC_SUM_PARTIALS_MAX_JOBS 16
 #define ASAC_ATTN_SUM_DEFER 2
 #define ASAC_CONV_SUM_DEFER 2
+#define ASAC_LINEAR_SUM_DEFER 2
 typedef struct {
     const float* partial;
     float* out;

@@ -164,3 +164,29 @@ def test_a_stack_used_twice_in_one_walk_gets_both_contributions():
     late = later.flush()[0]
     for p, w in zip(params, want):
         np.testing.assert_allclose(late[id(p)].cpu().numpy(), w.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_linear_tanh_head_defers_its_sums_too():
+    """the fused Linear + Tanh state head under `DeferredPartialSums`: no reduction of its own, the flushed gradients equal the
+    undeferred ones to rounding (another grouping of the same workgroup partials)"""
+    import asac_amd  # noqa: F401
+    from asac_amd import native
+    from algorithm.fused_linear import fuse_linear_tanh_heads
+    from algorithm.fused_mlp import DeferredPartialSums
+    torch.manual_seed(0)
+    model = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(18, 8), torch.nn.Tanh())]).cuda()
+    assert fuse_linear_tanh_heads(model) == 1
+    head = model[0]
+    x = torch.randn(9216, 18, device='cuda', requires_grad=True)
+    y = head(x)
+    gy = torch.randn_like(y)
+    params = list(head.parameters())
+    want = torch.autograd.grad(y, [x] + params, grad_outputs=gy, retain_graph=True)
+    with native.LaunchProfiler(repeat=1) as prof:
+        with DeferredPartialSums() as later:
+            got = torch.autograd.grad(y, [x] + params, grad_outputs=gy, retain_graph=True, allow_unused=True)
+        late = later.flush()[0]
+    assert torch.equal(got[0], want[0]) and got[1] is None and got[2] is None
+    assert prof.summary()['asac_sum_partials_multi']['calls'] == 1
+    for p, w in zip(params, want[1:]):
+        np.testing.assert_allclose(late[id(p)].cpu().numpy(), w.cpu().numpy(), rtol=2e-5, atol=2e-5)
