@@ -279,11 +279,17 @@ __global__ __launch_bounds__(kMseThreads) void k_mse_big(const float* __restrict
     __syncthreads();
     if (!last) return;
     // fixed order: lane t adds partials [8 t, 8 t + 8) in turn, then the tree above
-    float v = 0.f;
-    for (int j = 0; j < kMseBigGrid / kMseThreads; ++j) {
-        const unsigned int w = threadIdx.x * (kMseBigGrid / kMseThreads) + j;
-        if (w < gridDim.x) v += __hip_atomic_load(partial + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (all eight requested before the first is added: one by one each waited for its own trip to memory)
+    constexpr int PER = kMseBigGrid / kMseThreads;
+    float t[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const unsigned int w = min(threadIdx.x * PER + j, gridDim.x - 1);
+        t[j] = __hip_atomic_load(partial + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v += threadIdx.x * PER + j < gridDim.x ? t[j] : 0.f;
     red[threadIdx.x] = v;
     __syncthreads();
     for (int w = kMseThreads / 2; w > 0; w >>= 1) {
